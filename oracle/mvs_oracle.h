@@ -1,0 +1,160 @@
+/*
+ * mvs_oracle.h -- CPU ORACLE for the mvSLAM two-view-geometry hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.  The product path
+ * (mvslam_amd/, include/) never links, imports or executes anything under oracle/.
+ *
+ * It is a plain-C restatement (no copied source) of the reference algorithm, each
+ * function citing the reference file:line it follows (paths relative to the
+ * reference tree).  Arithmetic that the reference delegates to OpenCV
+ * (cv::SVDecomp, cv::BFMatcher::knnMatch; OpenCV >= 3.0, version unpinned by the
+ * reference, README.md:12) is restated from OpenCV's published algorithm
+ * (one-sided Hestenes/Jacobi SVD, modules/core/src/lapack.cpp JacobiSVDImpl_;
+ * brute-force k-NN insertion rule, modules/core/src/batch_distance.cpp).
+ *
+ * PARITY PINNING: the oracle is pinned by the reference's own known-answer tests
+ * that are reachable without OpenCV/Eigen/GTSAM (test/test-svd.cpp,
+ * test/test-sfm.cpp sfm_triangulate_cube + decomposition of the cube's analytic E,
+ * test/test-lie-group.cpp, test/test-camera.cpp) -- see tests/test_oracle_kat.py.
+ * The 8-point RANSAC estimator itself is PARITY-UNPINNED by the reference (its
+ * only fixture is a degenerate configuration and the default build bypasses it,
+ * SURVEY.md section 0); it is pinned here by analytic ground truth (L-shape rig)
+ * and LAPACK cross-checks.
+ *
+ * ARITHMETIC CONTRACT (shared, by specification only, with the HIP kernels):
+ * IEEE-754 binary64, round-to-nearest-even, no contraction except where fma()
+ * is written explicitly, no reassociation.  Build with -ffp-contract=off.
+ */
+#ifndef MVS_ORACLE_H
+#define MVS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout of cv::DMatch (base/image.hpp:37-48 -> MatchResultType) */
+typedef struct {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} orc_match;
+
+#define ORC_SAMPLER_IDENTITY 0 /* reference behaviour: index[0..7] (estimator-RANSAC.cpp:41-48) */
+#define ORC_SAMPLER_PHILOX 1   /* Philox4x32-10 keyed (seed, hypothesis id) */
+
+typedef struct {
+    int64_t rotations9; /* executed 9x9 Jacobi rotations */
+    int64_t pairs9;     /* visited 9x9 (i,j) pairs (rotated or skipped) */
+    int64_t rotations3;
+    int64_t pairs3;
+    int64_t rotations4;
+    int64_t pairs4;
+    int64_t hypotheses;
+    int64_t score_evals; /* hypothesis x point residual evaluations */
+} orc_counters;
+
+void orc_counters_reset(void);
+void orc_counters_get(orc_counters *out);
+
+/* ---- math/lie-group.{hpp,cpp} ---- */
+void orc_so3_rectify(double R[9]);                              /* lie-group.hpp:84-96 */
+void orc_so3_from_matrix(const double M[9], double R[9]);       /* lie-group.hpp:31-36 */
+void orc_so3_from_rpy(double roll, double pitch, double yaw, double R[9]); /* :41-56 */
+void orc_so3_ln(const double R[9], double w[3]);                /* lie-group.hpp:138-162 */
+void orc_rodrigues(const double v[3], double R[9]);             /* lie-group.cpp:15-32 */
+void orc_se3_inverse(const double R[9], const double t[3], double Ro[9], double to[3]); /* hpp:212-216 */
+void orc_se3_compose(const double Ra[9], const double ta[3], const double Rb[9], const double tb[3],
+                     double Ro[9], double to[3]);               /* hpp:229-234 */
+void orc_se3_ln(const double R[9], const double t[3], double se3[6]);  /* hpp:245-269 */
+void orc_se3_exp(const double se3[6], double R[9], double t[3]);       /* hpp:275-299 */
+
+/* ---- math/svd.hpp:59-72 == cv::SVDecomp(A, w, u, vt, MODIFY_A | FULL_UV) ---- */
+/* A: m x n row-major. w: min(m,n). u: m x m. vt: n x n. */
+void orc_svd(const double *A, int m, int n, double *w, double *u, double *vt);
+
+/* ---- vision/camera.cpp ---- */
+void orc_mat3_inverse(const double K[9], double Kinv[9]);                 /* camera.cpp:16 */
+void orc_normalize_points(const double Kinv[9], const double *uv, int n, double *xy); /* :55-79 */
+int orc_project_point(const double K[9], const double Rw2c[9], const double tw2c[3],
+                      const double X[3], double uv[2]);                   /* camera.cpp:24-37 */
+
+/* ---- vision/visual-feature.cpp:51-80 ---- */
+/* returns number of matches written to out (<= n_query), or -1 on precondition failure */
+int orc_match_visual_features(const uint8_t *train_desc, int n_train, const uint8_t *query_desc, int n_query,
+                              int desc_bytes, double ratio, double max_dist, orc_match *out);
+
+/* ---- vision/fundamental-matrix.cpp:204-267 ---- */
+/* p1, p2: 8 points (x, y) with implicit homogeneous 1.  returns 1 on success. */
+int orc_find_fundamental_matrix(const double p1[16], const double p2[16], double F[9]);
+
+/* sampler (the reference has none: estimator-RANSAC.cpp:41-42) */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_sample8(uint64_t seed, uint32_t hyp, int M, int sampler, int idx[8]);
+
+/* ---- vision/estimator-RANSAC.cpp:16-129 ---- */
+/* p1, p2: M x (x, y).  mask: M bytes.  returns 1 if best_count > 0.
+ * per_hyp_count / per_hyp_residual: optional [H] tables (may be NULL). */
+int orc_ransac_fundamental(const double *p1, const double *p2, int M, double max_error_sq, int H, int sampler,
+                           uint64_t seed, double F[9], uint8_t *mask, int *best_hyp, int *best_count,
+                           double *best_residual, int32_t *per_hyp_count, double *per_hyp_residual);
+int orc_count_inliers(const double *p1, const double *p2, int M, const double F[9], double max_error_sq,
+                      uint8_t *mask, double *residual); /* estimator-RANSAC.cpp:100-129 */
+
+/* ---- vision/sfm-solve.cpp ---- */
+void orc_project_essential(const double F[9], double E[9]);             /* sfm-solve.cpp:74-84 */
+void orc_decompose_essential(const double E[9], double Ra[9], double Rb[9], double t[3]); /* :97-127 */
+int orc_triangulate_points(const double R[9], const double t[3], const double *p1, const double *p2, int M,
+                           const uint8_t *mask, double *points, int64_t *idx); /* :134-227 */
+int orc_recover_pose_and_points(const double E[9], const double *p1, const double *p2, int M,
+                                const uint8_t *mask, double R[9], double t[3], double *points,
+                                int64_t *idx, int *n_points);             /* :232-284 */
+
+typedef struct {
+    double max_error_sq; /* <= 0: derive 5e-2 / K00 / K11 (sfm-solve.cpp:18-19,311) */
+    int32_t num_hypotheses;
+    int32_t sampler;
+    uint64_t seed;
+    int32_t min_inliers; /* 8 (sfm-solve.cpp:20-21) */
+} orc_params;
+
+typedef struct {
+    int32_t valid;
+    int32_t n_matches; /* M */
+    int32_t n_inliers;
+    int32_t n_points;
+    int32_t best_hyp;
+    int32_t best_count;
+    double best_residual;
+    double F[9];
+    double E[9];
+    double R1to2[9];
+    double t1to2[3];
+    double R[9]; /* pose2in1 = SE3(SO3(R1to2), t1to2).inverse() */
+    double t[3];
+} orc_two_view_result;
+
+/* sfm_solve (sfm-solve.cpp:285-368).  uv1/uv2: M x (u, v) image points.  returns 1 (true) / 0. */
+int orc_sfm_solve(const double *uv1, const double *uv2, int M, const double K[9], const orc_params *prm,
+                  orc_two_view_result *res, uint8_t *mask, double *points, int64_t *idx);
+
+/* sfm_triangulate (sfm-solve.cpp:370-394); poses are camera-in-world. returns n_points */
+int orc_sfm_triangulate(const double *uv1, const double *uv2, int M, const double K[9], const double R1[9],
+                        const double t1[3], const double R2[9], const double t2[3], double *points,
+                        int64_t *idx);
+
+/* ImagePair ctor + reconstruct (front-end/image-pair.cpp:30-71,116-174): match(base=train, pair=query)
+ * -> gather keypoints -> sfm_solve.  kp: N x (x, y) float.  matches: capacity n_pair. */
+int orc_image_pair(const uint8_t *base_desc, const float *base_kp, int n_base, const uint8_t *pair_desc,
+                   const float *pair_kp, int n_pair, int desc_bytes, double ratio, double max_dist,
+                   const double K[9], const orc_params *prm, orc_match *matches, orc_two_view_result *res,
+                   uint8_t *mask, double *points, int64_t *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
