@@ -1,0 +1,192 @@
+/*
+ * mvslam_hip.h -- C ABI of libmvslam_hip.so: mvSLAM's front-end two-view geometry
+ * hot path (brute-force Hamming match -> 8-point RANSAC -> essential decomposition
+ * -> linear triangulation) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (lonelycorn/mvSLAM) has no FFI layer: its boundary for this path is
+ * a set of C++ free functions / static methods in namespace mvSLAM.  Every entry
+ * point below names the reference interface it stands in for (file:line relative
+ * to the reference tree).  The C++ header shim that keeps the reference's own
+ * signatures on top of this ABI lives in mvslam_amd/compat/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - all pointers are caller-owned HOST memory unless the name says "device";
+ *   - matrices are row-major double (reference ScalarType = double, system-config.hpp:6);
+ *   - every call returns an mvs_status; nothing here aborts or throws
+ *     (the reference asserts on precondition violations, e.g. sfm-solve.cpp:37-41);
+ *   - one mvs_ctx per (host thread, GPU); calls on one ctx are serialised by the caller
+ *     (the reference path is single-threaded and not re-entrant, visual-feature.cpp:12-25).
+ *   - there is NO CPU fallback: without a HIP device mvs_ctx_create fails.
+ */
+#ifndef MVSLAM_HIP_H
+#define MVSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_ABI_VERSION 1
+
+typedef enum mvs_status {
+    MVS_OK = 0,
+    MVS_NO_MODEL = 1,          /* the reference's `return false` (sfm-solve.cpp:319-321,330-334,353-356) */
+    MVS_ERR_INVALID_ARG = -1,  /* the reference's assert()s */
+    MVS_ERR_NO_DEVICE = -2,
+    MVS_ERR_HIP = -3,
+    MVS_ERR_CAPACITY = -4,
+    MVS_ERR_BAD_INTRINSICS = -5 /* K must be affine: K[6..8] == (0, 0, 1) */
+} mvs_status;
+
+/* layout-identical to cv::DMatch (reference MatchResultType, base/image.hpp:37-48) */
+typedef struct mvs_match {
+    int32_t queryIdx; /* index into vf2 / pair frame */
+    int32_t trainIdx; /* index into vf1 / base frame */
+    int32_t imgIdx;
+    float distance;
+} mvs_match;
+
+#define MVS_SAMPLER_IDENTITY 0 /* reference behaviour: the first 8 matches (estimator-RANSAC.cpp:41-48) */
+#define MVS_SAMPLER_PHILOX 1   /* Philox4x32-10 keyed (seed, hypothesis id) */
+
+/* Knobs of the path */
+typedef struct mvs_params {
+    double ratio;           /* Lowe ratio, 0.7 as ScalarType = double (visual-feature.cpp:23) */
+    double max_dist;        /* max Hamming distance of a match, < 0 disables (image-pair.cpp:22-23: 10) */
+    double max_error_sq;    /* <= 0: 5e-2 / K00 / K11 (sfm-solve.cpp:18-19,311) */
+    int32_t num_hypotheses; /* reference: 1 (sfm-solve.cpp:67) */
+    int32_t sampler;        /* MVS_SAMPLER_* */
+    uint64_t seed;          /* hypothesis sampler key; pair p of a batch uses seed + global_index[p] */
+    int32_t min_inliers;    /* 8 (sfm-solve.cpp:20-21,330) */
+    int32_t reserved;
+} mvs_params;
+
+/* Fixed-size per-pair result (what ImagePair keeps after reconstruct(), image-pair.hpp:56-64) */
+typedef struct mvs_pair_result {
+    int32_t valid;      /* ImagePair::valid */
+    int32_t n_matches;  /* M: matches surviving ratio / max_dist */
+    int32_t n_inliers;  /* inliers of the winning hypothesis */
+    int32_t n_points;   /* triangulated points that passed cheirality = match_inlier_count */
+    int32_t best_hyp;   /* winning hypothesis id (-1: none) */
+    int32_t best_count;
+    double best_residual;
+    double F[9];        /* winning fundamental (= essential on ideal cameras) before projection */
+    double E[9];        /* after projection to (s, s, 0) (sfm-solve.cpp:74-84) */
+    double R1to2[9];    /* winning candidate of decompose_essential_matrix */
+    double t1to2[3];
+    double R[9];        /* pose2in1 = SE3(SO3(R1to2), t1to2).inverse() (sfm-solve.cpp:364) = T_pair_to_base */
+    double t[3];
+} mvs_pair_result;
+
+typedef struct mvs_ctx mvs_ctx;
+typedef struct mvs_batch mvs_batch;
+
+/* ---- context ------------------------------------------------------------------ */
+int mvs_abi_version(void);
+const char *mvs_status_str(mvs_status s);
+const char *mvs_last_error(const mvs_ctx *ctx); /* text of the last HIP failure on this ctx */
+mvs_status mvs_params_default(mvs_params *p);   /* reference defaults + num_hypotheses = 1, identity sampler */
+mvs_status mvs_ctx_create(int device_id, mvs_ctx **out);
+mvs_status mvs_ctx_create_on_stream(int device_id, void *hip_stream, mvs_ctx **out); /* borrow a stream */
+void mvs_ctx_destroy(mvs_ctx *ctx);
+void *mvs_ctx_stream(mvs_ctx *ctx); /* hipStream_t the kernels are launched on */
+
+/* ---- single-shot entry points (host buffers; the reference's call surface) ------ */
+
+/* VisualFeature::match_visual_features(vf1 = train, vf2 = query, max_dist)
+ * (vision/visual-feature.cpp:51-80, decl visual-feature.hpp:23-26).
+ * desc: n x desc_bytes row-major CV_8U (desc_bytes multiple of 4, <= 64).
+ * out: capacity n_query.  Output order: (distance, queryIdx) ascending.
+ * MVS_ERR_INVALID_ARG when n_train < 2 or n_query < 1 (reference: assert / UB). */
+mvs_status mvs_match_hamming(mvs_ctx *ctx, const uint8_t *train_desc, int n_train, const uint8_t *query_desc,
+                             int n_query, int desc_bytes, double ratio, double max_dist, mvs_match *out,
+                             int *n_out);
+
+/* sfm_solve(p1, p2, K, pose2in1, points, point_indexes) (vision/sfm-solve.cpp:285-368, decl sfm.hpp:30-35)
+ * with find_essential_matrix's own-RANSAC branch (sfm-solve.cpp:64-90).
+ * p1_uv / p2_uv: m x (u, v) image points.  points_xyz: capacity 3*m.  point_idx: capacity m.
+ * inlier_mask: capacity m (may be NULL).  result: may be NULL.
+ * returns MVS_OK (true) or MVS_NO_MODEL (false). */
+mvs_status mvs_two_view(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, int m, const double K[9],
+                        const mvs_params *params, double R[9], double t[3], double *points_xyz,
+                        int64_t *point_idx, int *n_points, uint8_t *inlier_mask, mvs_pair_result *result);
+
+/* sfm_triangulate(p1, p2, K, pose1, pose2, points, point_indexes) (sfm-solve.cpp:370-394, decl sfm.hpp:47-53).
+ * R1to2 / t1to2 = (pose2^-1 * pose1), composed by the caller-side shim exactly as the reference does. */
+mvs_status mvs_triangulate(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, int m, const double K[9],
+                           const double R1to2[9], const double t1to2[3], double *points_xyz, int64_t *point_idx,
+                           int *n_points);
+
+/* recover_pose_and_points(E, ...) + pose inverse (sfm-solve.cpp:232-284,364): the tail of sfm_solve for a
+ * caller-supplied essential matrix and inlier mask (mask may be NULL = all ones).  Not public in the
+ * reference; exported so the cube fixture (test/test-sfm.cpp:17-90) can pin decomposition + triangulation. */
+mvs_status mvs_recover_pose(mvs_ctx *ctx, const double E[9], const double *p1_uv, const double *p2_uv, int m,
+                            const double K[9], const uint8_t *inlier_mask, double R[9], double t[3],
+                            double *points_xyz, int64_t *point_idx, int *n_points, mvs_pair_result *result);
+
+/* find_fundamental_matrix(p1_sample, p2_sample, F21) (vision/fundamental-matrix.cpp:204-267, hpp:16-19).
+ * p1 / p2: 8 x (x, y) ideal-camera points (homogeneous 1).  MVS_NO_MODEL for a degenerate sample. */
+mvs_status mvs_find_fundamental_matrix(mvs_ctx *ctx, const double p1_xy[16], const double p2_xy[16], double F[9]);
+
+/* FundamentalMatrixEstimatorRANSAC(max_error_sq, max_iteration).compute(p1, p2, F21, inlier_mask)
+ * (vision/estimator-RANSAC.cpp:16-90, hpp:20-24).  p1 / p2: m x (x, y) ideal-camera points.
+ * count / residual: optional per-hypothesis tables [num_hypotheses] (count -1 = rejected sample). */
+mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const double *p2_xy, int m,
+                                  double max_error_sq, int num_hypotheses, int sampler, uint64_t seed, double F[9],
+                                  uint8_t *inlier_mask, int *best_hyp, int *best_count, double *best_residual,
+                                  int32_t *count, double *residual);
+
+/* ---- batched, device-resident pipeline ("one image pair" = ImagePair ctor + reconstruct,
+ *      front-end/image-pair.cpp:30-71,116-174, without refine()) ---------------------- */
+
+/* capacity: n_pairs pairs, max_kp keypoints per image (<= 4096), desc_bytes per descriptor. */
+mvs_status mvs_batch_create(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_bytes, mvs_batch **out);
+void mvs_batch_destroy(mvs_batch *b);
+
+/* Upload pairs [first, first + count).  base = vf1 = train, pair = vf2 = query.
+ * desc: count x max_kp x desc_bytes (rows >= n are ignored); kp: count x max_kp x (x, y) float (cv::KeyPoint::pt);
+ * n_base / n_pair: count;  K: count x 9;  global_index: count (NULL = first + i), added to params.seed. */
+mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
+                            const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
+                            const int32_t *n_pair, const double *K, const int64_t *global_index);
+
+/* Enqueue the whole pipeline for pairs [0, n_active) on the ctx stream (asynchronous). */
+mvs_status mvs_batch_run(mvs_batch *b, const mvs_params *params, int n_active);
+mvs_status mvs_batch_sync(mvs_batch *b);
+
+/* Timed replay: `warmup` untimed + `steps` timed passes over the resident inputs, bracketed by HIP events
+ * on the ctx stream.  ms_total: wall ms of the `steps` passes.  ms_kernel[5]: summed ms per kernel over the
+ * timed passes, in launch order {match_topk, match_compact, ransac, finalize, reserved}; measured with
+ * per-kernel events in a SEPARATE instrumented replay of `steps` passes (so ms_total has no event overhead).
+ * Either output may be NULL. */
+mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, int warmup, int steps,
+                          float *ms_total, float *ms_kernel);
+
+/* Results (host).  Any pointer may be NULL.  results: count;  matches: count x max_kp;  mask: count x max_kp;
+ * points: count x max_kp x 3;  point_idx: count x max_kp. */
+mvs_status mvs_batch_download(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                              uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx);
+
+/* Work statistics of the last run (for the roofline's algorithmic flop count): executed 9x9 Jacobi rotations,
+ * visited 9x9 pairs, hypotheses, hypothesis x point evaluations, summed over pairs [0, n_active).
+ * Collected by an instrumented replay outside any timed region. */
+typedef struct mvs_work_stats {
+    int64_t hypotheses;
+    int64_t rotations9;
+    int64_t pairs9;
+    int64_t score_evals;
+    int64_t matches; /* sum of M */
+    int64_t inliers; /* sum of n_inliers */
+} mvs_work_stats;
+mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
+
+/* Device pointer + pitch of the fixed-size result records (mvs_pair_result[n_pairs]) so a caller can hand them
+ * to a collective (RCCL all-gather of poses) without a host round trip. */
+mvs_status mvs_batch_results_device(mvs_batch *b, void **dev_ptr, size_t *record_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSLAM_HIP_H */

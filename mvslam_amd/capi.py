@@ -1,0 +1,337 @@
+"""ctypes binding of libmvslam_hip.so (include/mvslam_hip.h).
+
+Plumbing only: it forwards numpy buffers to the C ABI and never computes anything itself.
+There is no CPU fallback -- if the HIP library is missing or no device is present the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmvslam_hip.so")
+
+MVS_OK = 0
+MVS_NO_MODEL = 1
+SAMPLER_IDENTITY = 0
+SAMPLER_PHILOX = 1
+
+MATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("ratio", C.c_double),
+        ("max_dist", C.c_double),
+        ("max_error_sq", C.c_double),
+        ("num_hypotheses", C.c_int32),
+        ("sampler", C.c_int32),
+        ("seed", C.c_uint64),
+        ("min_inliers", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class PairResult(C.Structure):
+    _fields_ = [
+        ("valid", C.c_int32),
+        ("n_matches", C.c_int32),
+        ("n_inliers", C.c_int32),
+        ("n_points", C.c_int32),
+        ("best_hyp", C.c_int32),
+        ("best_count", C.c_int32),
+        ("best_residual", C.c_double),
+        ("F", C.c_double * 9),
+        ("E", C.c_double * 9),
+        ("R1to2", C.c_double * 9),
+        ("t1to2", C.c_double * 3),
+        ("R", C.c_double * 9),
+        ("t", C.c_double * 3),
+    ]
+
+
+RESULT_DTYPE = np.dtype([
+    ("valid", "<i4"), ("n_matches", "<i4"), ("n_inliers", "<i4"), ("n_points", "<i4"), ("best_hyp", "<i4"),
+    ("best_count", "<i4"), ("best_residual", "<f8"), ("F", "<f8", (3, 3)), ("E", "<f8", (3, 3)),
+    ("R1to2", "<f8", (3, 3)), ("t1to2", "<f8", (3,)), ("R", "<f8", (3, 3)), ("t", "<f8", (3,))])
+assert RESULT_DTYPE.itemsize == C.sizeof(PairResult)
+
+
+class WorkStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers")]
+
+
+EXPORTS = [
+    "mvs_abi_version", "mvs_status_str", "mvs_last_error", "mvs_params_default", "mvs_ctx_create",
+    "mvs_ctx_create_on_stream", "mvs_ctx_destroy", "mvs_ctx_stream", "mvs_match_hamming", "mvs_two_view",
+    "mvs_triangulate", "mvs_recover_pose", "mvs_find_fundamental_matrix", "mvs_ransac_fundamental",
+    "mvs_batch_create", "mvs_batch_destroy", "mvs_batch_upload", "mvs_batch_run", "mvs_batch_sync",
+    "mvs_batch_time", "mvs_batch_download", "mvs_batch_stats", "mvs_batch_results_device",
+]
+
+
+class MvsError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__("%s: status %d (%s)" % (what, status, status_str(status)))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmvslam_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C mvslam_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mvs_status_str.restype = C.c_char_p
+        _lib.mvs_last_error.restype = C.c_char_p
+        _lib.mvs_last_error.argtypes = [C.c_void_p]
+        _lib.mvs_ctx_stream.restype = C.c_void_p
+        _lib.mvs_ctx_stream.argtypes = [C.c_void_p]
+        _lib.mvs_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.mvs_batch_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def status_str(status):
+    return lib().mvs_status_str(C.c_int(status)).decode()
+
+
+def default_params(**kw):
+    p = Params()
+    lib().mvs_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """One mvs_ctx: one HIP stream on one GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        st = lib().mvs_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h))
+        if st != MVS_OK:
+            raise MvsError(st, "mvs_ctx_create")
+
+    def close(self):
+        if self._h:
+            lib().mvs_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().mvs_ctx_stream(self._h)
+
+    def _check(self, st, what, allow_no_model=False):
+        if st == MVS_OK or (allow_no_model and st == MVS_NO_MODEL):
+            return st
+        err = lib().mvs_last_error(self._h)
+        raise MvsError(st, what + (" [" + err.decode() + "]" if err else ""))
+
+    # VisualFeature::match_visual_features(vf1 = train, vf2 = query, max_dist)
+    def match_hamming(self, train_desc, query_desc, ratio=0.7, max_dist=-1.0):
+        train_desc = np.ascontiguousarray(train_desc, dtype=np.uint8)
+        query_desc = np.ascontiguousarray(query_desc, dtype=np.uint8)
+        nq = int(query_desc.shape[0])
+        out = np.zeros(max(nq, 1), dtype=MATCH_DTYPE)
+        n = C.c_int(0)
+        st = lib().mvs_match_hamming(
+            self._h, _ptr(train_desc, C.c_uint8), C.c_int(int(train_desc.shape[0])), _ptr(query_desc, C.c_uint8),
+            C.c_int(nq), C.c_int(int(train_desc.shape[1]) if train_desc.ndim == 2 else 0), C.c_double(ratio),
+            C.c_double(max_dist), out.ctypes.data_as(C.c_void_p), C.byref(n))
+        self._check(st, "mvs_match_hamming")
+        return out[:n.value].copy()
+
+    @staticmethod
+    def _unpack(res, mask, pts, idx, m):
+        r = np.frombuffer(bytes(res), dtype=RESULT_DTYPE)[0]
+        out = {k: (r[k].copy() if isinstance(r[k], np.ndarray) else r[k].item()) for k in RESULT_DTYPE.names}
+        out["valid"] = bool(out["valid"])
+        n = out["n_points"] if out["valid"] else 0
+        out["mask"] = None if mask is None else mask[:m].copy()
+        out["points"] = pts[:n].copy()
+        out["point_idx"] = idx[:n].copy()
+        return out
+
+    # sfm_solve(p1, p2, K, pose2in1, points, point_indexes)
+    def two_view(self, uv1, uv2, K, params):
+        uv1, uv2 = _f64(uv1).reshape(-1, 2), _f64(uv2).reshape(-1, 2)
+        m = len(uv1)
+        R, t = np.zeros(9), np.zeros(3)
+        pts = np.zeros((max(m, 1), 3))
+        idx = np.zeros(max(m, 1), dtype=np.int64)
+        mask = np.zeros(max(m, 1), dtype=np.uint8)
+        n = C.c_int(0)
+        res = PairResult()
+        st = lib().mvs_two_view(self._h, _ptr(uv1, C.c_double), _ptr(uv2, C.c_double), C.c_int(m),
+                                _ptr(_f64(K, (9,)), C.c_double), C.byref(params), _ptr(R, C.c_double),
+                                _ptr(t, C.c_double), _ptr(pts, C.c_double), _ptr(idx, C.c_int64), C.byref(n),
+                                _ptr(mask, C.c_uint8), C.byref(res))
+        self._check(st, "mvs_two_view", allow_no_model=True)
+        out = self._unpack(res, mask, pts, idx, m)
+        out["ok"] = st == MVS_OK
+        return out
+
+    # sfm_triangulate with T_1_to_2 composed by the caller
+    def triangulate(self, uv1, uv2, K, R1to2, t1to2):
+        uv1, uv2 = _f64(uv1).reshape(-1, 2), _f64(uv2).reshape(-1, 2)
+        m = len(uv1)
+        pts = np.zeros((max(m, 1), 3))
+        idx = np.zeros(max(m, 1), dtype=np.int64)
+        n = C.c_int(0)
+        st = lib().mvs_triangulate(self._h, _ptr(uv1, C.c_double), _ptr(uv2, C.c_double), C.c_int(m),
+                                   _ptr(_f64(K, (9,)), C.c_double), _ptr(_f64(R1to2, (9,)), C.c_double),
+                                   _ptr(_f64(t1to2, (3,)), C.c_double), _ptr(pts, C.c_double), _ptr(idx, C.c_int64),
+                                   C.byref(n))
+        self._check(st, "mvs_triangulate")
+        return pts[:n.value].copy(), idx[:n.value].copy()
+
+    def recover_pose(self, E, uv1, uv2, K, mask=None):
+        uv1, uv2 = _f64(uv1).reshape(-1, 2), _f64(uv2).reshape(-1, 2)
+        m = len(uv1)
+        R, t = np.zeros(9), np.zeros(3)
+        pts = np.zeros((max(m, 1), 3))
+        idx = np.zeros(max(m, 1), dtype=np.int64)
+        n = C.c_int(0)
+        res = PairResult()
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        st = lib().mvs_recover_pose(self._h, _ptr(_f64(E, (9,)), C.c_double), _ptr(uv1, C.c_double),
+                                    _ptr(uv2, C.c_double), C.c_int(m), _ptr(_f64(K, (9,)), C.c_double),
+                                    _ptr(mk, C.c_uint8), _ptr(R, C.c_double), _ptr(t, C.c_double),
+                                    _ptr(pts, C.c_double), _ptr(idx, C.c_int64), C.byref(n), C.byref(res))
+        self._check(st, "mvs_recover_pose", allow_no_model=True)
+        out = self._unpack(res, None, pts, idx, m)
+        out["ok"] = st == MVS_OK
+        return out
+
+    def find_fundamental_matrix(self, p1, p2):
+        p1, p2 = _f64(p1, (16,)), _f64(p2, (16,))
+        F = np.zeros((3, 3))
+        st = lib().mvs_find_fundamental_matrix(self._h, _ptr(p1, C.c_double), _ptr(p2, C.c_double),
+                                               _ptr(F, C.c_double))
+        self._check(st, "mvs_find_fundamental_matrix", allow_no_model=True)
+        return st == MVS_OK, F
+
+    def ransac_fundamental(self, p1, p2, max_error_sq, H, sampler=SAMPLER_PHILOX, seed=0, per_hyp=False):
+        p1, p2 = _f64(p1).reshape(-1, 2), _f64(p2).reshape(-1, 2)
+        m = len(p1)
+        F = np.zeros((3, 3))
+        mask = np.zeros(max(m, 1), dtype=np.uint8)
+        bh, bc, br = C.c_int(-1), C.c_int(0), C.c_double(0)
+        cnt = np.zeros(H, dtype=np.int32) if per_hyp else None
+        res = np.zeros(H, dtype=np.float64) if per_hyp else None
+        st = lib().mvs_ransac_fundamental(
+            self._h, _ptr(p1, C.c_double), _ptr(p2, C.c_double), C.c_int(m), C.c_double(max_error_sq), C.c_int(H),
+            C.c_int(sampler), C.c_uint64(seed), _ptr(F, C.c_double), _ptr(mask, C.c_uint8), C.byref(bh),
+            C.byref(bc), C.byref(br), _ptr(cnt, C.c_int32), _ptr(res, C.c_double))
+        self._check(st, "mvs_ransac_fundamental", allow_no_model=True)
+        out = dict(ok=st == MVS_OK, F=F, mask=mask[:m], best_hyp=bh.value, best_count=bc.value,
+                   best_residual=br.value)
+        if per_hyp:
+            out["count"], out["residual"] = cnt, res
+        return out
+
+
+class Batch:
+    """Device-resident batch of image pairs (ImagePair ctor + reconstruct per pair)."""
+
+    def __init__(self, ctx, n_pairs, max_kp, desc_bytes=32):
+        self.ctx, self.n_pairs, self.max_kp, self.desc_bytes = ctx, n_pairs, max_kp, desc_bytes
+        self._h = C.c_void_p()
+        st = lib().mvs_batch_create(ctx._h, C.c_int(n_pairs), C.c_int(max_kp), C.c_int(desc_bytes), C.byref(self._h))
+        ctx._check(st, "mvs_batch_create")
+
+    def close(self):
+        if self._h:
+            lib().mvs_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, first, base_desc, base_kp, n_base, pair_desc, pair_kp, n_pair, K, global_index=None):
+        count = len(n_base)
+        N, D = self.max_kp, self.desc_bytes
+        base_desc = np.ascontiguousarray(base_desc, dtype=np.uint8).reshape(count, N, D)
+        pair_desc = np.ascontiguousarray(pair_desc, dtype=np.uint8).reshape(count, N, D)
+        base_kp = np.ascontiguousarray(base_kp, dtype=np.float32).reshape(count, N, 2)
+        pair_kp = np.ascontiguousarray(pair_kp, dtype=np.float32).reshape(count, N, 2)
+        n_base = np.ascontiguousarray(n_base, dtype=np.int32)
+        n_pair = np.ascontiguousarray(n_pair, dtype=np.int32)
+        K = _f64(K)
+        if K.size == 9:
+            K = np.tile(K.reshape(1, 9), (count, 1))
+        K = np.ascontiguousarray(K.reshape(count, 9))
+        gi = None if global_index is None else np.ascontiguousarray(global_index, dtype=np.int64)
+        st = lib().mvs_batch_upload(self._h, C.c_int(first), C.c_int(count), _ptr(base_desc, C.c_uint8),
+                                    _ptr(base_kp, C.c_float), _ptr(n_base, C.c_int32), _ptr(pair_desc, C.c_uint8),
+                                    _ptr(pair_kp, C.c_float), _ptr(n_pair, C.c_int32), _ptr(K, C.c_double),
+                                    _ptr(gi, C.c_int64))
+        self.ctx._check(st, "mvs_batch_upload")
+
+    def run(self, params, n_active=None):
+        st = lib().mvs_batch_run(self._h, C.byref(params), C.c_int(n_active or self.n_pairs))
+        self.ctx._check(st, "mvs_batch_run")
+
+    def sync(self):
+        self.ctx._check(lib().mvs_batch_sync(self._h), "mvs_batch_sync")
+
+    def time(self, params, steps, warmup, n_active=None, per_kernel=True):
+        total = C.c_float(0)
+        kern = (C.c_float * 5)()
+        st = lib().mvs_batch_time(self._h, C.byref(params), C.c_int(n_active or self.n_pairs), C.c_int(warmup),
+                                  C.c_int(steps), C.byref(total), kern if per_kernel else None)
+        self.ctx._check(st, "mvs_batch_time")
+        names = ("match_topk", "match_compact", "ransac", "finalize")
+        return total.value, {n: kern[i] for i, n in enumerate(names)}
+
+    def stats(self, params, n_active=None):
+        ws = WorkStats()
+        st = lib().mvs_batch_stats(self._h, C.byref(params), C.c_int(n_active or self.n_pairs), C.byref(ws))
+        self.ctx._check(st, "mvs_batch_stats")
+        return {n: getattr(ws, n) for n, _ in WorkStats._fields_}
+
+    def download(self, first=0, count=None, matches=True, mask=True, points=True):
+        count = count or (self.n_pairs - first)
+        N = self.max_kp
+        res = np.zeros(count, dtype=RESULT_DTYPE)
+        mt = np.zeros((count, N), dtype=MATCH_DTYPE) if matches else None
+        mk = np.zeros((count, N), dtype=np.uint8) if mask else None
+        pts = np.zeros((count, N, 3)) if points else None
+        idx = np.zeros((count, N), dtype=np.int64) if points else None
+        st = lib().mvs_batch_download(self._h, C.c_int(first), C.c_int(count), res.ctypes.data_as(C.c_void_p),
+                                      None if mt is None else mt.ctypes.data_as(C.c_void_p), _ptr(mk, C.c_uint8),
+                                      _ptr(pts, C.c_double), _ptr(idx, C.c_int64))
+        self.ctx._check(st, "mvs_batch_download")
+        return dict(results=res, matches=mt, mask=mk, points=pts, point_idx=idx)
+
+    def results_device(self):
+        p = C.c_void_p()
+        sz = C.c_size_t(0)
+        self.ctx._check(lib().mvs_batch_results_device(self._h, C.byref(p), C.byref(sz)), "mvs_batch_results_device")
+        return p.value, sz.value

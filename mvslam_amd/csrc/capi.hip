@@ -1,0 +1,858 @@
+// capi.hip -- host side of libmvslam_hip.so: contexts, resident batches, the C ABI of include/mvslam_hip.h.
+// No CPU fallback exists anywhere in this file: every entry point ends in a HIP kernel launch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace mvs;
+
+struct mvs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    mvs_batch *scratch = nullptr;  // batch of one pair backing the single-shot entry points
+    double *d_uv1 = nullptr, *d_uv2 = nullptr;
+    int uv_cap = 0;
+    double *d_small = nullptr;  // 64 doubles of staging (fundamental_kernel)
+};
+
+struct mvs_batch {
+    mvs_ctx *ctx = nullptr;
+    BatchDev d{};
+    std::vector<void *> allocs;
+    int hyp_table_cap = 0;  // capacity of the optional per-hypothesis tables
+    int32_t *allocs_hc = nullptr;
+    double *allocs_hr = nullptr;
+    hipEvent_t ev[8]{};
+};
+
+#define HIP_TRY(ctx_, expr)                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            if (ctx_)                                                                          \
+                (ctx_)->err = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            return MVS_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+static RunParams to_run(const mvs_params &p)
+{
+    RunParams r;
+    r.ratio = p.ratio;
+    r.max_dist = p.max_dist;
+    r.max_error_sq = p.max_error_sq;
+    r.num_hypotheses = p.num_hypotheses;
+    r.sampler = p.sampler;
+    r.seed = p.seed;
+    r.min_inliers = p.min_inliers;
+    return r;
+}
+
+// PinholeCamera caches K.inverse() (vision/camera.cpp:16): fixed-size 3x3 cofactor inverse,
+// inv(r, c) = cofactor(c, r) * (1 / det), det expanded along the first column.
+static void mat3_inverse(const double *K, double *inv)
+{
+    auto m = [&](int r, int c) { return K[(r % 3) * 3 + (c % 3)]; };
+    auto cof = [&](int i, int j) { return m(i + 1, j + 1) * m(i + 2, j + 2) - m(i + 1, j + 2) * m(i + 2, j + 1); };
+    const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+    const double det = (c00 * K[0] + c10 * K[3]) + c20 * K[6];
+    const double invdet = 1.0 / det;
+    inv[0] = c00 * invdet;       inv[1] = c10 * invdet;       inv[2] = c20 * invdet;
+    inv[3] = cof(0, 1) * invdet; inv[4] = cof(1, 1) * invdet; inv[5] = cof(2, 1) * invdet;
+    inv[6] = cof(0, 2) * invdet; inv[7] = cof(1, 2) * invdet; inv[8] = cof(2, 2) * invdet;
+}
+
+static bool affine_K(const double *K) { return K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0 && K[0] != 0.0 && K[4] != 0.0; }
+
+template <typename T>
+static mvs_status dev_alloc(mvs_batch *b, T **ptr, size_t count)
+{
+    void *p = nullptr;
+    HIP_TRY(b->ctx, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    b->allocs.push_back(p);
+    *ptr = static_cast<T *>(p);
+    return MVS_OK;
+}
+
+static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
+{
+    const int G = (num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
+    if (G <= b->d.max_groups)
+        return MVS_OK;
+    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    WgBest *p = nullptr;
+    mvs_status st = dev_alloc(b, &p, (size_t)b->d.n_pairs * G);
+    if (st != MVS_OK)
+        return st;
+    b->d.wgbest = p;  // the smaller old block stays owned by allocs until destroy
+    b->d.max_groups = G;
+    return MVS_OK;
+}
+
+extern "C" {
+
+int mvs_abi_version(void) { return MVS_ABI_VERSION; }
+
+const char *mvs_status_str(mvs_status s)
+{
+    switch (s) {
+    case MVS_OK: return "ok";
+    case MVS_NO_MODEL: return "no model (reference: return false)";
+    case MVS_ERR_INVALID_ARG: return "invalid argument (reference: assert)";
+    case MVS_ERR_NO_DEVICE: return "no HIP device";
+    case MVS_ERR_HIP: return "HIP runtime error";
+    case MVS_ERR_CAPACITY: return "capacity exceeded";
+    case MVS_ERR_BAD_INTRINSICS: return "camera intrinsics must be affine (last row 0 0 1)";
+    }
+    return "unknown";
+}
+
+const char *mvs_last_error(const mvs_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+mvs_status mvs_params_default(mvs_params *p)
+{
+    if (!p)
+        return MVS_ERR_INVALID_ARG;
+    p->ratio = 0.7;          // visual-feature.cpp:23
+    p->max_dist = 10.0;      // image-pair.cpp:22-23
+    p->max_error_sq = 0.0;   // derive from K (sfm-solve.cpp:311)
+    p->num_hypotheses = 1;   // sfm-solve.cpp:67
+    p->sampler = MVS_SAMPLER_IDENTITY;
+    p->seed = 0;
+    p->min_inliers = 8;      // sfm-solve.cpp:20-21
+    p->reserved = 0;
+    return MVS_OK;
+}
+
+mvs_status mvs_ctx_create_on_stream(int device_id, void *hip_stream, mvs_ctx **out)
+{
+    if (!out)
+        return MVS_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return MVS_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *c = new mvs_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete c;
+        return MVS_ERR_NO_DEVICE;
+    }
+    if (hip_stream) {
+        c->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return MVS_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    if (hipMalloc((void **)&c->d_small, 64 * sizeof(double)) != hipSuccess) {
+        if (c->own_stream)
+            (void)hipStreamDestroy(c->stream);
+        delete c;
+        return MVS_ERR_HIP;
+    }
+    *out = c;
+    return MVS_OK;
+}
+
+mvs_status mvs_ctx_create(int device_id, mvs_ctx **out) { return mvs_ctx_create_on_stream(device_id, nullptr, out); }
+
+void mvs_ctx_destroy(mvs_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch)
+        mvs_batch_destroy(ctx->scratch);
+    if (ctx->d_uv1) (void)hipFree(ctx->d_uv1);
+    if (ctx->d_uv2) (void)hipFree(ctx->d_uv2);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *mvs_ctx_stream(mvs_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------------------------
+mvs_status mvs_batch_create(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_bytes, mvs_batch **out)
+{
+    if (!ctx || !out || n_pairs < 1 || max_kp < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (max_kp > kMaxKp)
+        return MVS_ERR_CAPACITY;
+    if (!(desc_bytes == 16 || desc_bytes == 32 || desc_bytes == 64))
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mvs_batch *b = new mvs_batch();
+    b->ctx = ctx;
+    BatchDev &d = b->d;
+    d.n_pairs = n_pairs;
+    d.max_kp = max_kp;
+    d.desc_words = desc_bytes / 4;
+    d.max_groups = 0;
+    const size_t P = n_pairs, N = max_kp;
+    mvs_status st = MVS_OK;
+    uint32_t *desc1, *desc2;
+    float *kp1, *kp2;
+    int32_t *n1, *n2;
+    double *Kinv, *K;
+    int64_t *gidx;
+#define ALLOC(ptr, cnt)                                \
+    if (st == MVS_OK) st = dev_alloc(b, &(ptr), (cnt));
+    ALLOC(desc1, P * N * d.desc_words);
+    ALLOC(desc2, P * N * d.desc_words);
+    ALLOC(kp1, P * N * 2);
+    ALLOC(kp2, P * N * 2);
+    ALLOC(n1, P);
+    ALLOC(n2, P);
+    ALLOC(Kinv, P * 9);
+    ALLOC(K, P * 9);
+    ALLOC(gidx, P);
+    ALLOC(d.knn_train, P * N);
+    ALLOC(d.knn_dist, P * N);
+    ALLOC(d.M, P);
+    ALLOC(d.matches, P * N);
+    ALLOC(d.pts, P * N * 4);
+    ALLOC(d.cand_pts, P * 4 * N * 3);
+    ALLOC(d.results, P);
+    ALLOC(d.mask, P * N);
+    ALLOC(d.points, P * N * 3);
+    ALLOC(d.point_idx, P * N);
+    ALLOC(d.stats, 4);
+#undef ALLOC
+    if (st != MVS_OK) {
+        mvs_batch_destroy(b);
+        return st;
+    }
+    d.desc1 = desc1; d.desc2 = desc2; d.kp1 = kp1; d.kp2 = kp2; d.n1 = n1; d.n2 = n2;
+    d.Kinv = Kinv; d.K = K; d.gidx = gidx;
+    d.wgbest = nullptr;
+    d.hyp_count = nullptr;
+    d.hyp_residual = nullptr;
+    hipStream_t s = ctx->stream;
+    // deterministic contents for rows the caller never uploads
+    (void)hipMemsetAsync(desc1, 0, P * N * d.desc_words * 4, s);
+    (void)hipMemsetAsync(desc2, 0, P * N * d.desc_words * 4, s);
+    (void)hipMemsetAsync(kp1, 0, P * N * 2 * sizeof(float), s);
+    (void)hipMemsetAsync(kp2, 0, P * N * 2 * sizeof(float), s);
+    (void)hipMemsetAsync(n1, 0, P * sizeof(int32_t), s);
+    (void)hipMemsetAsync(n2, 0, P * sizeof(int32_t), s);
+    (void)hipMemsetAsync(gidx, 0, P * sizeof(int64_t), s);
+    (void)hipMemsetAsync(d.M, 0, P * sizeof(int32_t), s);
+    (void)hipMemsetAsync(d.results, 0, P * sizeof(mvs_pair_result), s);
+    (void)hipMemsetAsync(d.mask, 0, P * N, s);
+    for (auto &e : b->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            mvs_batch_destroy(b);
+            return MVS_ERR_HIP;
+        }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *out = b;
+    return MVS_OK;
+}
+
+void mvs_batch_destroy(mvs_batch *b)
+{
+    if (!b)
+        return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    for (void *p : b->allocs)
+        (void)hipFree(p);
+    for (auto &e : b->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    delete b;
+}
+
+mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
+                            const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
+                            const int32_t *n_pair, const double *K, const int64_t *global_index)
+{
+    if (!b || first < 0 || count < 1 || first + count > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BatchDev &d = b->d;
+    hipStream_t s = ctx->stream;
+    const size_t N = d.max_kp, DW = d.desc_words;
+    if (n_base)
+        for (int i = 0; i < count; ++i)
+            if (n_base[i] < 0 || n_base[i] > (int)N)
+                return MVS_ERR_CAPACITY;
+    if (n_pair)
+        for (int i = 0; i < count; ++i)
+            if (n_pair[i] < 0 || n_pair[i] > (int)N)
+                return MVS_ERR_CAPACITY;
+    std::vector<double> kinv;
+    if (K) {
+        kinv.resize((size_t)count * 9);
+        for (int i = 0; i < count; ++i) {
+            if (!affine_K(K + 9 * i))
+                return MVS_ERR_BAD_INTRINSICS;
+            mat3_inverse(K + 9 * i, kinv.data() + 9 * i);
+        }
+    }
+    std::vector<int64_t> gi;
+    if (!global_index) {
+        gi.resize(count);
+        for (int i = 0; i < count; ++i)
+            gi[i] = first + i;
+        global_index = gi.data();
+    }
+    const size_t off = first;
+#define UP(dst, src, bytes_per_pair)                                                                                   \
+    if (src)                                                                                                           \
+    HIP_TRY(ctx, hipMemcpyAsync((char *)(dst) + off * (bytes_per_pair), (src), (size_t)count * (bytes_per_pair),       \
+                                hipMemcpyHostToDevice, s))
+    UP(const_cast<uint32_t *>(d.desc1), base_desc, N * DW * 4);
+    UP(const_cast<uint32_t *>(d.desc2), pair_desc, N * DW * 4);
+    UP(const_cast<float *>(d.kp1), base_kp, N * 2 * sizeof(float));
+    UP(const_cast<float *>(d.kp2), pair_kp, N * 2 * sizeof(float));
+    UP(const_cast<int32_t *>(d.n1), n_base, sizeof(int32_t));
+    UP(const_cast<int32_t *>(d.n2), n_pair, sizeof(int32_t));
+    UP(const_cast<double *>(d.K), K, 9 * sizeof(double));
+    const double *kinv_p = K ? kinv.data() : nullptr;
+    UP(const_cast<double *>(d.Kinv), kinv_p, 9 * sizeof(double));
+    UP(const_cast<int64_t *>(d.gidx), global_index, sizeof(int64_t));
+#undef UP
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MVS_OK;
+}
+
+static mvs_status check_params(const mvs_params *p)
+{
+    if (!p || p->num_hypotheses < 1 || (p->sampler != MVS_SAMPLER_IDENTITY && p->sampler != MVS_SAMPLER_PHILOX))
+        return MVS_ERR_INVALID_ARG;  // estimator-RANSAC.cpp:13 assert(max_iteration > 0)
+    return MVS_OK;
+}
+
+static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_active, bool stats, hipEvent_t *ev)
+{
+    hipStream_t s = b->ctx->stream;
+    if (ev) (void)hipEventRecord(ev[0], s);
+    launch_match_topk(b->d, rp, n_active, s);
+    if (ev) (void)hipEventRecord(ev[1], s);
+    launch_match_compact(b->d, rp, n_active, s);
+    if (ev) (void)hipEventRecord(ev[2], s);
+    launch_ransac(b->d, rp, n_active, stats, s);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    launch_finalize(b->d, rp, n_active, kFinalizeFull, s);
+    if (ev) (void)hipEventRecord(ev[4], s);
+    HIP_TRY(b->ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_run(mvs_batch *b, const mvs_params *params, int n_active)
+{
+    if (!b || n_active < 1 || n_active > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+    st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    return enqueue_pipeline(b, to_run(*params), n_active, false, nullptr);
+}
+
+mvs_status mvs_batch_sync(mvs_batch *b)
+{
+    if (!b)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, int warmup, int steps,
+                          float *ms_total, float *ms_kernel)
+{
+    if (!b || n_active < 1 || n_active > b->d.n_pairs || steps < 1 || warmup < 0)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    const RunParams rp = to_run(*params);
+    hipStream_t s = ctx->stream;
+    for (int i = 0; i < warmup; ++i)
+        if ((st = enqueue_pipeline(b, rp, n_active, false, nullptr)) != MVS_OK)
+            return st;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipEventRecord(b->ev[5], s));
+    for (int i = 0; i < steps; ++i)
+        if ((st = enqueue_pipeline(b, rp, n_active, false, nullptr)) != MVS_OK)
+            return st;
+    HIP_TRY(ctx, hipEventRecord(b->ev[6], s));
+    HIP_TRY(ctx, hipEventSynchronize(b->ev[6]));
+    if (ms_total)
+        HIP_TRY(ctx, hipEventElapsedTime(ms_total, b->ev[5], b->ev[6]));
+    if (ms_kernel) {
+        for (int k = 0; k < 5; ++k)
+            ms_kernel[k] = 0.f;
+        for (int i = 0; i < steps; ++i) {
+            if ((st = enqueue_pipeline(b, rp, n_active, false, b->ev)) != MVS_OK)
+                return st;
+            HIP_TRY(ctx, hipEventSynchronize(b->ev[4]));
+            for (int k = 0; k < 4; ++k) {
+                float ms = 0.f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]));
+                ms_kernel[k] += ms;
+            }
+        }
+    }
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_download(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                              uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx)
+{
+    if (!b || first < 0 || count < 1 || first + count > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const BatchDev &d = b->d;
+    const size_t N = d.max_kp, off = first, cnt = count;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (results)
+        HIP_TRY(ctx, hipMemcpy(results, d.results + off, cnt * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
+    if (matches)
+        HIP_TRY(ctx, hipMemcpy(matches, d.matches + off * N, cnt * N * sizeof(mvs_match), hipMemcpyDeviceToHost));
+    if (inlier_mask)
+        HIP_TRY(ctx, hipMemcpy(inlier_mask, d.mask + off * N, cnt * N, hipMemcpyDeviceToHost));
+    if (points_xyz)
+        HIP_TRY(ctx, hipMemcpy(points_xyz, d.points + off * N * 3, cnt * N * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (point_idx) {
+        std::vector<int32_t> tmp(cnt * N);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), d.point_idx + off * N, cnt * N * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt * N; ++i)
+            point_idx[i] = tmp[i];  // reference type: size_t (sfm.hpp:35)
+    }
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out)
+{
+    if (!b || !out || n_active < 1 || n_active > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 4 * sizeof(unsigned long long), s));
+    st = enqueue_pipeline(b, to_run(*params), n_active, true, nullptr);
+    if (st != MVS_OK)
+        return st;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    unsigned long long h[4];
+    HIP_TRY(ctx, hipMemcpy(h, b->d.stats, sizeof(h), hipMemcpyDeviceToHost));
+    std::vector<mvs_pair_result> res(n_active);
+    HIP_TRY(ctx, hipMemcpy(res.data(), b->d.results, n_active * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof(*out));
+    out->rotations9 = (int64_t)h[0];
+    out->pairs9 = (int64_t)h[1];
+    for (const auto &r : res) {
+        out->matches += r.n_matches;
+        out->inliers += r.n_inliers;
+        if (r.n_matches >= 8) {
+            out->hypotheses += params->num_hypotheses;
+            out->score_evals += (int64_t)params->num_hypotheses * r.n_matches;
+        }
+    }
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_results_device(mvs_batch *b, void **dev_ptr, size_t *record_bytes)
+{
+    if (!b || !dev_ptr)
+        return MVS_ERR_INVALID_ARG;
+    *dev_ptr = b->d.results;
+    if (record_bytes)
+        *record_bytes = sizeof(mvs_pair_result);
+    return MVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-shot entry points: a resident batch of one pair owned by the context
+// ---------------------------------------------------------------------------------------------
+static mvs_status ensure_scratch(mvs_ctx *ctx, int max_kp, int desc_bytes)
+{
+    if (max_kp > kMaxKp)
+        return MVS_ERR_CAPACITY;
+    if (ctx->scratch && ctx->scratch->d.max_kp >= max_kp && ctx->scratch->d.desc_words * 4 == desc_bytes)
+        return MVS_OK;
+    if (ctx->scratch) {
+        max_kp = std::max(max_kp, ctx->scratch->d.max_kp);
+        mvs_batch_destroy(ctx->scratch);
+        ctx->scratch = nullptr;
+    }
+    max_kp = std::max(max_kp, 64);
+    return mvs_batch_create(ctx, 1, max_kp, desc_bytes, &ctx->scratch);
+}
+
+static mvs_status ensure_uv(mvs_ctx *ctx, int cap)
+{
+    if (ctx->uv_cap >= cap)
+        return MVS_OK;
+    if (ctx->d_uv1) (void)hipFree(ctx->d_uv1);
+    if (ctx->d_uv2) (void)hipFree(ctx->d_uv2);
+    ctx->d_uv1 = ctx->d_uv2 = nullptr;
+    ctx->uv_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_uv1, (size_t)cap * 2 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_uv2, (size_t)cap * 2 * sizeof(double)));
+    ctx->uv_cap = cap;
+    return MVS_OK;
+}
+
+// stage image points + camera of a single-shot call; leaves normalised points in batch->pts
+static mvs_status stage_points(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, int m, const double K[9])
+{
+    if (!affine_K(K))
+        return MVS_ERR_BAD_INTRINSICS;
+    const int desc_bytes = ctx->scratch ? ctx->scratch->d.desc_words * 4 : 32;
+    mvs_status st = ensure_scratch(ctx, std::max(m, 8), desc_bytes);
+    if (st != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    st = ensure_uv(ctx, b->d.max_kp);
+    if (st != MVS_OK)
+        return st;
+    hipStream_t s = ctx->stream;
+    double kinv[9];
+    mat3_inverse(K, kinv);
+    const int64_t zero = 0;
+    const int32_t M = m;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_uv1, p1_uv, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_uv2, p2_uv, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.K), K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.Kinv), kinv, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d.M, &M, sizeof(M), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));  // host temporaries above go out of scope
+    launch_prep_points(b->d, ctx->d_uv1, ctx->d_uv2, 1, s);
+    return MVS_OK;
+}
+
+static mvs_status fetch_single(mvs_ctx *ctx, int m, mvs_pair_result *res, double *points_xyz, int64_t *point_idx,
+                               uint8_t *mask)
+{
+    mvs_batch *b = ctx->scratch;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(res, b->d.results, sizeof(*res), hipMemcpyDeviceToHost));
+    if (mask && m > 0)
+        HIP_TRY(ctx, hipMemcpy(mask, b->d.mask, (size_t)m, hipMemcpyDeviceToHost));
+    const int n = res->valid ? res->n_points : 0;
+    if (n > 0 && points_xyz)
+        HIP_TRY(ctx, hipMemcpy(points_xyz, b->d.points, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (n > 0 && point_idx) {
+        std::vector<int32_t> tmp(n);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), b->d.point_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            point_idx[i] = tmp[i];
+    }
+    return MVS_OK;
+}
+
+mvs_status mvs_match_hamming(mvs_ctx *ctx, const uint8_t *train_desc, int n_train, const uint8_t *query_desc,
+                             int n_query, int desc_bytes, double ratio, double max_dist, mvs_match *out, int *n_out)
+{
+    if (!ctx || !train_desc || !query_desc || !out || !n_out)
+        return MVS_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (n_train < 2 || n_query < 1)  // visual-feature.cpp:56 assert(valid), :67 needs two neighbours
+        return MVS_ERR_INVALID_ARG;
+    if (!(desc_bytes == 16 || desc_bytes == 32 || desc_bytes == 64))
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mvs_status st = ensure_scratch(ctx, std::max(n_train, n_query), desc_bytes);
+    if (st != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    hipStream_t s = ctx->stream;
+    const int32_t n1 = n_train, n2 = n_query;
+    const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t *>(b->d.desc1), train_desc, (size_t)n_train * desc_bytes,
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t *>(b->d.desc2), query_desc, (size_t)n_query * desc_bytes,
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int32_t *>(b->d.n1), &n1, sizeof(n1), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int32_t *>(b->d.n2), &n2, sizeof(n2), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.Kinv), eye, sizeof(eye), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.K), eye, sizeof(eye), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    RunParams rp{};
+    rp.ratio = ratio;
+    rp.max_dist = max_dist;
+    launch_match_topk(b->d, rp, 1, s);
+    launch_match_compact(b->d, rp, 1, s);
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t M = 0;
+    HIP_TRY(ctx, hipMemcpy(&M, b->d.M, sizeof(M), hipMemcpyDeviceToHost));
+    if (M > 0)
+        HIP_TRY(ctx, hipMemcpy(out, b->d.matches, (size_t)M * sizeof(mvs_match), hipMemcpyDeviceToHost));
+    *n_out = M;
+    return MVS_OK;
+}
+
+mvs_status mvs_two_view(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, int m, const double K[9],
+                        const mvs_params *params, double R[9], double t[3], double *points_xyz,
+                        int64_t *point_idx, int *n_points, uint8_t *inlier_mask, mvs_pair_result *result)
+{
+    if (!ctx || !p1_uv || !p2_uv || !K || m < 0)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    if (n_points)
+        *n_points = 0;
+    mvs_pair_result res;
+    std::memset(&res, 0, sizeof(res));
+    res.best_hyp = -1;
+    res.n_matches = m;
+    if (m < 8) {  // sfm-solve.cpp:37 asserts; estimator-RANSAC.cpp:25-29 returns false
+        if (result)
+            *result = res;
+        return m < 1 ? MVS_ERR_INVALID_ARG : MVS_NO_MODEL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    st = stage_points(ctx, p1_uv, p2_uv, m, K);
+    if (st != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    const RunParams rp = to_run(*params);
+    launch_ransac(b->d, rp, 1, false, ctx->stream);
+    launch_finalize(b->d, rp, 1, kFinalizeFull, ctx->stream);
+    st = fetch_single(ctx, m, &res, points_xyz, point_idx, inlier_mask);
+    if (st != MVS_OK)
+        return st;
+    if (result)
+        *result = res;
+    if (!res.valid)
+        return MVS_NO_MODEL;
+    if (R) std::memcpy(R, res.R, sizeof(res.R));
+    if (t) std::memcpy(t, res.t, sizeof(res.t));
+    if (n_points) *n_points = res.n_points;
+    return MVS_OK;
+}
+
+static mvs_status upload_mask(mvs_ctx *ctx, const uint8_t *mask, int m)
+{
+    mvs_batch *b = ctx->scratch;
+    if (mask) {
+        HIP_TRY(ctx, hipMemcpyAsync(b->d.mask, mask, (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(b->d.mask, 1, (size_t)m, ctx->stream));
+    }
+    return MVS_OK;
+}
+
+mvs_status mvs_triangulate(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, int m, const double K[9],
+                           const double R1to2[9], const double t1to2[3], double *points_xyz, int64_t *point_idx,
+                           int *n_points)
+{
+    if (!ctx || !p1_uv || !p2_uv || !K || !R1to2 || !t1to2 || !n_points || m < 1)  // sfm-solve.cpp:143-144
+        return MVS_ERR_INVALID_ARG;
+    *n_points = 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mvs_status st = stage_points(ctx, p1_uv, p2_uv, m, K);
+    if (st != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    mvs_pair_result res;
+    std::memset(&res, 0, sizeof(res));
+    std::memcpy(res.R1to2, R1to2, sizeof(res.R1to2));
+    std::memcpy(res.t1to2, t1to2, sizeof(res.t1to2));
+    HIP_TRY(ctx, hipMemcpy(b->d.results, &res, sizeof(res), hipMemcpyHostToDevice));
+    if ((st = upload_mask(ctx, nullptr, m)) != MVS_OK)
+        return st;
+    RunParams rp{};
+    rp.num_hypotheses = 1;
+    launch_finalize(b->d, rp, 1, kFinalizeTriangulate, ctx->stream);
+    st = fetch_single(ctx, m, &res, points_xyz, point_idx, nullptr);
+    if (st != MVS_OK)
+        return st;
+    *n_points = res.valid ? res.n_points : 0;
+    return MVS_OK;
+}
+
+mvs_status mvs_recover_pose(mvs_ctx *ctx, const double E[9], const double *p1_uv, const double *p2_uv, int m,
+                            const double K[9], const uint8_t *inlier_mask, double R[9], double t[3],
+                            double *points_xyz, int64_t *point_idx, int *n_points, mvs_pair_result *result)
+{
+    if (!ctx || !E || !p1_uv || !p2_uv || !K || m < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (n_points)
+        *n_points = 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mvs_status st = stage_points(ctx, p1_uv, p2_uv, m, K);
+    if (st != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    mvs_pair_result res;
+    std::memset(&res, 0, sizeof(res));
+    std::memcpy(res.E, E, sizeof(res.E));
+    HIP_TRY(ctx, hipMemcpy(b->d.results, &res, sizeof(res), hipMemcpyHostToDevice));
+    if ((st = upload_mask(ctx, inlier_mask, m)) != MVS_OK)
+        return st;
+    RunParams rp{};
+    rp.num_hypotheses = 1;
+    launch_finalize(b->d, rp, 1, kFinalizeFromE, ctx->stream);
+    st = fetch_single(ctx, m, &res, points_xyz, point_idx, nullptr);
+    if (st != MVS_OK)
+        return st;
+    if (result)
+        *result = res;
+    if (!res.valid)
+        return MVS_NO_MODEL;
+    if (R) std::memcpy(R, res.R, sizeof(res.R));
+    if (t) std::memcpy(t, res.t, sizeof(res.t));
+    if (n_points) *n_points = res.n_points;
+    return MVS_OK;
+}
+
+mvs_status mvs_find_fundamental_matrix(mvs_ctx *ctx, const double p1_xy[16], const double p2_xy[16], double F[9])
+{
+    if (!ctx || !p1_xy || !p2_xy || !F)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    double *d = ctx->d_small;  // [0,16) p1, [16,32) p2, [32,41) F, [48] ok flag (as int)
+    HIP_TRY(ctx, hipMemcpyAsync(d, p1_xy, 16 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d + 16, p2_xy, 16 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    launch_fundamental(d, d + 16, d + 32, reinterpret_cast<int *>(d + 48), s);
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    int ok = 0;
+    HIP_TRY(ctx, hipMemcpy(F, d + 32, 9 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&ok, d + 48, sizeof(int), hipMemcpyDeviceToHost));
+    return ok ? MVS_OK : MVS_NO_MODEL;
+}
+
+mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const double *p2_xy, int m, double max_error_sq,
+                                  int num_hypotheses, int sampler, uint64_t seed, double F[9], uint8_t *inlier_mask,
+                                  int *best_hyp, int *best_count, double *best_residual, int32_t *count,
+                                  double *residual)
+{
+    if (!ctx || !p1_xy || !p2_xy || m < 0 || num_hypotheses < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (!(max_error_sq > 2.220446049250313e-16))  // estimator-RANSAC.cpp:12
+        return MVS_ERR_INVALID_ARG;
+    if (best_hyp) *best_hyp = -1;
+    if (best_count) *best_count = 0;
+    if (best_residual) *best_residual = 0.0;
+    if (m < 8)
+        return MVS_NO_MODEL;  // estimator-RANSAC.cpp:25-29
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int desc_bytes = ctx->scratch ? ctx->scratch->d.desc_words * 4 : 32;
+    mvs_status st = ensure_scratch(ctx, m, desc_bytes);
+    if (st != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    st = ensure_groups(b, num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    hipStream_t s = ctx->stream;
+    std::vector<double> packed((size_t)m * 4);  // ideal-camera points are already normalised: pure packing
+    for (int i = 0; i < m; ++i) {
+        packed[4 * i] = p1_xy[2 * i];
+        packed[4 * i + 1] = p1_xy[2 * i + 1];
+        packed[4 * i + 2] = p2_xy[2 * i];
+        packed[4 * i + 3] = p2_xy[2 * i + 1];
+    }
+    const int32_t M = m;
+    const int64_t zero = 0;
+    const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    HIP_TRY(ctx, hipMemcpyAsync(b->d.pts, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d.M, &M, sizeof(M), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.K), eye, sizeof(eye), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.Kinv), eye, sizeof(eye), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (count || residual) {
+        if (b->hyp_table_cap < num_hypotheses) {
+            int32_t *hc;
+            double *hr;
+            if ((st = dev_alloc(b, &hc, (size_t)num_hypotheses)) != MVS_OK) return st;
+            if ((st = dev_alloc(b, &hr, (size_t)num_hypotheses)) != MVS_OK) return st;
+            b->d.hyp_count = hc;
+            b->d.hyp_residual = hr;
+            b->hyp_table_cap = num_hypotheses;
+            b->allocs_hc = hc;
+            b->allocs_hr = hr;
+        } else {
+            b->d.hyp_count = b->allocs_hc;
+            b->d.hyp_residual = b->allocs_hr;
+        }
+    } else {
+        b->d.hyp_count = nullptr;
+        b->d.hyp_residual = nullptr;
+    }
+    RunParams rp{};
+    rp.max_error_sq = max_error_sq;
+    rp.num_hypotheses = num_hypotheses;
+    rp.sampler = sampler;
+    rp.seed = seed;
+    rp.min_inliers = 0x7fffffff;  // stop after the mask: no decomposition / triangulation wanted here
+    launch_ransac(b->d, rp, 1, false, s);
+    launch_finalize(b->d, rp, 1, kFinalizeFull, s);
+    mvs_pair_result res;
+    st = fetch_single(ctx, m, &res, nullptr, nullptr, inlier_mask);
+    if (st == MVS_OK && count)
+        HIP_TRY(ctx, hipMemcpy(count, b->d.hyp_count, (size_t)num_hypotheses * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (st == MVS_OK && residual)
+        HIP_TRY(ctx, hipMemcpy(residual, b->d.hyp_residual, (size_t)num_hypotheses * sizeof(double),
+                               hipMemcpyDeviceToHost));
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    if (st != MVS_OK)
+        return st;
+    if (F) std::memcpy(F, res.F, sizeof(res.F));
+    if (best_hyp) *best_hyp = res.best_hyp;
+    if (best_count) *best_count = res.best_count;
+    if (best_residual) *best_residual = res.best_residual;
+    return res.best_count > 0 ? MVS_OK : MVS_NO_MODEL;  // estimator-RANSAC.cpp:89
+}
+
+}  // extern "C"

@@ -1,0 +1,488 @@
+// device_math.hpp -- per-lane fp64 building blocks of the two-view kernels (gfx950).
+//
+// Everything here runs one problem per LANE with the whole state in registers:
+// all matrix loops are fully unrolled so that every array index is a compile-time
+// constant (a runtime-indexed register array would be demoted to scratch memory).
+//
+// Arithmetic contract: IEEE binary64, one rounding per written
+// operation, fused multiply-add only where dfma() is written.  This file is
+// compiled with -ffp-contract=off.  The CPU oracle implements the same contract
+// independently; GPU<->oracle comparisons of integer outputs are bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MVS_DEV __device__ __forceinline__
+
+namespace mvs {
+
+constexpr double kEps = 2.220446049250313e-16;       // reference `epsilon` (system-config.hpp:8)
+constexpr double kTol = kEps * 1000.0;                // reference `tolerance` (system-config.hpp:10)
+constexpr double kJacobiEps = kEps * 10.0;            // cv::SVDecomp rotation threshold for double
+constexpr double kMinVal = 2.2250738585072014e-308;   // DBL_MIN: "zero singular value" in cv::SVDecomp
+constexpr double kSqrt2 = 1.4142135623730951;
+
+MVS_DEV double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+MVS_DEV double dsqrt(double a) { return __builtin_sqrt(a); }  // correctly rounded (no fast-math)
+MVS_DEV double dabs(double a) { return __builtin_fabs(a); }
+
+// ---------------------------------------------------------------------------------
+// One (i, j) step of the one-sided Jacobi SVD (cv::SVDecomp restated, lapack.cpp
+// JacobiSVDImpl_): orthogonalise rows Ai, Aj of At, mirror the rotation on Vt.
+// ---------------------------------------------------------------------------------
+template <int M, int N, bool HAS_V>
+MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], double (&Vj)[N], double &Wi, double &Wj,
+                         bool &changed, unsigned &rot)
+{
+    double a = Wi, b = Wj, p = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+        p = dfma(Ai[k], Aj[k], p);
+    if (!(dabs(p) <= kJacobiEps * dsqrt(a * b))) {
+        p *= 2.0;
+        const double beta = a - b;
+        const double gamma = dsqrt(dfma(p, p, beta * beta));
+        // beta < 0: s = sqrt(((gamma-beta)*0.5)/gamma), c = p/(gamma*s*2)
+        // else    : c = sqrt((gamma+beta)/(gamma*2)),   s = p/(gamma*c*2)
+        const bool neg = beta < 0.0;
+        const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
+        const double den = neg ? gamma : gamma * 2.0;
+        const double x = dsqrt(num / den);
+        const double y = p / (gamma * x * 2.0);
+        const double c = neg ? y : x;
+        const double s = neg ? x : y;
+        a = 0.0;
+        b = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            const double t0 = dfma(c, Ai[k], s * Aj[k]);
+            const double t1 = dfma(c, Aj[k], -(s * Ai[k]));
+            Ai[k] = t0;
+            Aj[k] = t1;
+            a = dfma(t0, t0, a);
+            b = dfma(t1, t1, b);
+        }
+        Wi = a;
+        Wj = b;
+        changed = true;
+        ++rot;
+        if (HAS_V) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double t0 = dfma(c, Vi[k], s * Vj[k]);
+                const double t1 = dfma(c, Vj[k], -(s * Vi[k]));
+                Vi[k] = t0;
+                Vj[k] = t1;
+            }
+        }
+    }
+}
+
+// Sweeps until a sweep without rotation (at most max(M, 30)); W ends as singular values.
+// At: N rows of length M.  Vt: N x N, initialised to identity here.
+template <int M, int N>
+MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N], unsigned &rot, unsigned &pairs)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sd = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+            sd = dfma(At[i][k], At[i][k], sd);
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            Vt[i][k] = (i == k) ? 1.0 : 0.0;
+    }
+    constexpr int kMaxIter = M > 30 ? M : 30;
+    for (int iter = 0; iter < kMaxIter; ++iter) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) {
+#pragma unroll
+            for (int j = i + 1; j < N; ++j)
+                jacobi_pair<M, N, true>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot);
+        }
+        pairs += N * (N - 1) / 2;
+        if (!changed)
+            break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sd = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+            sd = dfma(At[i][k], At[i][k], sd);
+        W[i] = dsqrt(sd);
+    }
+}
+
+// Selection sort (descending, strict '<', first maximum wins) of W with a row tag:
+// after the call tag[p] is the original row that cv::SVDecomp would have moved to position p.
+template <int N>
+MVS_DEV void sort_tags_desc(double (&W)[N], int (&tag)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        tag[i] = i;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        double best = W[i];
+        int bt = tag[i];
+        int bj = i;
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) {
+            const bool g = best < W[k];
+            best = g ? W[k] : best;
+            bt = g ? tag[k] : bt;
+            bj = g ? k : bj;
+        }
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) {
+            const bool hit = (bj == k);
+            W[k] = hit ? W[i] : W[k];
+            tag[k] = hit ? tag[i] : tag[k];
+        }
+        W[i] = best;
+        tag[i] = bt;
+    }
+}
+
+template <int N>
+MVS_DEV void select_row(const double (&Mx)[N][N], int row, double (&out)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        // start from a constant, not from Mx[0][k]: a select between two loads of the same
+        // private array gets folded into one load through a selected POINTER, which would
+        // pin the whole matrix in scratch memory.
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            v = (row == i) ? Mx[i][k] : v;
+        out[k] = v;
+    }
+}
+
+// Null vector of a symmetric 9x9 matrix B (= A^T A): last row of vt of cv::SVDecomp(B).
+MVS_DEV void svd9_last_vt_row(double (&At)[9][9], double (&f)[9], unsigned &rot, unsigned &pairs)
+{
+    double Vt[9][9], W[9];
+    int tag[9];
+    jacobi_svd_core<9, 9>(At, Vt, W, rot, pairs);
+    sort_tags_desc<9>(W, tag);
+    select_row<9>(Vt, tag[8], f);
+}
+
+// Last row of vt of cv::SVDecomp(A) for a 4x4 A given as At = A^T.
+MVS_DEV void svd4_last_vt_row(double (&At)[4][4], double (&x)[4], unsigned &rot, unsigned &pairs)
+{
+    double Vt[4][4], W[4];
+    int tag[4];
+    jacobi_svd_core<4, 4>(At, Vt, W, rot, pairs);
+    sort_tags_desc<4>(W, tag);
+    select_row<4>(Vt, tag[3], x);
+}
+
+// OpenCV's multiply-with-carry generator, used only when a singular value is <= DBL_MIN.
+MVS_DEV uint32_t cvrng_next(uint64_t &state)
+{
+    state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+    return (uint32_t)state;
+}
+
+// Full 3x3 SVD: A = U diag(w) Vt, exactly cv::SVDecomp(A, w, u, vt, MODIFY_A | FULL_UV).
+// U[i][j] row-major (columns are the left vectors), Vt rows are the right vectors.
+MVS_DEV void svd3_full(const double (&A)[3][3], double (&w)[3], double (&U)[3][3], double (&Vt)[3][3], unsigned &rot,
+                       unsigned &pairs)
+{
+    double At[3][3], W[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            At[i][k] = A[k][i];
+    jacobi_svd_core<3, 3>(At, Vt, W, rot, pairs);
+    // selection sort with physical row swaps (N = 3: cheap)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int bj = i;
+        double best = W[i];
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k) {
+            const bool g = best < W[k];
+            best = g ? W[k] : best;
+            bj = g ? k : bj;
+        }
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k) {
+            const bool hit = (bj == k);
+            const double tw = W[k];
+            W[k] = hit ? W[i] : tw;
+            W[i] = hit ? tw : W[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double ta = At[k][c], tv = Vt[k][c];
+                At[k][c] = hit ? At[i][c] : ta;
+                At[i][c] = hit ? ta : At[i][c];
+                Vt[k][c] = hit ? Vt[i][c] : tv;
+                Vt[i][c] = hit ? tv : Vt[i][c];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        w[i] = W[i];
+    // left vectors: rows of At scaled by 1/W; (numerically) zero singular values get a
+    // pseudo-random row orthogonalised against the previous ones (cold path).
+    uint64_t rng = 0x12345678ULL;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= kMinVal; ++ii) {
+            const double val0 = 1.0 / 3.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                At[i][k] = (cvrng_next(rng) & 256u) != 0 ? val0 : -val0;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (j < i) {
+                        sd = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            sd += At[i][k] * At[j][k];
+                        double asum = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const double t = At[i][k] - sd * At[j][k];
+                            At[i][k] = t;
+                            asum += dabs(t);
+                        }
+                        asum = asum > kJacobiEps * 100.0 ? 1.0 / asum : 0.0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            At[i][k] *= asum;
+                    }
+                }
+            }
+            sd = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                sd += At[i][k] * At[i][k];
+            sd = dsqrt(sd);
+        }
+        const double s = sd > kMinVal ? 1.0 / sd : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            At[i][k] *= s;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            U[i][j] = At[j][i];
+}
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 and the 8-of-M sampler
+// ---------------------------------------------------------------------------------
+MVS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                           uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// idx[k]: k-th draw = slot (w_k * (M - k)) >> 32 among the not yet chosen indices.
+MVS_DEV void sample8(uint64_t seed, uint32_t hyp, int M, int sampler, int (&idx)[8])
+{
+    if (sampler == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            idx[k] = k;
+        return;
+    }
+    uint32_t w[8];
+    {
+        uint32_t o[4];
+        philox4x32_10(hyp, 0u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+        philox4x32_10(hyp, 1u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        w[4] = o[0]; w[5] = o[1]; w[6] = o[2]; w[7] = o[3];
+    }
+    // sorted[] kept ascending with static indices only
+    int sorted[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        sorted[k] = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t r = __umulhi(w[k], (uint32_t)(M - k));
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < k && r >= (uint32_t)sorted[t])
+                ++r;
+        idx[k] = (int)r;
+        // insert r: everything greater shifts up by one
+        int carry = (int)r;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t <= k) {
+                const int cur = sorted[t];
+                const bool sw = carry < cur;
+                sorted[t] = sw ? carry : cur;
+                carry = sw ? cur : carry;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// find_fundamental_matrix (vision/fundamental-matrix.cpp:18-54,56-140,204-267)
+// p1 / p2: the 8 sampled ideal-camera points (x, y), homogeneous 1.
+// returns false for a degenerate sample (reference: assert(scale > epsilon), :45).
+// ---------------------------------------------------------------------------------
+MVS_DEV bool normalise8(const double (&px)[8], const double (&py)[8], double (&nx)[8], double (&ny)[8], double &scale,
+                        double &mx, double &my)
+{
+    mx = 0.0;
+    my = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mx += px[i];
+        my += py[i];
+    }
+    mx *= 0.125;
+    my *= 0.125;
+    double sc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double dx = px[i] - mx, dy = py[i] - my;
+        nx[i] = dx;
+        ny[i] = dy;
+        sc += dsqrt(dx * dx + dy * dy);
+    }
+    sc *= 0.125;
+    const bool ok = sc > kEps;
+    sc = kSqrt2 / sc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        nx[i] *= sc;
+        ny[i] *= sc;
+    }
+    scale = sc;
+    return ok;
+}
+
+MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
+                         double (&F)[9], unsigned &rot9, unsigned &pairs9)
+{
+    double f[9];
+    double s1, s2, m1x, m1y, m2x, m2y;
+    bool ok;
+    {
+        double a1[8], b1[8], a2[8], b2[8];
+        ok = normalise8(x1, y1, a1, b1, s1, m1x, m1y);
+        ok = normalise8(x2, y2, a2, b2, s2, m2x, m2y) && ok;
+        // design matrix rows [x2x1, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1]  (:78-87)
+        double A[8][9];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            A[i][0] = a2[i] * a1[i]; A[i][1] = a2[i] * b1[i]; A[i][2] = a2[i];
+            A[i][3] = b2[i] * a1[i]; A[i][4] = b2[i] * b1[i]; A[i][5] = b2[i];
+            A[i][6] = a1[i];         A[i][7] = b1[i];         A[i][8] = 1.0;
+        }
+        // A^T A, sequential k, separate mul / add (:104-111); symmetric by construction
+        double At[9][9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+#pragma unroll
+            for (int j = i; j < 9; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc += A[k][i] * A[k][j];
+                At[i][j] = acc;
+                At[j][i] = acc;
+            }
+        }
+        svd9_last_vt_row(At, f, rot9, pairs9);
+    }
+    // rank-2 enforcement (:127-136): F = u diag(w0, w1, 0) vt
+    double Fn[3][3];
+    {
+        double Fp[3][3] = {{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}};
+        double w[3], U[3][3], Vt[3][3];
+        unsigned r3 = 0, p3 = 0;
+        svd3_full(Fp, w, U, Vt, r3, p3);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double a = U[i][0] * w[0], b = U[i][1] * w[1];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                Fn[i][j] = a * Vt[0][j] + b * Vt[1][j];
+        }
+    }
+    // de-normalise (:245): F = T2^T Fn T1, T = [s 0 -m0 s; 0 s -m1 s; 0 0 1]
+    const double tx1 = -m1x * s1, ty1 = -m1y * s1, tx2 = -m2x * s2, ty2 = -m2y * s2;
+    double G[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        G[0][j] = s2 * Fn[0][j];
+        G[1][j] = s2 * Fn[1][j];
+        G[2][j] = (tx2 * Fn[0][j] + ty2 * Fn[1][j]) + Fn[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F[i * 3 + 0] = G[i][0] * s1;
+        F[i * 3 + 1] = G[i][1] * s1;
+        F[i * 3 + 2] = (G[i][0] * tx1 + G[i][1] * ty1) + G[i][2];
+    }
+    return ok;
+}
+
+// |p2^T F p1| with homogeneous 1 (estimator-RANSAC.cpp:114-116), fused form of the contract.
+MVS_DEV double epipolar_residual(const double (&F)[9], double x1, double y1, double x2, double y2)
+{
+    const double u0 = dfma(x2, F[0], dfma(y2, F[3], F[6]));
+    const double u1 = dfma(x2, F[1], dfma(y2, F[4], F[7]));
+    const double u2 = dfma(x2, F[2], dfma(y2, F[5], F[8]));
+    return dabs(dfma(u0, x1, dfma(u1, y1, u2)));
+}
+
+// ---------------------------------------------------------------------------------
+// small fixed-size helpers used by the finalize kernel (Eigen left-to-right sums)
+// ---------------------------------------------------------------------------------
+MVS_DEV double det3(const double (&m)[3][3])
+{
+    const double h0 = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]);
+    const double h1 = m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]);
+    const double h2 = m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    return (h0 - h1) + h2;
+}
+
+// SO3::rectify (math/lie-group.hpp:84-96): Gram-Schmidt on rows, row 1 not re-normalised.
+MVS_DEV void rectify3(double (&R)[3][3])
+{
+    const double n = dsqrt((R[0][0] * R[0][0] + R[0][1] * R[0][1]) + R[0][2] * R[0][2]);
+    const double u00 = R[0][0] / n, u01 = R[0][1] / n, u02 = R[0][2] / n;
+    const double d = (R[1][0] * u00 + R[1][1] * u01) + R[1][2] * u02;
+    const double u10 = R[1][0] - d * u00, u11 = R[1][1] - d * u01, u12 = R[1][2] - d * u02;
+    R[0][0] = u00; R[0][1] = u01; R[0][2] = u02;
+    R[1][0] = u10; R[1][1] = u11; R[1][2] = u12;
+    R[2][0] = u01 * u12 - u02 * u11;
+    R[2][1] = u02 * u10 - u00 * u12;
+    R[2][2] = u00 * u11 - u01 * u10;
+}
+
+}  // namespace mvs

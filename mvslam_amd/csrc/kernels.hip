@@ -1,0 +1,764 @@
+// kernels.hip -- the four kernels of the two-view-geometry path, written for gfx950 (wave64).
+//
+//   match_topk     brute-force Hamming 2-NN + Lowe ratio / max-dist       (visual-feature.cpp:51-70)
+//   match_compact  canonical sort (distance, queryIdx) + keypoint gather +
+//                  K^-1 normalisation                                       (visual-feature.cpp:72-80,
+//                                                                            image-pair.cpp:123-140, camera.cpp:55-79)
+//   ransac         one hypothesis per LANE: sample 8 -> normalise -> A^T A -> 9x9 Jacobi SVD ->
+//                  rank-2 -> de-normalise -> score against all M matches    (fundamental-matrix.cpp,
+//                                                                            estimator-RANSAC.cpp)
+//   finalize       arg-best, inlier mask, E projection, decomposition, 4 x M_inl triangulations
+//                  (4x4 Jacobi SVD per lane), candidate selection, pose     (sfm-solve.cpp:64-368)
+//
+// Why one hypothesis per lane (not per wavefront): the 8-point solve is a long serial
+// chain on an 81+81-double state with a handful of transcendental-rate scalars per rotation;
+// spreading one 9x9 problem over lanes leaves >80 % of the wave idle in the rotation-angle
+// computation and needs a cross-lane reduction per dot product, whereas 64 independent
+// problems per wave keep every lane busy, need no cross-lane traffic, and give the
+// reference's sequential residual order for free.  See DESIGN.md.
+#include "kernels.hpp"
+
+#include "device_math.hpp"
+
+namespace mvs {
+
+// ---------------------------------------------------------------------------------------------
+// match_topk: grid (ceil(N/64), P), block 256 = 4 waves.  Lane = one query descriptor (registers),
+// wave w scans train rows of quarter w (wave-uniform addresses -> scalar loads), partial top-2
+// lists are merged through LDS with the (distance, train index) order of a sequential scan.
+// ---------------------------------------------------------------------------------------------
+struct Top2 {
+    int d0, i0, d1, i1;
+};
+// insert (d, i) into a (distance, train index)-ordered top-2 list; `use` = false leaves it unchanged
+__device__ __forceinline__ Top2 top2_insert(Top2 t, int d, int i, bool use)
+{
+    const bool b0 = use && ((d < t.d0) || (d == t.d0 && i < t.i0));
+    const bool b1 = use && !b0 && ((d < t.d1) || (d == t.d1 && i < t.i1));
+    Top2 r;
+    r.d1 = b0 ? t.d0 : (b1 ? d : t.d1);
+    r.i1 = b0 ? t.i0 : (b1 ? i : t.i1);
+    r.d0 = b0 ? d : t.d0;
+    r.i0 = b0 ? i : t.i0;
+    return r;
+}
+
+template <int DW>
+__global__ __launch_bounds__(256) void match_topk_kernel(BatchDev b, double ratio, double max_dist)
+{
+    const int pair = blockIdx.y;
+    const int n1 = b.n1[pair], n2 = b.n2[pair];
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= n2)
+        return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = q0 + lane;
+    const bool live = q < n2;
+    const size_t base = (size_t)pair * b.max_kp;
+
+    uint32_t qv[DW];
+    {
+        const uint32_t *qd = b.desc2 + (base + (live ? q : q0)) * DW;
+#pragma unroll
+        for (int k = 0; k < DW; k += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(qd + k);
+            qv[k] = v.x; qv[k + 1] = v.y; qv[k + 2] = v.z; qv[k + 3] = v.w;
+        }
+    }
+    const uint32_t *tr = b.desc1 + base * DW;
+    const int chunk = (n1 + 3) >> 2;
+    const int t0 = __builtin_amdgcn_readfirstlane(w * chunk);
+    const int t1 = min(n1, t0 + chunk);
+
+    int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1, i1 = -1;
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t *td = tr + (size_t)t * DW;  // wave-uniform
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < DW; ++k)
+            d += __popc(qv[k] ^ td[k]);
+        // strict '<' insertion: equal distances keep the smaller train index first
+        if (d < d1) {
+            if (d < d0) {
+                d1 = d0; i1 = i0;
+                d0 = d;  i0 = t;
+            } else {
+                d1 = d; i1 = t;
+            }
+        }
+    }
+
+    __shared__ int s_d0[4][64], s_i0[4][64], s_d1[4][64], s_i1[4][64];
+    s_d0[w][lane] = d0; s_i0[w][lane] = i0; s_d1[w][lane] = d1; s_i1[w][lane] = i1;
+    __syncthreads();
+    if (w == 0 && live) {
+        Top2 t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int a0 = s_d0[c][lane], j0 = s_i0[c][lane], a1 = s_d1[c][lane], j1 = s_i1[c][lane];
+            t = top2_insert(t, a0, j0, j0 >= 0);
+            t = top2_insert(t, a1, j1, j1 >= 0);
+        }
+        const int D0 = t.d0, D1 = t.d1, I0 = t.i0;
+        // Lowe ratio in double on float distances (visual-feature.cpp:67-68)
+        const float f0 = (float)D0, f1 = (float)D1;
+        const bool check1 = (double)f0 < ratio * (double)f1;
+        const bool check2 = (max_dist < 0.0) || ((double)f0 <= max_dist);
+        const bool pass = (n1 >= 2) && check1 && check2;
+        b.knn_train[base + q] = pass ? I0 : -1;
+        b.knn_dist[base + q] = D0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// match_compact: grid P, block 1024.  Rank sort on key = (distance << 16 | queryIdx) held in LDS
+// (every thread streams the same keys -> LDS broadcast reads), then gathers both keypoints of
+// match m and applies K^-1.  Output m-th match / m-th point pair in canonical order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void match_compact_kernel(BatchDev b)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[kMaxKp];
+    __shared__ int s_count;
+    const int pair = blockIdx.x;
+    const int n2 = min(b.n2[pair], b.max_kp);
+    const size_t base = (size_t)pair * b.max_kp;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        s_count = 0;
+    const int n2p = (n2 + 3) & ~3;
+    for (int q = tid; q < n2p; q += 1024) {
+        uint32_t key = 0xffffffffu;
+        if (q < n2) {
+            const int tr = b.knn_train[base + q];
+            if (tr >= 0)
+                key = ((uint32_t)b.knn_dist[base + q] << 16) | (uint32_t)q;
+        }
+        s_key[q] = key;
+    }
+    __syncthreads();
+    int local = 0;
+    const double *Ki = b.Kinv + (size_t)pair * 9;
+    const double k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5];
+    for (int q = tid; q < n2; q += 1024) {
+        const uint32_t key = s_key[q];
+        if (key == 0xffffffffu)
+            continue;
+        ++local;
+        int rank = 0;
+        for (int j = 0; j < n2p; j += 4) {
+            const uint4 kk = *reinterpret_cast<const uint4 *>(&s_key[j]);
+            rank += (kk.x < key) + (kk.y < key) + (kk.z < key) + (kk.w < key);
+        }
+        const int tr = b.knn_train[base + q];
+        mvs_match m;
+        m.queryIdx = q;
+        m.trainIdx = tr;
+        m.imgIdx = 0;
+        m.distance = (float)(key >> 16);
+        b.matches[base + rank] = m;
+        // base_points[m] = kp1[trainIdx], pair_points[m] = kp2[queryIdx], float -> double, K^-1 (u, v, 1)
+        const float2 a = *reinterpret_cast<const float2 *>(b.kp1 + (base + tr) * 2);
+        const float2 c = *reinterpret_cast<const float2 *>(b.kp2 + (base + q) * 2);
+        const double u1 = (double)a.x, v1 = (double)a.y, u2 = (double)c.x, v2 = (double)c.y;
+        double4 p;
+        p.x = (k0 * u1 + k1 * v1) + k2;
+        p.y = (k3 * u1 + k4 * v1) + k5;
+        p.z = (k0 * u2 + k1 * v2) + k2;
+        p.w = (k3 * u2 + k4 * v2) + k5;
+        *reinterpret_cast<double4 *>(b.pts + (base + rank) * 4) = p;
+    }
+    if (local)
+        atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0)
+        b.M[pair] = s_count;
+}
+
+// prep_points: single-shot sfm_solve / sfm_triangulate entry: image points are given directly.
+// grid (ceil(N/256), P).  uv: [P][N][2] doubles; M[pair] preset by the host.
+__global__ __launch_bounds__(256) void prep_points_kernel(BatchDev b, const double *uv1, const double *uv2)
+{
+    const int pair = blockIdx.y;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= b.M[pair])
+        return;
+    const size_t base = (size_t)pair * b.max_kp;
+    const double *Ki = b.Kinv + (size_t)pair * 9;
+    const double u1 = uv1[(base + m) * 2], v1 = uv1[(base + m) * 2 + 1];
+    const double u2 = uv2[(base + m) * 2], v2 = uv2[(base + m) * 2 + 1];
+    double4 p;
+    p.x = (Ki[0] * u1 + Ki[1] * v1) + Ki[2];
+    p.y = (Ki[3] * u1 + Ki[4] * v1) + Ki[5];
+    p.z = (Ki[0] * u2 + Ki[1] * v2) + Ki[2];
+    p.w = (Ki[3] * u2 + Ki[4] * v2) + Ki[5];
+    *reinterpret_cast<double4 *>(b.pts + (base + m) * 4) = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ransac: grid (G, P), block 256 (one wave per SIMD; the 9x9 state needs the whole register file).
+// ---------------------------------------------------------------------------------------------
+struct Cand {
+    int cnt;
+    uint32_t hyp;
+    double res;
+};
+
+// the reference's sequential replacement rule (estimator-RANSAC.cpp:76-84) as a total order:
+// more inliers, then smaller residual, then smaller hypothesis id.
+__device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b)
+{
+    if (a.cnt != b.cnt)
+        return a.cnt > b.cnt;
+    if (a.res != b.res)
+        return a.res < b.res;
+    return a.hyp < b.hyp;
+}
+
+__device__ __forceinline__ double pair_max_error_sq(const BatchDev &b, const RunParams &rp, int pair)
+{
+    if (rp.max_error_sq > 0.0)
+        return rp.max_error_sq;
+    const double *K = b.K + (size_t)pair * 9;
+    return 5e-2 / K[0] / K[4];  // sfm-solve.cpp:311
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp)
+{
+    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int M = b.M[pair];
+    WgBest *out = b.wgbest + (size_t)pair * b.max_groups + g;
+    if (M < 8) {  // estimator-RANSAC.cpp:25-29
+        if (tid == 0) {
+            out->count = -1;
+            out->hyp = 0xffffffffu;
+            out->residual = 0.0;
+        }
+        return;
+    }
+    const int H = rp.num_hypotheses;
+    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
+    const bool live = h < (uint32_t)H;
+    const uint32_t hh = live ? h : (uint32_t)(H - 1);
+    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+
+    double F[9];
+    unsigned rot = 0, pairs = 0;
+    bool ok;
+    {
+        int idx[8];
+        sample8(seed, hh, M, rp.sampler, idx);
+        double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
+            x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
+        }
+        ok = eight_point(x1, y1, x2, y2, F, rot, pairs);
+    }
+
+    // score against all M matches; the point stream is wave-uniform (scalar loads), F is per lane.
+    const double thr = pair_max_error_sq(b, rp, pair);
+    int cnt = 0;
+    double res = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < M; ++i) {
+        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)i * 4);
+        const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+        const bool in = r < thr;  // strict (estimator-RANSAC.cpp:117)
+        cnt += in ? 1 : 0;
+        res += in ? r : 0.0;  // adding +0.0 is exact: identical to the conditional add
+    }
+    if (!ok || !live) {
+        cnt = -1;
+        res = 0.0;
+    }
+    if (b.hyp_count && live) {
+        b.hyp_count[(size_t)pair * H + h] = cnt;
+        b.hyp_residual[(size_t)pair * H + h] = res;
+    }
+    if (STATS) {
+        unsigned r = live ? rot : 0u, p = live ? pairs : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            r += __shfl_xor(r, o);
+            p += __shfl_xor(p, o);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&b.stats[0], (unsigned long long)r);
+            atomicAdd(&b.stats[1], (unsigned long long)p);
+        }
+    }
+
+    // workgroup arg-best
+    Cand me{cnt, h, res};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand other;
+        other.cnt = __shfl_xor(me.cnt, o);
+        other.hyp = __shfl_xor(me.hyp, o);
+        other.res = __shfl_xor(me.res, o);
+        if (cand_better(other, me))
+            me = other;
+    }
+    __shared__ Cand s_c[4];
+    __shared__ uint32_t s_win;
+    if ((tid & 63) == 0)
+        s_c[tid >> 6] = me;
+    __syncthreads();
+    if (tid == 0) {
+        Cand best = s_c[0];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2)
+            if (cand_better(s_c[w2], best))
+                best = s_c[w2];
+        s_win = best.hyp;
+        out->count = best.cnt;
+        out->hyp = best.hyp;
+        out->residual = best.res;
+    }
+    __syncthreads();
+    if (h == s_win) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            out->F[k] = F[k];
+    }
+}
+
+// find_fundamental_matrix on one explicit sample (single lane); diagnostics / API parity only.
+__global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, const double *p2, double *Fout, int *okout)
+{
+    if (threadIdx.x != 0)
+        return;
+    double x1[8], y1[8], x2[8], y2[8], F[9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        x1[k] = p1[2 * k]; y1[k] = p1[2 * k + 1];
+        x2[k] = p2[2 * k]; y2[k] = p2[2 * k + 1];
+    }
+    unsigned rot = 0, pairs = 0;
+    const bool ok = eight_point(x1, y1, x2, y2, F, rot, pairs);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        Fout[k] = F[k];
+    *okout = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: grid P, block 256.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFinThreads = 256;
+
+struct FinShared {
+    double F[9];
+    double E[9];
+    double R[2][9];   // Ra, Rb (raw)
+    double Rr[2][9];  // rectified (SO3 ctor) -> P2
+    double T[3];
+    int wave_tot[4];
+    int n_inl;
+    int ncand;
+    int cand_cnt[4];
+    int win;
+    int proceed;
+    Cand red[4];
+    uint32_t win_group;
+    uint16_t inl[kMaxKp];
+    uint8_t okf[4][kMaxKp];
+};
+
+// ordered compaction of {i in [0, n) : pred(i)}; emit(i, position); returns the count (block-uniform)
+template <typename Pred, typename Emit>
+__device__ __forceinline__ int block_compact(int n, int *s_tot, Pred pred, Emit emit)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int basepos = 0;
+    for (int start = 0; start < n; start += kFinThreads) {
+        const int i = start + tid;
+        const bool flag = (i < n) && pred(i);
+        const unsigned long long bal = __ballot(flag);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_tot[w] = __popcll(bal);
+        __syncthreads();
+        int off = basepos, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = s_tot[k];
+            off += (k < w) ? v : 0;
+            tot += v;
+        }
+        if (flag)
+            emit(i, off + pre);
+        basepos += tot;
+        __syncthreads();
+    }
+    return basepos;
+}
+
+__global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunParams rp, int mode)
+{
+    __shared__ FinShared s;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)pair * b.max_kp;
+    const int M = min(b.M[pair], b.max_kp);
+    mvs_pair_result *res = b.results + pair;
+    const double *P = b.pts + base * 4;
+    uint8_t *mask = b.mask + base;
+
+    if (tid == 0) {
+        s.proceed = 0;
+        s.n_inl = 0;
+        s.ncand = 4;
+    }
+    __syncthreads();
+
+    if (mode == kFinalizeFull) {
+        // ---- arg-best over the workgroup records (sequential-replacement order) ----
+        const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
+        Cand me{-2, 0xffffffffu, 0.0};
+        uint32_t mygroup = 0;
+        if (M >= 8) {
+            const WgBest *wb = b.wgbest + (size_t)pair * b.max_groups;
+            for (int g = tid; g < G; g += kFinThreads) {
+                Cand c{wb[g].count, wb[g].hyp, wb[g].residual};
+                if (c.cnt >= 0 && (me.cnt < -1 || cand_better(c, me))) {
+                    me = c;
+                    mygroup = g;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Cand other;
+            other.cnt = __shfl_xor(me.cnt, o);
+            other.hyp = __shfl_xor(me.hyp, o);
+            other.res = __shfl_xor(me.res, o);
+            const uint32_t og = __shfl_xor(mygroup, o);
+            if (other.cnt >= 0 && (me.cnt < -1 || cand_better(other, me))) {
+                me = other;
+                mygroup = og;
+            }
+        }
+        __shared__ uint32_t s_grp[4];
+        if ((tid & 63) == 0) {
+            s.red[tid >> 6] = me;
+            s_grp[tid >> 6] = mygroup;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Cand best = s.red[0];
+            uint32_t bg = s_grp[0];
+            for (int w = 1; w < 4; ++w)
+                if (s.red[w].cnt >= 0 && (best.cnt < -1 || cand_better(s.red[w], best))) {
+                    best = s.red[w];
+                    bg = s_grp[w];
+                }
+            res->valid = 0;
+            res->n_matches = M;
+            res->n_inliers = 0;
+            res->n_points = 0;
+            res->best_hyp = best.cnt >= 0 ? (int)best.hyp : -1;
+            res->best_count = best.cnt >= 0 ? best.cnt : 0;
+            res->best_residual = best.cnt >= 0 ? best.res : 0.0;
+            if (best.cnt >= 0) {
+                const WgBest *wb = b.wgbest + (size_t)pair * b.max_groups + bg;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    s.F[k] = wb->F[k];
+                    res->F[k] = wb->F[k];
+                }
+                s.proceed = 1;
+            }
+        }
+        __syncthreads();
+        if (!s.proceed) {
+            for (int i = tid; i < M; i += kFinThreads)
+                mask[i] = 0;
+            return;
+        }
+        // ---- inlier mask of the winner (estimator-RANSAC.cpp:100-129) ----
+        double F[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            F[k] = s.F[k];
+        const double thr = pair_max_error_sq(b, rp, pair);
+        for (int i = tid; i < M; i += kFinThreads) {
+            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)i * 4);
+            mask[i] = epipolar_residual(F, p.x, p.y, p.z, p.w) < thr ? 1 : 0;
+        }
+        __syncthreads();
+    } else if (tid == 0) {
+        res->valid = 0;
+        res->n_matches = M;
+        res->n_points = 0;
+        res->best_hyp = -1;
+        res->best_count = 0;
+        res->best_residual = 0.0;
+    }
+
+    // ---- ordered inlier list ----
+    const int n_inl = block_compact(
+        M, s.wave_tot, [&](int i) { return mask[i] != 0; }, [&](int i, int pos) { s.inl[pos] = (uint16_t)i; });
+
+    // ---- E projection + decomposition (single lane; sfm-solve.cpp:74-84,97-127) ----
+    if (tid == 0) {
+        res->n_inliers = n_inl;
+        unsigned rot = 0, prs = 0;
+        bool go = true;
+        if (mode == kFinalizeFull) {
+            double Fm[3][3], w[3], U[3][3], Vt[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Fm[i][j] = s.F[i * 3 + j];
+            svd3_full(Fm, w, U, Vt, rot, prs);
+            const double v = dsqrt(w[0] * w[1]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double a = U[i][0] * v, c = U[i][1] * v;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double e = a * Vt[0][j] + c * Vt[1][j];
+                    s.E[i * 3 + j] = e;
+                    res->E[i * 3 + j] = e;
+                }
+            }
+            // compute() returns best_count > 0 (estimator-RANSAC.cpp:89); sfm_solve needs >= min inliers (:330)
+            go = (res->best_count > 0) && (n_inl >= rp.min_inliers);
+        } else if (mode == kFinalizeFromE) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                s.E[k] = res->E[k];
+        }
+        if (mode == kFinalizeTriangulate) {
+            double R[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    R[i][j] = res->R1to2[i * 3 + j];
+                    s.R[0][i * 3 + j] = R[i][j];
+                }
+            rectify3(R);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    s.Rr[0][i * 3 + j] = R[i][j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                s.T[k] = res->t1to2[k];
+            s.ncand = 1;
+        } else if (go) {
+            double Em[3][3], w[3], U[3][3], Vt[3][3], V[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Em[i][j] = s.E[i * 3 + j];
+            svd3_full(Em, w, U, Vt, rot, prs);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    V[i][j] = Vt[j][i];
+            if (det3(U) < 0.0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        U[i][j] = -U[i][j];
+            }
+            if (det3(V) < 0.0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        V[i][j] = -V[i][j];
+            }
+            double Ra[3][3], Rb[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    Ra[i][j] = (U[i][1] * V[j][0] + (-U[i][0]) * V[j][1]) + U[i][2] * V[j][2];
+                    Rb[i][j] = ((-U[i][1]) * V[j][0] + U[i][0] * V[j][1]) + U[i][2] * V[j][2];
+                    s.R[0][i * 3 + j] = Ra[i][j];
+                    s.R[1][i * 3 + j] = Rb[i][j];
+                }
+            // S = U Z U^T, t = (-S12, S02, -S01)
+            s.T[0] = -((-U[1][1]) * U[2][0] + U[1][0] * U[2][1]);
+            s.T[1] = ((-U[0][1]) * U[2][0] + U[0][0] * U[2][1]);
+            s.T[2] = -((-U[0][1]) * U[1][0] + U[0][0] * U[1][1]);
+            rectify3(Ra);
+            rectify3(Rb);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    s.Rr[0][i * 3 + j] = Ra[i][j];
+                    s.Rr[1][i * 3 + j] = Rb[i][j];
+                }
+            s.ncand = 4;
+        }
+        s.proceed = go ? 1 : 0;
+        s.n_inl = n_inl;
+        s.cand_cnt[0] = s.cand_cnt[1] = s.cand_cnt[2] = s.cand_cnt[3] = 0;
+    }
+    __syncthreads();
+    if (!s.proceed || n_inl == 0)
+        return;
+
+    // ---- triangulation: item = (candidate c, inlier j); 4x4 DLT + SVD per lane (sfm-solve.cpp:134-227) ----
+    const int ncand = s.ncand;
+    double *cp = b.cand_pts + (size_t)pair * 4 * b.max_kp * 3;
+    const int items = ncand * n_inl;
+    for (int it = tid; it < items; it += kFinThreads) {
+        const int c = it / n_inl, j = it - c * n_inl;
+        const int i = s.inl[j];
+        const double *R = s.R[c >> 1], *Rr = s.Rr[c >> 1];
+        const bool flip = (c & 1) != 0;
+        const double t0 = flip ? -s.T[0] : s.T[0], t1 = flip ? -s.T[1] : s.T[1], t2 = flip ? -s.T[2] : s.T[2];
+        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)i * 4);
+        double At[4][4];  // At[col][row] of A
+        At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
+        At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
+        At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
+        At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
+        double X[4];
+        unsigned rot = 0, prs = 0;
+        svd4_last_vt_row(At, X, rot, prs);
+        bool okp = !(dabs(X[3]) < kTol);
+        const double scale = 1.0 / X[3];
+        const double px = X[0] * scale, py = X[1] * scale, pz = X[2] * scale;
+        okp = okp && !(pz < kTol);
+        const double z2 = ((R[6] * px + R[7] * py) + R[8] * pz) + t2;
+        okp = okp && !(z2 < kTol);
+        s.okf[c][j] = okp ? 1 : 0;
+        double *dst = cp + ((size_t)c * b.max_kp + j) * 3;
+        dst[0] = px; dst[1] = py; dst[2] = pz;
+    }
+    __syncthreads();
+    // ---- candidate selection: strictly more points wins, order (Ra,t),(Ra,-t),(Rb,t),(Rb,-t) ----
+    {
+        int cnt[4] = {0, 0, 0, 0};
+        for (int j = tid; j < n_inl; j += kFinThreads) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                cnt[c] += (c < ncand) ? s.okf[c][j] : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                cnt[c] += __shfl_xor(cnt[c], o);
+            if ((tid & 63) == 0 && cnt[c])
+                atomicAdd(&s.cand_cnt[c], cnt[c]);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0, win = -1;
+        for (int c = 0; c < ncand; ++c)
+            if (s.cand_cnt[c] > best) {
+                best = s.cand_cnt[c];
+                win = c;
+            }
+        s.win = win;
+    }
+    __syncthreads();
+    const int win = s.win;
+    if (win < 0)
+        return;  // recover_pose_and_points returned false
+    // ---- compact the winner's points in index order ----
+    const double *src = cp + (size_t)win * b.max_kp * 3;
+    const int n_pts = block_compact(
+        n_inl, s.wave_tot, [&](int j) { return s.okf[win][j] != 0; },
+        [&](int j, int pos) {
+            double *d = b.points + (base + pos) * 3;
+            d[0] = src[j * 3]; d[1] = src[j * 3 + 1]; d[2] = src[j * 3 + 2];
+            b.point_idx[base + pos] = s.inl[j];
+        });
+    // ---- pose2in1 = SE3(SO3(R), t).inverse()  (sfm-solve.cpp:364; lie-group.hpp:212-216) ----
+    if (tid == 0) {
+        const double *Rw = s.R[win >> 1];
+        const bool flip = (win & 1) != 0;
+        const double t[3] = {flip ? -s.T[0] : s.T[0], flip ? -s.T[1] : s.T[1], flip ? -s.T[2] : s.T[2]};
+        double Rr[3][3], RT[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Rr[i][j] = Rw[i * 3 + j];
+                res->R1to2[i * 3 + j] = Rw[i * 3 + j];
+            }
+        rectify3(Rr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                RT[i][j] = Rr[j][i];
+        rectify3(RT);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            res->t1to2[i] = t[i];
+            res->t[i] = -((RT[i][0] * t[0] + RT[i][1] * t[1]) + RT[i][2] * t[2]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                res->R[i * 3 + j] = RT[i][j];
+        }
+        res->n_points = n_pts;
+        res->valid = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
+{
+    const dim3 grid((b.max_kp + 63) / 64, n_active), block(256);
+    const double ratio = rp.ratio, md = rp.max_dist;
+    switch (b.desc_words) {
+    case 4: hipLaunchKernelGGL(match_topk_kernel<4>, grid, block, 0, stream, b, ratio, md); break;
+    case 8: hipLaunchKernelGGL(match_topk_kernel<8>, grid, block, 0, stream, b, ratio, md); break;
+    case 16: hipLaunchKernelGGL(match_topk_kernel<16>, grid, block, 0, stream, b, ratio, md); break;
+    default: break;
+    }
+}
+
+void launch_match_compact(const BatchDev &b, const RunParams &, int n_active, hipStream_t stream)
+{
+    hipLaunchKernelGGL(match_compact_kernel, dim3(n_active), dim3(1024), 0, stream, b);
+}
+
+void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2, int n_active, hipStream_t stream)
+{
+    hipLaunchKernelGGL(prep_points_kernel, dim3((b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b, uv1, uv2);
+}
+
+void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream)
+{
+    const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
+    const dim3 grid(G, n_active), block(kHypPerBlock);
+    if (stats)
+        hipLaunchKernelGGL(ransac_kernel<true>, grid, block, 0, stream, b, rp);
+    else
+        hipLaunchKernelGGL(ransac_kernel<false>, grid, block, 0, stream, b, rp);
+}
+
+void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b, rp, mode);
+}
+
+void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fundamental_kernel, dim3(1), dim3(64), 0, stream, p1, p2, F, ok);
+}
+
+}  // namespace mvs

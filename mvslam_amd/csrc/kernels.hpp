@@ -1,0 +1,88 @@
+// kernels.hpp -- device data layout + kernel launch interface (host side sees only PODs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvslam_hip.h"
+
+namespace mvs {
+
+constexpr int kMaxKp = 4096;          // capacity limit of one image (LDS lists in finalize/compact)
+constexpr int kHypPerBlock = 256;     // hypotheses per RANSAC workgroup (one per lane, 4 waves)
+constexpr int kMaxDescWords = 16;     // descriptor <= 64 bytes
+
+// Best hypothesis of one RANSAC workgroup.  count < 0: no valid hypothesis in the group.
+struct WgBest {
+    int32_t count;
+    uint32_t hyp;
+    double residual;
+    double F[9];
+};
+static_assert(sizeof(WgBest) == 88, "WgBest layout");
+
+// Resident state of a batch (all device pointers).  P pairs, capacity N keypoints per image.
+struct BatchDev {
+    int n_pairs;
+    int max_kp;       // N
+    int desc_words;   // descriptor bytes / 4
+    int max_groups;   // capacity of wgbest per pair
+
+    // inputs
+    const uint32_t *desc1;  // [P][N][desc_words]   base / train (vf1)
+    const uint32_t *desc2;  // [P][N][desc_words]   pair / query (vf2)
+    const float *kp1;       // [P][N][2]
+    const float *kp2;       // [P][N][2]
+    const int32_t *n1;      // [P]
+    const int32_t *n2;      // [P]
+    const double *Kinv;     // [P][9]  host-computed cofactor inverse (camera.cpp:16)
+    const double *K;        // [P][9]
+    const int64_t *gidx;    // [P] global pair index (sampler key offset)
+
+    // intermediates
+    int32_t *knn_train;  // [P][N] best train index per query, -1 = rejected
+    int32_t *knn_dist;   // [P][N]
+    int32_t *M;          // [P] number of matches
+    mvs_match *matches;  // [P][N]
+    double *pts;         // [P][N][4]  (x1, y1, x2, y2) ideal-camera coordinates of match m
+    WgBest *wgbest;      // [P][max_groups]
+    double *cand_pts;    // [P][4][N][3] triangulation scratch
+
+    // outputs
+    mvs_pair_result *results;  // [P]
+    uint8_t *mask;             // [P][N]
+    double *points;            // [P][N][3]
+    int32_t *point_idx;        // [P][N]
+
+    // optional per-hypothesis tables (single-shot diagnostics), may be null
+    int32_t *hyp_count;     // [P][H]
+    double *hyp_residual;   // [P][H]
+
+    // work statistics (instrumented replay only), may be null: {rotations9, pairs9}
+    unsigned long long *stats;
+};
+
+enum FinalizeMode : int {
+    kFinalizeFull = 0,      // reduce wgbest -> F -> mask -> E -> decompose -> triangulate -> pose
+    kFinalizeFromE = 1,     // results[p].E and mask are given
+    kFinalizeTriangulate = 2  // results[p].R1to2 / t1to2 given, mask given; one candidate
+};
+
+struct RunParams {
+    double ratio;
+    double max_dist;
+    double max_error_sq;  // <= 0: 5e-2 / K00 / K11 per pair
+    int num_hypotheses;
+    int sampler;
+    uint64_t seed;
+    int min_inliers;
+};
+
+// launch wrappers (all asynchronous on `stream`)
+void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
+void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
+void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2, int n_active, hipStream_t stream);
+void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream);
+void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
+void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream);
+
+}  // namespace mvs

@@ -1,0 +1,340 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): inlier indices / match lists / hypothesis tables BIT-EXACT;
+pose and points within 1e-4 relative.  Because oracle and kernels implement the same arithmetic
+contract, floating-point outputs are in fact expected to be bit-identical; the tests assert the
+contractual 1e-4 and additionally the much tighter TIGHT bound so any drift is caught early.
+"""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib as o
+from mvslam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4   # north_star tolerance for pose / points
+TIGHT = 1e-12    # what the shared arithmetic contract actually delivers
+
+
+def _rand_desc(rng, n, nbytes=32):
+    return rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+
+
+# ----------------------------------------------------------------------------- matcher
+@pytest.mark.parametrize("n_train,n_query,nbytes", [(2, 1, 32), (63, 65, 32), (500, 500, 32), (2000, 2000, 32),
+                                                     (257, 130, 16), (300, 301, 64)])
+def test_match_random_bit_exact(ctx, n_train, n_query, nbytes):
+    rng = np.random.default_rng(n_train * 7919 + n_query)
+    train, query = _rand_desc(rng, n_train, nbytes), _rand_desc(rng, n_query, nbytes)
+    # plant true matches so that the ratio test passes for some queries
+    k = min(n_train, n_query) // 2
+    for i in range(k):
+        query[i] = train[(i * 3) % n_train]
+        query[i, rng.integers(0, nbytes)] ^= np.uint8(1 << rng.integers(0, 8))
+    for ratio, max_dist in ((0.7, -1.0), (0.7, 10.0), (0.95, 200.0)):
+        ref = o.match_visual_features(train, query, ratio, max_dist)
+        got = ctx.match_hamming(train, query, ratio, max_dist)
+        assert len(got) == len(ref)
+        assert got.tobytes() == ref.tobytes()
+
+
+def test_match_ties_canonical_order(ctx):
+    """Constructed ties: equal distances must resolve to the smaller train index; equal-distance matches are
+    ordered by queryIdx (SURVEY 8(c) KAT 5)."""
+    rng = np.random.default_rng(5)
+    train = _rand_desc(rng, 64)
+    train[10] = train[3]          # duplicate rows: query == train[3] ties at distance 0 with index 10
+    train[40] = train[3]
+    query = np.stack([train[3], train[20], train[3], train[21]])
+    ref = o.match_visual_features(train, query, 0.7, -1.0)
+    got = ctx.match_hamming(train, query, 0.7, -1.0)
+    assert got.tobytes() == ref.tobytes()
+    # d0 == d1 == 0 for the duplicated rows -> ratio test 0 < 0.7*0 fails; the unique rows pass
+    assert sorted(got["queryIdx"].tolist()) == [1, 3]
+    assert got["trainIdx"].tolist() == [20, 21]
+
+
+def test_match_preconditions(ctx):
+    rng = np.random.default_rng(1)
+    with pytest.raises(capi.MvsError):
+        ctx.match_hamming(_rand_desc(rng, 1), _rand_desc(rng, 4))      # < 2 train rows (reference: UB)
+    with pytest.raises(capi.MvsError):
+        ctx.match_hamming(_rand_desc(rng, 4), np.zeros((0, 32), np.uint8))  # invalid VisualFeature (assert)
+    assert o.match_visual_features(_rand_desc(rng, 1), _rand_desc(rng, 4)) is None
+
+
+# ----------------------------------------------------------------------------- 8-point
+def test_find_fundamental_bitwise(ctx):
+    """The whole solve chain (normalise, A^T A, 9x9 + 3x3 Jacobi SVD, sqrt / div / fma) bit for bit."""
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        p1 = rng.uniform(-0.6, 0.6, size=(8, 2))
+        p2 = p1 + rng.normal(scale=0.05, size=(8, 2))
+        ok_r, F_r = o.find_fundamental_matrix(p1, p2)
+        ok_g, F_g = ctx.find_fundamental_matrix(p1, p2)
+        assert ok_r == ok_g
+        assert F_g.tobytes() == F_r.tobytes(), "trial %d: max diff %g" % (trial, np.abs(F_g - F_r).max())
+
+
+def test_find_fundamental_degenerate_sample(ctx):
+    p = np.tile(np.array([[0.1, 0.2]]), (8, 1))  # all points coincide -> scale == 0 (reference asserts)
+    ok_r, _ = o.find_fundamental_matrix(p, p)
+    ok_g, _ = ctx.find_fundamental_matrix(p, p)
+    assert not ok_r and not ok_g
+
+
+def _scene(seed, m, noise, outliers=0.3):
+    rng = np.random.default_rng(seed)
+    w = rng.normal(size=3)
+    w *= 0.08 / np.linalg.norm(w)
+    R = o.rodrigues(w)
+    t = np.array([0.3, 0.02, 0.01])
+    X = np.stack([rng.uniform(-2, 2, m), rng.uniform(-1.5, 1.5, m), rng.uniform(3, 9, m)], axis=1)
+    p1 = X[:, :2] / X[:, 2:3]
+    X2 = (R @ X.T).T + t
+    p2 = X2[:, :2] / X2[:, 2:3]
+    p1 = p1 + rng.normal(scale=noise, size=p1.shape)
+    p2 = p2 + rng.normal(scale=noise, size=p2.shape)
+    bad = rng.random(m) < outliers
+    p2[bad] = rng.uniform(-0.5, 0.5, size=(int(bad.sum()), 2))
+    return p1, p2
+
+
+@pytest.mark.parametrize("m,H,thr,noise", [(8, 1, 1e-3, 0.0), (9, 300, 1e-3, 1e-4), (100, 1000, 2e-3, 2e-4),
+                                           (777, 2048, 1e-3, 2e-4), (1500, 513, 1e-7, 1e-3)])
+def test_ransac_tables_bit_exact(ctx, m, H, thr, noise):
+    """Every hypothesis' inlier count and residual sum, the winner and its mask: bit-exact."""
+    p1, p2 = _scene(m * 31 + H, m, noise)
+    ref = o.ransac_fundamental(p1, p2, thr, H, o.SAMPLER_PHILOX, seed=0xABCDEF12345, per_hyp=True)
+    got = ctx.ransac_fundamental(p1, p2, thr, H, capi.SAMPLER_PHILOX, seed=0xABCDEF12345, per_hyp=True)
+    assert np.array_equal(got["count"], ref["count"])
+    assert got["residual"].tobytes() == ref["residual"].tobytes()
+    assert got["best_hyp"] == ref["best_hyp"] and got["best_count"] == ref["best_count"]
+    assert got["best_residual"] == ref["best_residual"]
+    assert np.array_equal(got["mask"], ref["mask"])
+    assert got["F"].tobytes() == ref["F"].tobytes()
+    assert got["ok"] == ref["ok"]
+
+
+def test_ransac_identity_sampler_is_reference_behaviour(ctx):
+    """H = 1 + identity sample = the reference as shipped: one fit on the first 8 matches."""
+    p1, p2 = _scene(3, 50, 1e-4, outliers=0.0)
+    ref = o.ransac_fundamental(p1, p2, 1e-3, 1, o.SAMPLER_IDENTITY)
+    got = ctx.ransac_fundamental(p1, p2, 1e-3, 1, capi.SAMPLER_IDENTITY)
+    ok, F8 = o.find_fundamental_matrix(p1[:8], p2[:8])
+    assert ok and got["F"].tobytes() == F8.tobytes() == ref["F"].tobytes()
+    assert np.array_equal(got["mask"], ref["mask"]) and got["best_hyp"] == 0
+
+
+def test_ransac_too_few_points(ctx):
+    p1, p2 = _scene(4, 7, 0.0)
+    got = ctx.ransac_fundamental(p1, p2, 1e-3, 10)
+    assert not got["ok"] and got["best_hyp"] == -1     # estimator-RANSAC.cpp:25-29
+
+
+# ----------------------------------------------------------------------------- sfm_solve / triangulate KATs
+def _check_two_view(got, ref, m):
+    assert got["ok"] == ref["ok"]
+    assert got["best_hyp"] == ref["best_hyp"] and got["best_count"] == ref["best_count"]
+    assert np.array_equal(got["mask"], ref["mask"][:m])                  # inlier indices: bit-exact
+    if ref["ok"]:
+        assert np.array_equal(got["point_idx"], ref["point_idx"])         # surviving indices: bit-exact
+        for k in ("R", "t", "E", "F", "R1to2", "t1to2"):
+            assert helpers.rel_err(got[k], ref[k]) <= REL_TOL, k
+            assert helpers.rel_err(got[k], ref[k]) <= TIGHT, k
+        assert helpers.rel_err(got["points"], ref["points"]) <= REL_TOL
+        assert helpers.rel_err(got["points"], ref["points"]) <= TIGHT
+
+
+def test_sfm_solve_L_shape_kat(ctx):
+    """test/test-sfm.cpp geometry with the L-shaped rig (the cube is degenerate for the 8-point solver,
+    SURVEY section 0.3): pose.ln() == (1,0,0,0,0,0), the 8 points recovered in input order, tol 1e-3."""
+    for se3 in ((1, 0, 0, 0, 0, 0), (1, 0, 0, 0, 0.1, 0)):
+        rig = helpers.two_camera_rig("L", rpy=(1.5, 0.7, 0.0), scale=0.5, se3_2to1=se3)
+        prm = capi.default_params()               # H = 1, identity sampler: the reference as shipped
+        got = ctx.two_view(rig["uv1"], rig["uv2"], rig["K"], prm)
+        ref = o.sfm_solve(rig["uv1"], rig["uv2"], rig["K"], o.make_params(1, o.SAMPLER_IDENTITY))
+        _check_two_view(got, ref, 8)
+        assert got["ok"] and got["n_points"] == 8
+        # the reconstruction is up to scale with |t| = 1: compare after scaling by the true baseline
+        base = np.linalg.norm(rig["pose2in1"][1])
+        assert np.abs(o.se3_ln(got["R"], got["t"] * base) - np.array(se3, dtype=float)).max() < 1e-3
+        assert np.abs(got["points"] * base - rig["X"]).max() < 1e-3
+        assert got["point_idx"].tolist() == list(range(8))
+
+
+def test_sfm_triangulate_cube_kat(ctx):
+    """test/test-sfm.cpp:92-155."""
+    rig = helpers.two_camera_rig("cube")
+    R12, t12 = rig["T1to2"]
+    pts, idx = ctx.triangulate(rig["uv1"], rig["uv2"], rig["K"], R12, t12)
+    ref_pts, ref_idx = o.sfm_triangulate(rig["uv1"], rig["uv2"], rig["K"], (np.eye(3), np.zeros(3)), rig["pose2in1"])
+    assert idx.tolist() == ref_idx.tolist() == list(range(8))
+    assert np.abs(pts - rig["X"]).max() < 1e-3
+    assert helpers.rel_err(pts, ref_pts) <= TIGHT
+
+
+def test_recover_pose_cube_kat(ctx):
+    """test/test-sfm.cpp:17-90 with the analytic essential matrix: exercises decomposition with an EXACTLY zero
+    singular value (the OpenCV random-completion path), 4-candidate selection and the pose convention."""
+    rig = helpers.two_camera_rig("cube")
+    R12, t12 = rig["T1to2"]
+    E = helpers.skew(t12) @ R12
+    got = ctx.recover_pose(E, rig["uv1"], rig["uv2"], rig["K"])
+    ok, R, t, pts, idx = o.recover_pose_and_points(E, rig["uv1"], rig["uv2"])
+    assert got["ok"] and ok
+    assert got["point_idx"].tolist() == idx.tolist() == list(range(8))
+    assert np.abs(o.se3_ln(got["R"], got["t"]) - np.array([1, 0, 0, 0, 0, 0.0])).max() < 1e-3
+    assert np.abs(got["points"] - rig["X"]).max() < 1e-3
+    assert helpers.rel_err(got["R1to2"], R) <= TIGHT and helpers.rel_err(got["points"], pts) <= TIGHT
+
+
+@pytest.mark.parametrize("m,H,noise,thr", [(60, 256, 1e-4, 1e-3), (400, 1500, 2e-4, 2e-3), (1600, 700, 1e-3, 1e-2)])
+def test_two_view_random_scenes(ctx, m, H, noise, thr):
+    rng = np.random.default_rng(m)
+    K = np.array([[525.0, 0, 320], [0, 525, 240], [0, 0, 1]])
+    p1, p2 = _scene(m + 1, m, noise)
+    uv1 = p1 * 525 + np.array([320, 240.0])
+    uv2 = p2 * 525 + np.array([320, 240.0])
+    seed = int(rng.integers(0, 2**62))
+    got = ctx.two_view(uv1, uv2, K, capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=seed,
+                                                        max_error_sq=thr))
+    ref = o.sfm_solve(uv1, uv2, K, o.make_params(H, o.SAMPLER_PHILOX, seed, thr))
+    _check_two_view(got, ref, m)
+    assert ref["ok"] and ref["n_points"] > 8
+
+
+def test_two_view_errors(ctx):
+    rig = helpers.two_camera_rig("L", rpy=(1.5, 0.7, 0.0), scale=0.5)
+    prm = capi.default_params()
+    got = ctx.two_view(rig["uv1"][:7], rig["uv2"][:7], rig["K"], prm)       # < 8 pairs: false, never aborts
+    assert not got["ok"]
+    Kbad = np.array([[1, 0, 0], [0, 1, 0], [0.1, 0, 1.0]])
+    with pytest.raises(capi.MvsError):
+        ctx.two_view(rig["uv1"], rig["uv2"], Kbad, prm)
+
+
+# ----------------------------------------------------------------------------- batched pipeline
+def _run_batch(ctx, first, count, n_kp, prm, **gen):
+    data = synth.make_batch(first, count, n_kp=n_kp, **gen)
+    b = capi.Batch(ctx, count, n_kp, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+             data["global_index"])
+    b.run(prm)
+    b.sync()
+    out = b.download()
+    b.close()
+    return data, out
+
+
+def _check_batch_against_oracle(data, out, prm, n1=None, n2=None):
+    count = len(out["results"])
+    for i in range(count):
+        a1 = data["n1"][i] if n1 is None else n1[i]
+        a2 = data["n2"][i] if n2 is None else n2[i]
+        oprm = o.make_params(prm.num_hypotheses, prm.sampler, prm.seed + int(data["global_index"][i]),
+                             prm.max_error_sq, prm.min_inliers)
+        ref = o.image_pair(data["desc1"][i][:a1], data["kp1"][i][:a1], data["desc2"][i][:a2], data["kp2"][i][:a2],
+                           data["K"][i].reshape(3, 3), oprm, prm.ratio, prm.max_dist)
+        r = out["results"][i]
+        M = ref["n_matches"]
+        assert r["n_matches"] == M
+        assert out["matches"][i][:M].tobytes() == ref["matches"].tobytes()           # match list: bit-exact
+        assert bool(r["valid"]) == ref["ok"]
+        assert r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"]
+        assert np.array_equal(out["mask"][i][:M], ref["mask"])                        # inlier set: bit-exact
+        if ref["ok"]:
+            n = ref["n_points"]
+            assert r["n_points"] == n and r["n_inliers"] == ref["n_inliers"]
+            assert np.array_equal(out["point_idx"][i][:n], ref["point_idx"])
+            assert helpers.rel_err(out["points"][i][:n], ref["points"]) <= REL_TOL
+            assert helpers.rel_err(r["R"], ref["R"]) <= REL_TOL and helpers.rel_err(r["t"], ref["t"]) <= REL_TOL
+            assert helpers.rel_err(out["points"][i][:n], ref["points"]) <= TIGHT
+            assert helpers.rel_err(r["R"], ref["R"]) <= TIGHT and helpers.rel_err(r["t"], ref["t"]) <= TIGHT
+
+
+def test_batch_pipeline_parity_healthy(ctx):
+    """8 pairs x 600 keypoints, 0.5 px noise, explicit threshold: the whole path incl. triangulation."""
+    prm = capi.default_params(num_hypotheses=1024, sampler=capi.SAMPLER_PHILOX, seed=0x5EED0000, max_error_sq=1e-2)
+    data, out = _run_batch(ctx, 100, 8, 600, prm)
+    _check_batch_against_oracle(data, out, prm)
+    assert out["results"]["valid"].all() and (out["results"]["n_points"] > 100).all()
+
+
+def test_batch_pipeline_parity_reference_threshold(ctx):
+    """Reference threshold 5e-2/K00/K11 (sfm-solve.cpp:311): tiny inlier sets, ties broken by the residual sum --
+    the regime where only a bit-exact solve chain agrees with the oracle."""
+    prm = capi.default_params(num_hypotheses=1500, sampler=capi.SAMPLER_PHILOX, seed=77)
+    data, out = _run_batch(ctx, 7, 6, 500, prm)
+    _check_batch_against_oracle(data, out, prm)
+    prm0 = capi.default_params(num_hypotheses=700, sampler=capi.SAMPLER_PHILOX, seed=78)
+    data, out = _run_batch(ctx, 7, 4, 500, prm0, noise_px=0.0)
+    _check_batch_against_oracle(data, out, prm0)
+    assert out["results"]["valid"].all()
+
+
+def test_batch_ragged_and_empty_pairs(ctx):
+    """Ragged keypoint counts, an empty image, an image with one descriptor, and a pair with < 8 matches."""
+    n_kp, count = 320, 6
+    data = synth.make_batch(40, count, n_kp=n_kp)
+    n1 = np.array([320, 200, 0, 1, 320, 64], dtype=np.int32)
+    n2 = np.array([320, 320, 100, 50, 0, 7], dtype=np.int32)
+    b = capi.Batch(ctx, count, n_kp, 32)
+    b.upload(0, data["desc1"], data["kp1"], n1, data["desc2"], data["kp2"], n2, data["K"], data["global_index"])
+    prm = capi.default_params(num_hypotheses=300, sampler=capi.SAMPLER_PHILOX, seed=5, max_error_sq=1e-2)
+    b.run(prm)
+    out = b.download()
+    b.close()
+    res = out["results"]
+    for i in (2, 3, 4):   # invalid VisualFeature / < 2 train rows: no matches, no model, nothing aborts
+        assert res["n_matches"][i] == 0 and not res["valid"][i]
+    keep = [0, 1, 5]
+    sub = {k: v[keep] for k, v in data.items()}
+    sub_out = {k: v[keep] for k, v in out.items()}
+    _check_batch_against_oracle(sub, sub_out, prm, n1[keep], n2[keep])
+
+
+def test_full_size_pair_50k_hypotheses(ctx):
+    """BASELINE config 2: one 2000-keypoint pair, 50 000 hypotheses, checked against the oracle end to end."""
+    prm = capi.default_params(num_hypotheses=50000, sampler=capi.SAMPLER_PHILOX, seed=0x5EED0000, max_error_sq=1e-2)
+    data, out = _run_batch(ctx, 0, 1, 2000, prm)
+    _check_batch_against_oracle(data, out, prm)
+    r = out["results"][0]
+    assert r["valid"] and r["n_matches"] > 1400 and r["n_points"] > 900
+
+
+def test_full_size_properties(ctx):
+    """Size-independent properties at BASELINE sizes (no oracle): determinism, shard invariance (pair p gives the
+    same result alone as inside a batch), mask/count consistency, cheirality of every returned point, sorted match
+    lists, epipolar residual of every inlier under the returned F below the threshold."""
+    prm = capi.default_params(num_hypotheses=50000, sampler=capi.SAMPLER_PHILOX, seed=0x5EED0000, max_error_sq=1e-2)
+    data, out = _run_batch(ctx, 200, 3, 2000, prm)
+    data1, out1 = _run_batch(ctx, 201, 1, 2000, prm)
+    assert out["results"][1].tobytes() == out1["results"][0].tobytes()          # shard invariance + determinism
+    M1 = out["results"][1]["n_matches"]
+    assert out["matches"][1][:M1].tobytes() == out1["matches"][0][:M1].tobytes()
+    assert np.array_equal(out["mask"][1][:M1], out1["mask"][0][:M1])
+    for i in range(3):
+        r = out["results"][i]
+        M, n = r["n_matches"], r["n_points"]
+        mt = out["matches"][i][:M]
+        key = mt["distance"].astype(np.int64) * 65536 + mt["queryIdx"]
+        assert (np.diff(key) > 0).all()                                          # sorted by (distance, queryIdx)
+        assert len(set(mt["queryIdx"].tolist())) == M
+        assert out["mask"][i][:M].sum() == r["n_inliers"] == r["best_count"]
+        idx = out["point_idx"][i][:n]
+        assert (np.diff(idx) > 0).all() and out["mask"][i][idx].all()            # ordered subset of the inliers
+        pts = out["points"][i][:n]
+        assert (pts[:, 2] > 0).all()
+        z2 = (r["R1to2"] @ pts.T).T[:, 2] + r["t1to2"][2]
+        assert (z2 > 0).all()                                                    # cheirality in both cameras
+        Kinv = np.linalg.inv(data["K"][i].reshape(3, 3))
+        x1 = (Kinv @ np.c_[data["kp1"][i][mt["trainIdx"]].astype(float), np.ones(M)].T).T
+        x2 = (Kinv @ np.c_[data["kp2"][i][mt["queryIdx"]].astype(float), np.ones(M)].T).T
+        res = np.abs(np.einsum("ij,jk,ik->i", x2, r["F"], x1))
+        inl = out["mask"][i][:M].astype(bool)
+        assert (res[inl] < 1e-2 * (1 + 1e-9)).all() and (res[~inl] > 1e-2 * (1 - 1e-9)).all()
+        assert abs(np.linalg.norm(r["t1to2"]) - 1.0) < 1e-9
+        assert np.abs(r["R"] @ r["R"].T - np.eye(3)).max() < 1e-9
