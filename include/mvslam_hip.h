@@ -186,6 +186,10 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
  * to a collective (RCCL all-gather of poses) without a host round trip. */
 mvs_status mvs_batch_results_device(mvs_batch *b, void **dev_ptr, size_t *record_bytes);
 
+/* Asynchronous device-to-device copy (on the ctx stream) of the result records of pairs [first, first + count)
+ * into caller-owned DEVICE memory, e.g. a torch tensor that is then all-gathered over RCCL. */
+mvs_status mvs_batch_copy_results_device(mvs_batch *b, int first, int count, void *dst_device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,7 @@ EXPORTS = [
     "mvs_triangulate", "mvs_recover_pose", "mvs_find_fundamental_matrix", "mvs_ransac_fundamental",
     "mvs_batch_create", "mvs_batch_destroy", "mvs_batch_upload", "mvs_batch_run", "mvs_batch_sync",
     "mvs_batch_time", "mvs_batch_download", "mvs_batch_stats", "mvs_batch_results_device",
+    "mvs_batch_copy_results_device",
 ]
 
 
@@ -329,6 +330,12 @@ class Batch:
                                       _ptr(pts, C.c_double), _ptr(idx, C.c_int64))
         self.ctx._check(st, "mvs_batch_download")
         return dict(results=res, matches=mt, mask=mk, points=pts, point_idx=idx)
+
+    def copy_results_device(self, dst_ptr, first=0, count=None):
+        """async D2D copy of the fixed-size result records into caller-owned device memory (e.g. a torch tensor)"""
+        st = lib().mvs_batch_copy_results_device(self._h, C.c_int(first), C.c_int(count or self.n_pairs - first),
+                                                 C.c_void_p(dst_ptr))
+        self.ctx._check(st, "mvs_batch_copy_results_device")
 
     def results_device(self):
         p = C.c_void_p()

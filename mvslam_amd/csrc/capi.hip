@@ -505,6 +505,16 @@ mvs_status mvs_batch_results_device(mvs_batch *b, void **dev_ptr, size_t *record
     return MVS_OK;
 }
 
+mvs_status mvs_batch_copy_results_device(mvs_batch *b, int first, int count, void *dst_device)
+{
+    if (!b || !dst_device || first < 0 || count < 1 || first + count > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+    HIP_TRY(b->ctx, hipMemcpyAsync(dst_device, b->d.results + first, (size_t)count * sizeof(mvs_pair_result),
+                                   hipMemcpyDeviceToDevice, b->ctx->stream));
+    return MVS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // single-shot entry points: a resident batch of one pair owned by the context
 // ---------------------------------------------------------------------------------------------
