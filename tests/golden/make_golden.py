@@ -1,0 +1,80 @@
+"""Generates tests/golden/*.npz: small input/expected-output vectors for the hot path.
+
+The reference itself cannot run in this container (no OpenCV/Eigen/GTSAM), so these vectors come
+from the CPU oracle AFTER it has been pinned by the reference's own known answers (tests/test_oracle_kat.py:
+test-svd, test-sfm cube/L-shape geometry, test-lie-group, test-camera).  They are data only -- inputs and expected
+outputs -- and serve two purposes: (1) regression pin for the oracle, (2) oracle-free expected values for the
+GPU tests.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import helpers  # noqa: E402
+import oracle_lib as o  # noqa: E402
+from mvslam_amd import synth  # noqa: E402
+
+
+def main():
+    rng = np.random.default_rng(20261003)
+    # ---- matcher: random descriptors with planted matches and constructed ties
+    train = rng.integers(0, 256, size=(96, 32), dtype=np.uint8)
+    query = rng.integers(0, 256, size=(80, 32), dtype=np.uint8)
+    for i in range(40):
+        query[i] = train[(5 * i) % 96]
+        query[i, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+    train[90] = train[7]   # duplicate train rows -> distance ties
+    query[70] = train[7]
+    out = {}
+    for tag, (ratio, md) in {"a": (0.7, -1.0), "b": (0.7, 10.0), "c": (0.9, 120.0)}.items():
+        out["matches_" + tag] = o.match_visual_features(train, query, ratio, md)
+        out["params_" + tag] = np.array([ratio, md])
+    np.savez_compressed(os.path.join(HERE, "match_small.npz"), train=train, query=query, **out)
+
+    # ---- RANSAC tables on a small synthetic scene
+    import test_gpu_parity as T  # the scene generator only
+
+    p1, p2 = T._scene(4242, 120, 2e-4)
+    r = o.ransac_fundamental(p1, p2, 1.5e-3, 384, o.SAMPLER_PHILOX, seed=0x1234ABCD5678, per_hyp=True)
+    np.savez_compressed(os.path.join(HERE, "ransac_small.npz"), p1=p1, p2=p2, thr=1.5e-3, H=384,
+                        seed=np.uint64(0x1234ABCD5678), count=r["count"], residual=r["residual"], F=r["F"],
+                        mask=r["mask"], best=np.array([r["best_hyp"], r["best_count"]]),
+                        best_residual=r["best_residual"],
+                        samples=np.stack([o.sample8(0x1234ABCD5678, h, 120) for h in range(384)]))
+
+    # ---- two full image pairs (match -> RANSAC -> decomposition -> triangulation)
+    d = synth.make_batch(900, 2, n_kp=256)
+    res = []
+    for i in range(2):
+        prm = o.make_params(256, o.SAMPLER_PHILOX, 0x5EED0000 + 900 + i, 1e-2)
+        res.append(o.image_pair(d["desc1"][i], d["kp1"][i], d["desc2"][i], d["kp2"][i], d["K"][i].reshape(3, 3), prm,
+                                0.7, 10.0))
+    pack = {k: d[k] for k in ("desc1", "kp1", "desc2", "kp2", "K", "global_index")}
+    for i, r in enumerate(res):
+        for k in ("matches", "mask", "points", "point_idx", "R", "t", "F", "E", "R1to2", "t1to2"):
+            pack["%s_%d" % (k, i)] = r[k]
+        pack["scalars_%d" % i] = np.array([r["ok"], r["n_matches"], r["n_inliers"], r["n_points"], r["best_hyp"],
+                                           r["best_count"]], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "image_pair_small.npz"), H=256, seed=np.uint64(0x5EED0000),
+                        max_error_sq=1e-2, **pack)
+
+    # ---- reference test geometry (test/test-sfm.cpp, test/unit-test-helper.cpp)
+    L = helpers.two_camera_rig("L", rpy=(1.5, 0.7, 0.0), scale=0.5)
+    cube = helpers.two_camera_rig("cube")
+    rl = o.sfm_solve(L["uv1"], L["uv2"], L["K"], o.make_params(1, o.SAMPLER_IDENTITY))
+    tp, ti = o.sfm_triangulate(cube["uv1"], cube["uv2"], cube["K"], (np.eye(3), np.zeros(3)), cube["pose2in1"])
+    np.savez_compressed(os.path.join(HERE, "rig_kat.npz"), L_uv1=L["uv1"], L_uv2=L["uv2"], L_X=L["X"], L_R=rl["R"],
+                        L_t=rl["t"], L_points=rl["points"], L_F=rl["F"], cube_uv1=cube["uv1"], cube_uv2=cube["uv2"],
+                        cube_X=cube["X"], cube_R12=cube["T1to2"][0], cube_t12=cube["T1to2"][1], cube_points=tp,
+                        cube_idx=ti)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
