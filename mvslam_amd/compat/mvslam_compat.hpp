@@ -1,0 +1,595 @@
+// mvslam_compat.hpp -- the reference's C++ call surface for the two-view path, on top of the C ABI.
+//
+// Header-only.  Same names, argument meaning and error behaviour as the reference
+// (namespace mvSLAM): VisualFeature::match_visual_features / match_and_filter_visual_features,
+// sfm_solve, sfm_triangulate, find_fundamental_matrix, FundamentalMatrixEstimatorRANSAC, ImagePair,
+// SO3 / SE3 / PinholeCamera.  The arithmetic of the path runs in libmvslam_hip.so (HIP kernels);
+// this file only marshals arguments, exactly where the reference crosses from its callers
+// (front-end/image-pair.cpp:57,146; utility/reconstruct-scene.cpp:40,48) into source/vision/.
+//
+// OpenCV and Eigen are not available in the build image, so layout-compatible stand-ins are
+// defined here (KeyPoint, DMatch, Mat8u, Vector3Type, Matrix3Type).  In the real tree compile with
+// -DMVSLAM_HAVE_OPENCV / -DMVSLAM_HAVE_EIGEN and the adapters at the bottom convert from the real
+// types without touching the call sites.
+#pragma once
+
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mvslam_hip.h"
+
+namespace mvSLAM
+{
+// ---- system-config.hpp:6-14 -----------------------------------------------------------------
+using ScalarType = double;
+constexpr ScalarType epsilon = std::numeric_limits<ScalarType>::epsilon();
+constexpr ScalarType tolerance = epsilon * 1000;
+constexpr ScalarType taylor_threshold = static_cast<ScalarType>(1e-5);
+constexpr ScalarType infinity = std::numeric_limits<ScalarType>::max() / 10;
+
+// ---- math/matrix.hpp: minimal fixed-size stand-ins for the Eigen typedefs --------------------
+struct Vector3Type
+{
+    ScalarType v[3];
+    Vector3Type() : v{0, 0, 0} {}
+    Vector3Type(ScalarType x, ScalarType y, ScalarType z) : v{x, y, z} {}
+    ScalarType &operator[](size_t i) { return v[i]; }
+    const ScalarType &operator[](size_t i) const { return v[i]; }
+    ScalarType &operator()(size_t i) { return v[i]; }
+    const ScalarType &operator()(size_t i) const { return v[i]; }
+    ScalarType x() const { return v[0]; }
+    ScalarType y() const { return v[1]; }
+    ScalarType z() const { return v[2]; }
+    ScalarType norm() const { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+    static Vector3Type Zero() { return Vector3Type(); }
+};
+inline Vector3Type operator-(const Vector3Type &a) { return Vector3Type(-a[0], -a[1], -a[2]); }
+inline Vector3Type operator+(const Vector3Type &a, const Vector3Type &b) { return Vector3Type(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+
+struct Matrix3Type
+{
+    ScalarType m[9];  // row-major
+    Matrix3Type() { std::memset(m, 0, sizeof(m)); }
+    ScalarType &operator()(size_t r, size_t c) { return m[r * 3 + c]; }
+    const ScalarType &operator()(size_t r, size_t c) const { return m[r * 3 + c]; }
+    const ScalarType *data() const { return m; }
+    ScalarType *data() { return m; }
+    static Matrix3Type Identity()
+    {
+        Matrix3Type I;
+        I(0, 0) = I(1, 1) = I(2, 2) = 1;
+        return I;
+    }
+    Matrix3Type transpose() const
+    {
+        Matrix3Type T;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                T(j, i) = (*this)(i, j);
+        return T;
+    }
+    ScalarType trace() const { return (m[0] + m[4]) + m[8]; }
+};
+inline Matrix3Type operator*(const Matrix3Type &A, const Matrix3Type &B)
+{
+    Matrix3Type C;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C(i, j) = (A(i, 0) * B(0, j) + A(i, 1) * B(1, j)) + A(i, 2) * B(2, j);
+    return C;
+}
+inline Vector3Type operator*(const Matrix3Type &A, const Vector3Type &x)
+{
+    Vector3Type y;
+    for (int i = 0; i < 3; ++i)
+        y[i] = (A(i, 0) * x[0] + A(i, 1) * x[1]) + A(i, 2) * x[2];
+    return y;
+}
+using Vector6Type = std::array<ScalarType, 6>;
+
+template <typename T>
+constexpr T sqr(T x) { return x * x; }  // math/utility.hpp:8-12
+
+// ---- math/lie-group.{hpp,cpp} -----------------------------------------------------------------
+inline Matrix3Type skew_symmetric_matrix(const Vector3Type &v)
+{
+    Matrix3Type K;
+    K(0, 1) = -v[2]; K(0, 2) = v[1];
+    K(1, 0) = v[2];  K(1, 2) = -v[0];
+    K(2, 0) = -v[1]; K(2, 1) = v[0];
+    return K;
+}
+
+inline Matrix3Type rodrigues(const Vector3Type &v)  // lie-group.cpp:15-32
+{
+    const ScalarType theta = v.norm();
+    ScalarType A, B;
+    if (theta < epsilon) {
+        A = 1.0 - sqr(theta) / 6.0;
+        B = 0.5 - sqr(theta) / 24.0;
+    } else {
+        A = std::sin(theta) / theta;
+        B = (1.0 - std::cos(theta)) / sqr(theta);
+    }
+    const Matrix3Type K = skew_symmetric_matrix(v);
+    Matrix3Type BK;
+    for (int i = 0; i < 9; ++i)
+        BK.m[i] = B * K.m[i];
+    const Matrix3Type BKK = BK * K;
+    Matrix3Type R = Matrix3Type::Identity();
+    for (int i = 0; i < 9; ++i)
+        R.m[i] = (R.m[i] + A * K.m[i]) + BKK.m[i];
+    return R;
+}
+
+class SO3
+{
+public:
+    struct already_rectified_t {};
+    SO3() : _R(Matrix3Type::Identity()) {}
+    explicit SO3(const Matrix3Type &m) : _R(m) { rectify(); }  // lie-group.hpp:31-36
+    // adopt a matrix that already went through the SO3 constructor inside the library (no second Gram-Schmidt)
+    SO3(const Matrix3Type &m, already_rectified_t) : _R(m) {}
+    SO3(ScalarType roll, ScalarType pitch, ScalarType yaw)     // lie-group.hpp:41-56
+    {
+        Matrix3Type Rx = Matrix3Type::Identity(), Ry = Rx, Rz = Rx;
+        Rx(1, 1) = std::cos(roll);  Rx(1, 2) = -std::sin(roll); Rx(2, 1) = std::sin(roll);  Rx(2, 2) = std::cos(roll);
+        Ry(0, 0) = std::cos(pitch); Ry(0, 2) = std::sin(pitch); Ry(2, 0) = -std::sin(pitch); Ry(2, 2) = std::cos(pitch);
+        Rz(0, 0) = std::cos(yaw);   Rz(0, 1) = -std::sin(yaw);  Rz(1, 0) = std::sin(yaw);   Rz(1, 1) = std::cos(yaw);
+        _R = Rz * Ry * Rx;
+    }
+    SO3(const Vector3Type &so3) : _R(rodrigues(so3)) {}
+    const Matrix3Type &get_matrix() const { return _R; }
+    SO3 inverse() const { return SO3(_R.transpose()); }
+    void rectify()  // lie-group.hpp:84-96: row 1 is not re-normalised
+    {
+        Vector3Type u0(_R(0, 0), _R(0, 1), _R(0, 2));
+        const ScalarType n = u0.norm();
+        u0 = Vector3Type(u0[0] / n, u0[1] / n, u0[2] / n);
+        Vector3Type u1(_R(1, 0), _R(1, 1), _R(1, 2));
+        const ScalarType d = (u1[0] * u0[0] + u1[1] * u0[1]) + u1[2] * u0[2];
+        u1 = Vector3Type(u1[0] - d * u0[0], u1[1] - d * u0[1], u1[2] - d * u0[2]);
+        const Vector3Type u2(u0[1] * u1[2] - u0[2] * u1[1], u0[2] * u1[0] - u0[0] * u1[2], u0[0] * u1[1] - u0[1] * u1[0]);
+        for (int k = 0; k < 3; ++k) {
+            _R(0, k) = u0[k];
+            _R(1, k) = u1[k];
+            _R(2, k) = u2[k];
+        }
+    }
+    ScalarType get_roll() const { return std::atan2(_R(2, 1), _R(2, 2)); }
+    ScalarType get_pitch() const { return std::asin(-_R(2, 0)); }
+    ScalarType get_yaw() const { return std::atan2(_R(1, 0), _R(0, 0)); }
+    Vector3Type operator*(const Vector3Type &v) const { return _R * v; }
+    SO3 operator*(const SO3 &rhs) const { return SO3(_R * rhs._R); }
+    Vector3Type ln() const  // lie-group.hpp:138-162
+    {
+        ScalarType c = 0.5 * (_R.trace() - 1.0);
+        c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
+        const ScalarType theta = std::acos(c);
+        const Vector3Type v(_R(2, 1) - _R(1, 2), _R(0, 2) - _R(2, 0), _R(1, 0) - _R(0, 1));
+        const ScalarType A = theta < taylor_threshold ? (1.0 + sqr(theta) / 6.0) * 0.5 : 0.5 * theta / std::sin(theta);
+        return Vector3Type(v[0] * A, v[1] * A, v[2] * A);
+    }
+    static SO3 exp(const Vector3Type &so3) { return SO3(so3); }
+
+private:
+    Matrix3Type _R;
+};
+
+class SE3
+{
+public:
+    SE3(const SO3 &r, const Vector3Type &t) : _R(r), _t(t) {}
+    SE3() : _R(), _t() {}
+    const SO3 &rotation() const { return _R; }
+    const Vector3Type &translation() const { return _t; }
+    SE3 inverse() const  // lie-group.hpp:212-216
+    {
+        const SO3 RT = _R.inverse();
+        return SE3(RT, -(RT * _t));
+    }
+    Vector3Type operator*(const Vector3Type &v) const { return _R * v + _t; }
+    SE3 operator*(const SE3 &rhs) const { return SE3(_R * rhs._R, _R * rhs._t + _t); }
+    Vector6Type ln() const  // lie-group.hpp:245-269
+    {
+        const Vector3Type w = _R.ln();
+        const ScalarType theta = w.norm();
+        ScalarType G;
+        if (theta < taylor_threshold) {
+            G = 1.0 / 12.0 + sqr(theta) / 720.0;
+        } else {
+            const ScalarType A = std::sin(theta) / theta, B = (1.0 - std::cos(theta)) / sqr(theta);
+            G = (1.0 - 0.5 * A / B) / sqr(theta);
+        }
+        const Matrix3Type K = skew_symmetric_matrix(w);
+        Matrix3Type GK;
+        for (int i = 0; i < 9; ++i)
+            GK.m[i] = G * K.m[i];
+        const Matrix3Type GKK = GK * K;
+        Matrix3Type Vinv = Matrix3Type::Identity();
+        for (int i = 0; i < 9; ++i)
+            Vinv.m[i] = (Vinv.m[i] - 0.5 * K.m[i]) + GKK.m[i];
+        const Vector3Type u = Vinv * _t;
+        return Vector6Type{u[0], u[1], u[2], w[0], w[1], w[2]};
+    }
+    static SE3 exp(const Vector6Type &se3)  // lie-group.hpp:275-299
+    {
+        const Vector3Type u(se3[0], se3[1], se3[2]), w(se3[3], se3[4], se3[5]);
+        const ScalarType theta = w.norm();
+        ScalarType A, B, C;
+        if (theta < taylor_threshold) {
+            A = 1.0 - sqr(theta) / 6.0;
+            B = 0.5 - sqr(theta) / 24.0;
+            C = 1.0 / 6.0 - sqr(theta) / 120.0;
+        } else {
+            A = std::sin(theta) / theta;
+            B = (1.0 - std::cos(theta)) / sqr(theta);
+            C = (1.0 - A) / sqr(theta);
+        }
+        (void)A;
+        const Matrix3Type K = skew_symmetric_matrix(w);
+        Matrix3Type CK;
+        for (int i = 0; i < 9; ++i)
+            CK.m[i] = C * K.m[i];
+        const Matrix3Type CKK = CK * K;
+        Matrix3Type V = Matrix3Type::Identity();
+        for (int i = 0; i < 9; ++i)
+            V.m[i] = (V.m[i] + B * K.m[i]) + CKK.m[i];
+        return SE3(SO3::exp(w), V * u);
+    }
+
+private:
+    SO3 _R;
+    Vector3Type _t;
+};
+
+// ---- base/data-type.hpp:19-32, base/image.hpp:37-51 ---------------------------------------------
+using Point3 = Vector3Type;
+using Transformation = SE3;
+using CameraIntrinsics = Matrix3Type;
+using CameraExtrinsics = SE3;
+using IdealCameraImagePoint = Vector3Type;
+struct ImagePoint  // cv::Point_<double>
+{
+    ScalarType x, y;
+    ImagePoint() : x(0), y(0) {}
+    ImagePoint(ScalarType x_, ScalarType y_) : x(x_), y(y_) {}
+};
+struct Point2f { float x, y; };
+struct KeyPoint  // cv::KeyPoint layout
+{
+    Point2f pt;
+    float size, angle, response;
+    int octave, class_id;
+};
+using DMatch = mvs_match;  // cv::DMatch layout: queryIdx, trainIdx, imgIdx, distance
+struct Mat8u               // cv::Mat CV_8U, rows x cols, row-major, not owning
+{
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> data;
+    const uint8_t *row(int r) const { return data.data() + (size_t)r * cols; }
+    void push_back_row(const uint8_t *p)
+    {
+        data.insert(data.end(), p, p + cols);
+        ++rows;
+    }
+};
+struct VisualFeatureConfig
+{
+    using DetectorResultType = std::vector<KeyPoint>;
+    using ExtractorResultType = Mat8u;
+    using MatchResultType = std::vector<DMatch>;
+};
+
+// ---- the HIP backend handle ---------------------------------------------------------------------
+namespace hip
+{
+struct RansacConfig  // what the reference hard-codes (sfm-solve.cpp:67, estimator-RANSAC.cpp:41-42)
+{
+    int num_hypotheses = 1;
+    int sampler = MVS_SAMPLER_IDENTITY;
+    uint64_t seed = 0;
+    double max_error_sq = 0.0;  // <= 0: 5e-2 / K00 / K11 (sfm-solve.cpp:311)
+};
+inline RansacConfig &ransac_config()
+{
+    static thread_local RansacConfig cfg;
+    return cfg;
+}
+// one mvs_ctx per host thread; throws if there is no HIP device (there is no CPU fallback)
+inline mvs_ctx *context()
+{
+    struct Holder
+    {
+        mvs_ctx *ctx = nullptr;
+        ~Holder() { if (ctx) mvs_ctx_destroy(ctx); }
+    };
+    static thread_local Holder h;
+    if (!h.ctx) {
+        const mvs_status st = mvs_ctx_create(0, &h.ctx);
+        if (st != MVS_OK)
+            throw std::runtime_error(std::string("mvSLAM HIP backend: ") + mvs_status_str(st));
+    }
+    return h.ctx;
+}
+inline void check(mvs_status st, const char *what)
+{
+    if (st < 0)  // negative = the reference's assert()s / runtime failure
+        throw std::runtime_error(std::string(what) + ": " + mvs_status_str(st) + " [" + mvs_last_error(context()) + "]");
+}
+}  // namespace hip
+
+// ---- vision/camera.{hpp,cpp} (normalise / project only) -------------------------------------------
+class PinholeCamera
+{
+public:
+    PinholeCamera(const CameraIntrinsics &K_, const CameraExtrinsics &P_) : K(K_), P(P_) {}
+    ImagePoint project_point(const Point3 &p_world) const  // camera.cpp:24-37
+    {
+        const Vector3Type pc = P * p_world;
+        assert(pc[2] > 0);
+        const Vector3Type ph = K * pc;
+        return ImagePoint(ph[0] / ph[2], ph[1] / ph[2]);
+    }
+    std::vector<ImagePoint> project_points(const std::vector<Point3> &pts) const
+    {
+        std::vector<ImagePoint> r;
+        r.reserve(pts.size());
+        for (const auto &p : pts)
+            r.push_back(project_point(p));
+        return r;
+    }
+    const CameraIntrinsics &get_intrinsics() const { return K; }
+    const CameraExtrinsics &get_extrinsics() const { return P; }
+
+private:
+    CameraIntrinsics K;
+    CameraExtrinsics P;
+};
+
+// ---- vision/visual-feature.{hpp,cpp} --------------------------------------------------------------
+class VisualFeature
+{
+public:
+    VisualFeature() : m_image_width(-1), m_image_height(-1) {}
+    VisualFeature(std::vector<KeyPoint> kp, Mat8u desc, int w, int h)
+        : m_keypoints(std::move(kp)), m_descriptors(std::move(desc)), m_image_width(w), m_image_height(h) {}
+
+    // visual-feature.cpp:51-80.  a vector of {trainIdx -> vf1, queryIdx -> vf2, distance}
+    static VisualFeatureConfig::MatchResultType match_visual_features(const VisualFeature &vf1, const VisualFeature &vf2,
+                                                                     ScalarType max_dist = -1)
+    {
+        assert(vf1.valid() && vf2.valid());
+        VisualFeatureConfig::MatchResultType out(vf2.size());
+        int n = 0;
+        hip::check(mvs_match_hamming(hip::context(), vf1.m_descriptors.data.data(), (int)vf1.size(),
+                                     vf2.m_descriptors.data.data(), (int)vf2.size(), vf1.m_descriptors.cols, 0.7,
+                                     max_dist, out.data(), &n),
+                   "match_visual_features");
+        out.resize(n);
+        return out;
+    }
+    // visual-feature.cpp:93-119 (the reference pushes vf2's descriptor rows into filtered1, :115; fixed here)
+    static std::pair<VisualFeature, VisualFeature> match_and_filter_visual_features(const VisualFeature &vf1,
+                                                                                   const VisualFeature &vf2,
+                                                                                   ScalarType max_dist = -1)
+    {
+        const auto matches = match_visual_features(vf1, vf2, max_dist);
+        assert(vf1.m_image_height == vf2.m_image_height && vf1.m_image_width == vf2.m_image_width);
+        VisualFeature f1, f2;
+        f1.m_image_height = f2.m_image_height = vf1.m_image_height;
+        f1.m_image_width = f2.m_image_width = vf1.m_image_width;
+        f1.m_descriptors.cols = f2.m_descriptors.cols = vf1.m_descriptors.cols;
+        for (const auto &m : matches) {
+            f1.m_keypoints.push_back(vf1.m_keypoints[m.trainIdx]);
+            f1.m_descriptors.push_back_row(vf1.m_descriptors.row(m.trainIdx));
+            f2.m_keypoints.push_back(vf2.m_keypoints[m.queryIdx]);
+            f2.m_descriptors.push_back_row(vf2.m_descriptors.row(m.queryIdx));
+        }
+        return std::make_pair(f1, f2);
+    }
+    size_t size() const { return m_keypoints.size(); }
+    bool valid() const { return size() > 0 && m_image_width > 0 && m_image_height > 0; }  // :209-213
+    const std::vector<KeyPoint> &get_keypoints() const { return m_keypoints; }
+    const Mat8u &get_descriptors() const { return m_descriptors; }
+    std::vector<ImagePoint> get_image_points() const  // :179-190
+    {
+        std::vector<ImagePoint> r;
+        r.reserve(m_keypoints.size());
+        for (const auto &kp : m_keypoints)
+            r.emplace_back(kp.pt.x, kp.pt.y);
+        return r;
+    }
+
+private:
+    std::vector<KeyPoint> m_keypoints;
+    Mat8u m_descriptors;
+    int m_image_width, m_image_height;
+};
+
+// ---- vision/fundamental-matrix.hpp:16-19 ----------------------------------------------------------
+inline bool find_fundamental_matrix(const std::vector<Vector3Type> &p1_sample, const std::vector<Vector3Type> &p2_sample,
+                                    Matrix3Type &F21)
+{
+    assert(p1_sample.size() == 8 && p2_sample.size() == 8);
+    double a[16], b[16];
+    for (int i = 0; i < 8; ++i) {
+        a[2 * i] = p1_sample[i][0]; a[2 * i + 1] = p1_sample[i][1];
+        b[2 * i] = p2_sample[i][0]; b[2 * i + 1] = p2_sample[i][1];
+    }
+    const mvs_status st = mvs_find_fundamental_matrix(hip::context(), a, b, F21.data());
+    hip::check(st, "find_fundamental_matrix");
+    return st == MVS_OK;
+}
+
+// ---- vision/estimator-RANSAC.hpp:10-50 -----------------------------------------------------------
+class FundamentalMatrixEstimatorRANSAC
+{
+public:
+    FundamentalMatrixEstimatorRANSAC(ScalarType max_error_sq_, size_t max_iteration_)
+        : max_error_sq(max_error_sq_), max_iteration(max_iteration_)
+    {
+        assert(max_error_sq > epsilon);
+        assert(max_iteration > 0);
+    }
+    bool compute(const std::vector<Vector3Type> &p1, const std::vector<Vector3Type> &p2, Matrix3Type &F21,
+                 std::vector<uint8_t> &inlier_mask)
+    {
+        assert(p1.size() == p2.size());
+        const size_t n = p1.size();
+        std::vector<double> a(2 * n), b(2 * n);
+        for (size_t i = 0; i < n; ++i) {
+            a[2 * i] = p1[i][0]; a[2 * i + 1] = p1[i][1];
+            b[2 * i] = p2[i][0]; b[2 * i + 1] = p2[i][1];
+        }
+        std::vector<uint8_t> mask(n ? n : 1);
+        const auto &cfg = hip::ransac_config();
+        const mvs_status st = mvs_ransac_fundamental(hip::context(), a.data(), b.data(), (int)n, max_error_sq,
+                                                     (int)max_iteration, cfg.sampler, cfg.seed, F21.data(), mask.data(),
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr);
+        hip::check(st, "FundamentalMatrixEstimatorRANSAC::compute");
+        mask.resize(n);
+        if (n >= 8)
+            inlier_mask.swap(mask);
+        return st == MVS_OK;
+    }
+
+private:
+    const ScalarType max_error_sq;
+    const size_t max_iteration;
+};
+
+// ---- vision/sfm.hpp:30-53 -------------------------------------------------------------------------
+inline mvs_params make_params_()
+{
+    mvs_params p;
+    mvs_params_default(&p);
+    const auto &cfg = hip::ransac_config();
+    p.num_hypotheses = cfg.num_hypotheses;
+    p.sampler = cfg.sampler;
+    p.seed = cfg.seed;
+    p.max_error_sq = cfg.max_error_sq;
+    return p;
+}
+inline SE3 se3_from_arrays_(const double R[9], const double t[3])
+{
+    Matrix3Type Rm;
+    std::memcpy(Rm.data(), R, sizeof(double) * 9);
+    // the library already returns SE3(SO3(R1to2), t1to2).inverse() (sfm-solve.cpp:364), rectified as the reference does
+    return SE3(SO3(Rm, SO3::already_rectified_t()), Vector3Type(t[0], t[1], t[2]));
+}
+
+inline bool sfm_solve(const std::vector<ImagePoint> &p1, const std::vector<ImagePoint> &p2, const CameraIntrinsics &K,
+                      Transformation &pose2in1_scaled, std::vector<Point3> &pointsin1_scaled,
+                      std::vector<size_t> &point_indexes)
+{
+    assert(p1.size() == p2.size());
+    const int m = (int)p1.size();
+    static_assert(sizeof(ImagePoint) == 2 * sizeof(double), "ImagePoint is two packed doubles");
+    std::vector<double> pts(3 * (size_t)(m ? m : 1));
+    std::vector<int64_t> idx(m ? m : 1);
+    double R[9], t[3];
+    int n = 0;
+    const mvs_params prm = make_params_();
+    const mvs_status st = mvs_two_view(hip::context(), m ? &p1[0].x : nullptr, m ? &p2[0].x : nullptr, m, K.data(), &prm,
+                                       R, t, pts.data(), idx.data(), &n, nullptr, nullptr);
+    hip::check(st, "sfm_solve");
+    if (st != MVS_OK)
+        return false;
+    pose2in1_scaled = se3_from_arrays_(R, t);
+    std::vector<Point3> P(n);
+    std::vector<size_t> I(n);
+    for (int i = 0; i < n; ++i) {
+        P[i] = Point3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        I[i] = (size_t)idx[i];
+    }
+    pointsin1_scaled.swap(P);
+    point_indexes.swap(I);
+    return true;
+}
+
+inline void sfm_triangulate(const std::vector<ImagePoint> &p1, const std::vector<ImagePoint> &p2, const CameraIntrinsics &K,
+                            const Transformation &pose1, const Transformation &pose2, std::vector<Point3> &points,
+                            std::vector<size_t> &point_indexes)
+{
+    assert(p1.size() == p2.size() && !p1.empty());
+    const Transformation T_1_to_2 = pose2.inverse() * pose1;  // sfm-solve.cpp:381
+    const int m = (int)p1.size();
+    std::vector<double> pts(3 * (size_t)m);
+    std::vector<int64_t> idx(m);
+    int n = 0;
+    const Vector3Type &t = T_1_to_2.translation();
+    hip::check(mvs_triangulate(hip::context(), &p1[0].x, &p2[0].x, m, K.data(), T_1_to_2.rotation().get_matrix().data(),
+                               t.v, pts.data(), idx.data(), &n),
+               "sfm_triangulate");
+    std::vector<Point3> P(n);
+    std::vector<size_t> I(n);
+    for (int i = 0; i < n; ++i) {
+        P[i] = Point3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        I[i] = (size_t)idx[i];
+    }
+    points.swap(P);
+    point_indexes.swap(I);
+}
+
+// ---- front-end/image-pair.{hpp,cpp} (ctor + reconstruct; refine() is GTSAM, out of scope) ---------
+struct Frame
+{
+    uint32_t id;
+    VisualFeature visual_feature;
+};
+class ImagePair
+{
+public:
+    struct MatchedPoint
+    {
+        Point3 position;
+        size_t vf_idx_in_base, vf_idx_in_pair;
+    };
+    struct Params
+    {
+        ScalarType max_match_inlier_distance;   // image-pair.cpp:22-23
+        bool refine_structure_in_constructor;   // image-pair.cpp:25-26 (refinement is GTSAM: not part of this path)
+    };
+    static Params get_default_params() { return Params{10, false}; }  // image-pair.cpp:17-28
+    ImagePair(const Frame &base_frame_, const Frame &pair_frame_, const CameraIntrinsics &K,
+              const Params &params = get_default_params())
+        : valid(false), match_inlier_count(0), match_inlier_ssd(0)
+    {
+        assert(base_frame_.id != pair_frame_.id);
+        const auto matches = VisualFeature::match_visual_features(base_frame_.visual_feature, pair_frame_.visual_feature,
+                                                                  params.max_match_inlier_distance);
+        const auto bp = base_frame_.visual_feature.get_image_points(), pp = pair_frame_.visual_feature.get_image_points();
+        std::vector<ImagePoint> base_points, pair_points;
+        for (const auto &m : matches) {  // image-pair.cpp:123-140
+            base_points.push_back(bp[m.trainIdx]);
+            pair_points.push_back(pp[m.queryIdx]);
+        }
+        std::vector<Point3> points;
+        std::vector<size_t> idx;
+        valid = matches.size() >= 1 && sfm_solve(base_points, pair_points, K, T_pair_to_base, points, idx);
+        if (valid) {
+            match_inlier_count = (uint32_t)idx.size();
+            for (size_t k = 0; k < idx.size(); ++k) {  // points[k] belongs to match idx[k] (the reference indexes
+                const auto &m = matches[idx[k]];        // points[idx], image-pair.cpp:164 -- SURVEY Q12, not copied)
+                matched_points.push_back(MatchedPoint{points[k], (size_t)m.trainIdx, (size_t)m.queryIdx});
+                match_inlier_ssd += (uint32_t)sqr(m.distance);
+            }
+        }
+    }
+    bool valid;
+    uint32_t match_inlier_count;
+    uint32_t match_inlier_ssd;
+    Transformation T_pair_to_base;
+    std::vector<MatchedPoint> matched_points;
+};
+
+}  // namespace mvSLAM

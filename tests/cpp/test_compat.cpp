@@ -1,0 +1,204 @@
+// C++ tests of the drop-in call surface (mvslam_amd/compat/mvslam_compat.hpp), written the way the reference's own
+// tests read (test/test-sfm.cpp, test/test-lie-group.cpp, test/unit-test-helper.cpp) -- same rigs, same tolerances.
+// Build + run: tests/test_compat_cpp.py (needs a GPU to run; compiles anywhere).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../mvslam_amd/compat/mvslam_compat.hpp"
+
+static int g_fail = 0;
+#define ASSERT_TRUE(c) do { if (!(c)) { std::printf("  FAILED %s:%d  %s\n", __FILE__, __LINE__, #c); ++g_fail; return; } } while (0)
+#define ASSERT_EQUAL(a, b, tol) ASSERT_TRUE(std::fabs((a) - (b)) <= (tol))
+#define RUN(t) do { int before = g_fail; std::printf("[ RUN  ] %s\n", #t); t(); std::printf(g_fail == before ? "[  OK  ] %s\n" : "[ FAIL ] %s\n", #t); } while (0)
+
+using namespace mvSLAM;
+
+enum class RIG_TYPE { CUBE, L_SHAPE };
+static std::vector<Vector3Type> get_rig_points(RIG_TYPE type, const SO3 &rotation, const Vector3Type &translation, ScalarType scale)
+{   // test/unit-test-helper.cpp:42-79
+    std::vector<Vector3Type> p;
+    if (type == RIG_TYPE::CUBE) {
+        for (int x = -1; x <= 1; x += 2) for (int y = -1; y <= 1; y += 2) for (int z = -1; z <= 1; z += 2) p.emplace_back(x, y, z);
+    } else {
+        p = {{1, 0, 0}, {0, 0, 0}, {0, 2, 0}, {1, 0, 3}, {0, 0, 3}, {0, 2, 3}, {0.5, 0.0, 1.5}, {0.0, 1.0, 1.5}};
+    }
+    for (auto &q : p)
+        q = rotation * Vector3Type(scale * q[0], scale * q[1], scale * q[2]) + translation;
+    return p;
+}
+
+struct Rig
+{
+    CameraIntrinsics K = Matrix3Type::Identity();
+    CameraExtrinsics P1, P2;
+    std::vector<Point3> X;
+    std::vector<ImagePoint> ip1, ip2;
+};
+static Rig make_rig(RIG_TYPE type, const SO3 &rot, ScalarType scale)
+{   // test/test-sfm.cpp:19-42
+    Rig r;
+    Vector6Type se3_2to1{1, 0, 0, 0, 0, 0};
+    r.P2 = SE3::exp(se3_2to1).inverse();
+    r.X = get_rig_points(type, rot, Vector3Type(0.6, 0.0, 3.0), scale);
+    r.ip1 = PinholeCamera(r.K, r.P1).project_points(r.X);
+    r.ip2 = PinholeCamera(r.K, r.P2).project_points(r.X);
+    return r;
+}
+
+static void sfm_solve_L_shape()
+{   // test-sfm.cpp:17-90 on the non-degenerate rig (the cube is a critical configuration for the 8-point solver)
+    const ScalarType tol = 0.001;
+    Rig r = make_rig(RIG_TYPE::L_SHAPE, SO3(1.5, 0.7, 0.0), 0.5);
+    Transformation pose2in1;
+    std::vector<Point3> points;
+    std::vector<size_t> idx;
+    ASSERT_TRUE(sfm_solve(r.ip1, r.ip2, r.K, pose2in1, points, idx));
+    const Vector6Type expect{1, 0, 0, 0, 0, 0}, got = pose2in1.ln();
+    for (int i = 0; i < 6; ++i) ASSERT_EQUAL(expect[i], got[i], tol);
+    ASSERT_TRUE(points.size() == r.X.size());
+    for (size_t i = 0; i < points.size(); ++i) {
+        ASSERT_TRUE(idx[i] == i);
+        for (int j = 0; j < 3; ++j) ASSERT_EQUAL(r.X[i][j], points[i][j], tol);
+    }
+}
+
+static void sfm_triangulate_cube()
+{   // test-sfm.cpp:92-155
+    const ScalarType tol = 0.001;
+    Rig r = make_rig(RIG_TYPE::CUBE, SO3(0.0, 0.0, 0.0), 1.0);
+    std::vector<Point3> points;
+    std::vector<size_t> idx;
+    sfm_triangulate(r.ip1, r.ip2, r.K, r.P1.inverse(), r.P2.inverse(), points, idx);
+    ASSERT_TRUE(points.size() == r.X.size());
+    for (size_t i = 0; i < points.size(); ++i)
+        for (int j = 0; j < 3; ++j) ASSERT_EQUAL(r.X[i][j], points[i][j], tol);
+}
+
+static void sfm_solve_too_few_points_returns_false()
+{
+    Rig r = make_rig(RIG_TYPE::L_SHAPE, SO3(1.5, 0.7, 0.0), 0.5);
+    r.ip1.resize(7);
+    r.ip2.resize(7);
+    Transformation T;
+    std::vector<Point3> points;
+    std::vector<size_t> idx;
+    ASSERT_TRUE(!sfm_solve(r.ip1, r.ip2, r.K, T, points, idx));
+}
+
+static void lie_group_round_trips()
+{   // test/test-lie-group.cpp:22-132, tolerance 0.01
+    const ScalarType tol = 0.01;
+    SO3 b(0.1, -0.2, 0.3);
+    ASSERT_EQUAL(0.1, b.get_roll(), tol);
+    ASSERT_EQUAL(-0.2, b.get_pitch(), tol);
+    ASSERT_EQUAL(0.3, b.get_yaw(), tol);
+    Matrix3Type I = b.inverse().get_matrix() * b.get_matrix();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) ASSERT_EQUAL(I(i, j), i == j ? 1.0 : 0.0, tol);
+    SE3 T(b, Vector3Type(1.0, 2.0, -3.0));
+    SE3 T2 = SE3::exp(T.ln());
+    for (int i = 0; i < 3; ++i) {
+        ASSERT_EQUAL(T2.translation()[i], T.translation()[i], tol);
+        for (int j = 0; j < 3; ++j) ASSERT_EQUAL(T2.rotation().get_matrix()(i, j), b.get_matrix()(i, j), tol);
+    }
+}
+
+static VisualFeature random_feature(std::mt19937 &g, int n)
+{
+    std::vector<KeyPoint> kp(n);
+    Mat8u d;
+    d.cols = 32;
+    for (int i = 0; i < n; ++i) {
+        kp[i] = KeyPoint{{float(g() % 640), float(g() % 480)}, 31.f, 0.f, 1.f, 0, -1};
+        uint8_t row[32];
+        for (auto &b : row) b = uint8_t(g());
+        d.push_back_row(row);
+    }
+    return VisualFeature(kp, d, 640, 480);
+}
+
+static void match_visual_features_planted()
+{   // no matcher test exists in the reference (test-frame-manager only checks size() > 0): planted matches
+    std::mt19937 g(7);
+    VisualFeature vf1 = random_feature(g, 300);
+    std::vector<KeyPoint> kp2 = vf1.get_keypoints();
+    Mat8u d2 = vf1.get_descriptors();
+    for (int i = 0; i < 300; ++i) d2.data[(size_t)i * 32 + (i % 32)] ^= 1;   // one flipped bit per descriptor
+    std::reverse(kp2.begin(), kp2.end());
+    Mat8u d2r; d2r.cols = 32;
+    for (int i = 299; i >= 0; --i) d2r.push_back_row(d2.row(i));
+    VisualFeature vf2(kp2, d2r, 640, 480);
+    auto m = VisualFeature::match_visual_features(vf1, vf2, 10);
+    ASSERT_TRUE(m.size() == 300);
+    for (size_t i = 0; i < m.size(); ++i) {
+        ASSERT_TRUE(m[i].trainIdx == 299 - m[i].queryIdx && m[i].distance == 1.0f && m[i].imgIdx == 0);
+        ASSERT_TRUE(i == 0 || m[i - 1].queryIdx < m[i].queryIdx);       // ties ordered by queryIdx
+    }
+    auto f = VisualFeature::match_and_filter_visual_features(vf1, vf2, 10);
+    ASSERT_TRUE(f.first.size() == 300 && f.second.size() == 300 && f.second.get_descriptors().rows == 300);
+    ASSERT_TRUE(f.first.get_keypoints()[5].pt.x == f.second.get_keypoints()[5].pt.x);
+}
+
+static void ransac_estimator_and_image_pair()
+{
+    // an L-rig seen by 2 cameras gives only 8 matches; use a random cloud for the estimator + ImagePair path
+    std::mt19937 g(11);
+    std::uniform_real_distribution<double> U(-1, 1);
+    const int n = 200;
+    CameraIntrinsics K = Matrix3Type::Identity();
+    K(0, 0) = K(1, 1) = 525; K(0, 2) = 320; K(1, 2) = 240;
+    SE3 P2 = SE3::exp(Vector6Type{0.3, 0.02, 0.01, 0.01, 0.03, -0.02}).inverse();
+    std::vector<Point3> X;
+    for (int i = 0; i < n; ++i) X.emplace_back(2 * U(g), 1.5 * U(g), 6 + 3 * U(g));
+    auto ip1 = PinholeCamera(K, SE3()).project_points(X), ip2 = PinholeCamera(K, P2).project_points(X);
+    hip::ransac_config().num_hypotheses = 256;
+    hip::ransac_config().sampler = MVS_SAMPLER_PHILOX;
+    hip::ransac_config().seed = 99;
+    hip::ransac_config().max_error_sq = 1e-6;
+    Transformation T;
+    std::vector<Point3> pts;
+    std::vector<size_t> idx;
+    ASSERT_TRUE(sfm_solve(ip1, ip2, K, T, pts, idx));
+    ASSERT_TRUE(pts.size() == (size_t)n);
+    const Vector6Type got = T.ln();
+    const ScalarType base = std::sqrt(0.3 * 0.3 + 0.02 * 0.02 + 0.01 * 0.01);
+    const Vector6Type want = P2.inverse().ln();
+    for (int i = 0; i < 3; ++i) ASSERT_EQUAL(got[i] * base, want[i], 2e-3);   // up to scale
+    for (int i = 3; i < 6; ++i) ASSERT_EQUAL(got[i], want[i], 1e-3);
+    // FundamentalMatrixEstimatorRANSAC on ideal-camera points
+    std::vector<Vector3Type> q1, q2;
+    for (int i = 0; i < n; ++i) {
+        q1.emplace_back((ip1[i].x - 320) / 525, (ip1[i].y - 240) / 525, 1.0);
+        q2.emplace_back((ip2[i].x - 320) / 525, (ip2[i].y - 240) / 525, 1.0);
+    }
+    FundamentalMatrixEstimatorRANSAC est(1e-6, 64);
+    Matrix3Type F;
+    std::vector<uint8_t> mask;
+    ASSERT_TRUE(est.compute(q1, q2, F, mask));
+    size_t inl = 0;
+    for (auto b : mask) inl += b;
+    ASSERT_TRUE(mask.size() == (size_t)n && inl == (size_t)n);
+    for (int i = 0; i < n; i += 17) {
+        const Vector3Type l = F * q1[i];
+        ASSERT_EQUAL((q2[i][0] * l[0] + q2[i][1] * l[1]) + l[2], 0.0, 1e-6);
+    }
+    hip::ransac_config() = hip::RansacConfig();
+}
+
+int main()
+{
+    try {
+        RUN(lie_group_round_trips);
+        RUN(sfm_solve_L_shape);
+        RUN(sfm_triangulate_cube);
+        RUN(sfm_solve_too_few_points_returns_false);
+        RUN(match_visual_features_planted);
+        RUN(ransac_estimator_and_image_pair);
+    } catch (const std::exception &e) {
+        std::printf("EXCEPTION: %s\n", e.what());
+        return 2;
+    }
+    std::printf(g_fail ? "%d FAILED\n" : "ALL PASSED\n", g_fail);
+    return g_fail ? 1 : 0;
+}
