@@ -101,6 +101,39 @@ extern "C" {
 
 int mvs_abi_version(void) { return MVS_ABI_VERSION; }
 
+// diagnostics only (not in the public header): bitwise comparison of the unscaled sqrt / div device sequences with
+// the compiler's IEEE ones on host-supplied operands.  counts[4] = {sqrt mismatches, div mismatches, sqrt checked,
+// div checked}
+int mvs_debug_fastmath_check(mvs_ctx *ctx, const double *x, const double *y, int n, unsigned long long counts[4])
+{
+    if (!ctx || n < 1)
+        return MVS_ERR_INVALID_ARG;
+    double *dx = nullptr, *dy = nullptr;
+    unsigned long long *dc = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc((void **)&dx, (size_t)n * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&dy, (size_t)n * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&dc, 32));
+    HIP_TRY(ctx, hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dy, y, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(dc, 0, 32));
+    launch_fastmath_check(dx, dy, n, dc, ctx->stream);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(counts, dc, 32, hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    (void)hipFree(dc);
+    return MVS_OK;
+}
+
+// diagnostics only (not in the public header): pick a co-compiled ransac_kernel variant for A/B timing
+int mvs_debug_set_ransac_variant(int v)
+{
+    const int old = get_ransac_variant();
+    set_ransac_variant(v);
+    return old;
+}
+
 const char *mvs_status_str(mvs_status s)
 {
     switch (s) {

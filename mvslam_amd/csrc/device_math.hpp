@@ -30,37 +30,116 @@ MVS_DEV double dabs(double a) { return __builtin_fabs(a); }
 // One (i, j) step of the one-sided Jacobi SVD (cv::SVDecomp restated, lapack.cpp
 // JacobiSVDImpl_): orthogonalise rows Ai, Aj of At, mirror the rotation on Vt.
 // ---------------------------------------------------------------------------------
-template <int M, int N, bool HAS_V>
+// (x, y) <- (c*x + s*y, c*y - s*x) with the contract's rounding: x' = fma(c, x, s*y), y' = fma(c, y, -(s*x)).
+// Written as VOP3 fma that overwrites its own multiplicand: hipcc otherwise picks the 2-address v_fmac form,
+// computes both results into temporaries and copies them back at the end of the predicated region
+// (20 v_mov_b64 per rotation; every instruction costs a full issue slot at one wave per SIMD).
+MVS_DEV void rotate_inplace(double &x, double &y, double c, double s)
+{
+    double t0, t1;
+    asm("v_mul_f64 %0, %4, %3\n\t"
+        "v_mul_f64 %1, %4, %2\n\t"
+        "v_fma_f64 %3, %5, %3, -%1\n\t"
+        "v_fma_f64 %2, %5, %2, %0"
+        : "=&v"(t0), "=&v"(t1), "+v"(x), "+v"(y)
+        : "v"(s), "v"(c));
+}
+
+// ---------------------------------------------------------------------------------
+// Unscaled IEEE sqrt / division.  hipcc's correctly rounded f64 sqrt is
+//   [scale x by 2^256 if x < 2^-767]  y = rsq(x); g = x*y; h = y/2; r = fma(-h,g,1/2); g = fma(g,r,g); h = fma(h,r,h);
+//   d = fma(-g,g,x); g = fma(d,h,g); d = fma(-g,g,x); g = fma(d,h,g)  [unscale]  result = (x == 0 || x == inf) ? x : g
+// and its division is the v_div_scale / v_rcp / 2 Newton steps / v_div_fmas / v_div_fixup sequence, where the scale
+// and fixup instructions only act on operands near the ends of the exponent range.  The functions below are the
+// SAME sequences without the scaling steps, so they return bit-identical (correctly rounded) results whenever the
+// guards hold.  The Jacobi loop only RECORDS a violated guard (`bad`); the caller then recomputes the wave's
+// hypotheses with the compiler's full sequences (never taken for Hartley-normalised samples, whose A^T A has
+// O(1) entries and row norms >= ~1e-17), so the hot loop carries no extra control flow.
+// Every instruction costs a full issue slot at one wave per SIMD: this removes ~8 of 18 (sqrt) and 3 of 11 (div).
+// ---------------------------------------------------------------------------------
+MVS_DEV bool sqrt_fast_ok(double x) { return !(x < 0x1p-767); }  // zero / NaN handled below; tiny -> slow path
+MVS_DEV double sqrt_fast(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = dfma(-h, g, 0.5);
+    g = dfma(g, r, g);
+    h = dfma(h, r, h);
+    double d = dfma(-g, g, x);
+    g = dfma(d, h, g);
+    d = dfma(-g, g, x);
+    g = dfma(d, h, g);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g;
+}
+MVS_DEV double div_fast(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = dfma(-d, r, 1.0);
+    r = dfma(r, e, r);
+    e = dfma(-d, r, 1.0);
+    r = dfma(r, e, r);
+    const double q = n * r;
+    const double rem = dfma(-d, q, n);
+    return dfma(rem, r, q);
+}
+
+template <int M, int N, bool HAS_V, bool INPLACE, bool FAST>
 MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], double (&Vj)[N], double &Wi, double &Wj,
-                         bool &changed, unsigned &rot)
+                         bool &changed, unsigned &rot, bool &bad)
 {
     double a = Wi, b = Wj, p = 0.0;
 #pragma unroll
     for (int k = 0; k < M; ++k)
         p = dfma(Ai[k], Aj[k], p);
-    if (!(dabs(p) <= kJacobiEps * dsqrt(a * b))) {
+    const double ab = a * b;
+    double sq_ab;
+    if (FAST) {
+        bad = bad || !sqrt_fast_ok(ab);
+        sq_ab = sqrt_fast(ab);
+    } else {
+        sq_ab = dsqrt(ab);
+    }
+    if (!(dabs(p) <= kJacobiEps * sq_ab)) {
         p *= 2.0;
         const double beta = a - b;
-        const double gamma = dsqrt(dfma(p, p, beta * beta));
+        const double g2 = dfma(p, p, beta * beta);
         // beta < 0: s = sqrt(((gamma-beta)*0.5)/gamma), c = p/(gamma*s*2)
         // else    : c = sqrt((gamma+beta)/(gamma*2)),   s = p/(gamma*c*2)
         const bool neg = beta < 0.0;
-        const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
-        const double den = neg ? gamma : gamma * 2.0;
-        const double x = dsqrt(num / den);
-        const double y = p / (gamma * x * 2.0);
+        double x, y;
+        if (FAST) {
+            // with gamma and |p| in [2^-200, 2^200] every sqrt / div operand below is far from the ends of the
+            // exponent range (num, den in [gamma/2, 2 gamma]; num/den in [1/2, 1]); otherwise flag the lane
+            bad = bad || !((g2 >= 0x1p-400) && (g2 <= 0x1p400) && (dabs(p) >= 0x1p-200));
+            const double gamma = sqrt_fast(g2);
+            const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
+            const double den = neg ? gamma : gamma * 2.0;
+            x = sqrt_fast(div_fast(num, den));
+            y = div_fast(p, gamma * x * 2.0);
+        } else {
+            const double gamma = dsqrt(g2);
+            const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
+            const double den = neg ? gamma : gamma * 2.0;
+            x = dsqrt(num / den);
+            y = p / (gamma * x * 2.0);
+        }
         const double c = neg ? y : x;
         const double s = neg ? x : y;
         a = 0.0;
         b = 0.0;
 #pragma unroll
         for (int k = 0; k < M; ++k) {
-            const double t0 = dfma(c, Ai[k], s * Aj[k]);
-            const double t1 = dfma(c, Aj[k], -(s * Ai[k]));
-            Ai[k] = t0;
-            Aj[k] = t1;
-            a = dfma(t0, t0, a);
-            b = dfma(t1, t1, b);
+            if (INPLACE) {
+                rotate_inplace(Ai[k], Aj[k], c, s);
+            } else {
+                const double t0 = dfma(c, Ai[k], s * Aj[k]);
+                const double t1 = dfma(c, Aj[k], -(s * Ai[k]));
+                Ai[k] = t0;
+                Aj[k] = t1;
+            }
+            a = dfma(Ai[k], Ai[k], a);
+            b = dfma(Aj[k], Aj[k], b);
         }
         Wi = a;
         Wj = b;
@@ -69,10 +148,14 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
         if (HAS_V) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                const double t0 = dfma(c, Vi[k], s * Vj[k]);
-                const double t1 = dfma(c, Vj[k], -(s * Vi[k]));
-                Vi[k] = t0;
-                Vj[k] = t1;
+                if (INPLACE) {
+                    rotate_inplace(Vi[k], Vj[k], c, s);
+                } else {
+                    const double t0 = dfma(c, Vi[k], s * Vj[k]);
+                    const double t1 = dfma(c, Vj[k], -(s * Vi[k]));
+                    Vi[k] = t0;
+                    Vj[k] = t1;
+                }
             }
         }
     }
@@ -80,8 +163,9 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
 
 // Sweeps until a sweep without rotation (at most max(M, 30)); W ends as singular values.
 // At: N rows of length M.  Vt: N x N, initialised to identity here.
-template <int M, int N>
-MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N], unsigned &rot, unsigned &pairs)
+template <int M, int N, bool INPLACE = false, bool FAST = false>
+MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N], unsigned &rot, unsigned &pairs,
+                             bool &bad)
 {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -101,7 +185,7 @@ MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)
         for (int i = 0; i < N - 1; ++i) {
 #pragma unroll
             for (int j = i + 1; j < N; ++j)
-                jacobi_pair<M, N, true>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot);
+                jacobi_pair<M, N, true, INPLACE, FAST>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot, bad);
         }
         pairs += N * (N - 1) / 2;
         if (!changed)
@@ -165,11 +249,12 @@ MVS_DEV void select_row(const double (&Mx)[N][N], int row, double (&out)[N])
 }
 
 // Null vector of a symmetric 9x9 matrix B (= A^T A): last row of vt of cv::SVDecomp(B).
-MVS_DEV void svd9_last_vt_row(double (&At)[9][9], double (&f)[9], unsigned &rot, unsigned &pairs)
+template <bool INPLACE, bool FAST>
+MVS_DEV void svd9_last_vt_row(double (&At)[9][9], double (&f)[9], unsigned &rot, unsigned &pairs, bool &bad)
 {
     double Vt[9][9], W[9];
     int tag[9];
-    jacobi_svd_core<9, 9>(At, Vt, W, rot, pairs);
+    jacobi_svd_core<9, 9, INPLACE, FAST>(At, Vt, W, rot, pairs, bad);
     sort_tags_desc<9>(W, tag);
     select_row<9>(Vt, tag[8], f);
 }
@@ -179,7 +264,8 @@ MVS_DEV void svd4_last_vt_row(double (&At)[4][4], double (&x)[4], unsigned &rot,
 {
     double Vt[4][4], W[4];
     int tag[4];
-    jacobi_svd_core<4, 4>(At, Vt, W, rot, pairs);
+    bool bad = false;
+    jacobi_svd_core<4, 4>(At, Vt, W, rot, pairs, bad);
     sort_tags_desc<4>(W, tag);
     select_row<4>(Vt, tag[3], x);
 }
@@ -202,7 +288,8 @@ MVS_DEV void svd3_full(const double (&A)[3][3], double (&w)[3], double (&U)[3][3
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             At[i][k] = A[k][i];
-    jacobi_svd_core<3, 3>(At, Vt, W, rot, pairs);
+    bool bad3 = false;
+    jacobi_svd_core<3, 3>(At, Vt, W, rot, pairs, bad3);
     // selection sort with physical row swaps (N = 3: cheap)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -384,8 +471,10 @@ MVS_DEV bool normalise8(const double (&px)[8], const double (&py)[8], double (&n
     return ok;
 }
 
+// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences behind a wave-uniform range guard
+template <int VAR>
 MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
-                         double (&F)[9], unsigned &rot9, unsigned &pairs9)
+                         double (&F)[9], unsigned &rot9, unsigned &pairs9, bool &bad)
 {
     double f[9];
     double s1, s2, m1x, m1y, m2x, m2y;
@@ -416,7 +505,7 @@ MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const dou
                 At[j][i] = acc;
             }
         }
-        svd9_last_vt_row(At, f, rot9, pairs9);
+        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0>(At, f, rot9, pairs9, bad);
     }
     // rank-2 enforcement (:127-136): F = u diag(w0, w1, 0) vt
     double Fn[3][3];

@@ -223,7 +223,26 @@ __device__ __forceinline__ double pair_max_error_sq(const BatchDev &b, const Run
     return 5e-2 / K[0] / K[4];  // sfm-solve.cpp:311
 }
 
-template <bool STATS>
+// VAR (co-compiled A/B variants): 8 = point stream staged in LDS (broadcast ds_read_b128: in order, so the compiler
+// keeps many in flight; scalar loads return out of order and drain at every batch), 16 = in-place rotation,
+// 32 = unscaled sqrt/div behind a range guard, 64 = mask-multiply residual accumulation
+// sample 8 matches, gather them, fit F (one hypothesis, one lane)
+template <int VAR>
+__device__ __forceinline__ bool solve_hypothesis(uint64_t seed, uint32_t hyp, int M, int sampler, const double *P,
+                                                 double (&F)[9], unsigned &rot, unsigned &pairs, bool &bad)
+{
+    int idx[8];
+    sample8(seed, hyp, M, sampler, idx);
+    double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
+        x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
+    }
+    return eight_point<VAR>(x1, y1, x2, y2, F, rot, pairs, bad);
+}
+
+template <bool STATS, int VAR>
 __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp)
 {
     const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
@@ -244,32 +263,64 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
     const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
     const double *P = b.pts + (size_t)pair * b.max_kp * 4;
 
+    // rows 1..8 of every lane's Vt (72 doubles x 256 lanes = 144 KB: one workgroup per CU, one wave per SIMD)
+    constexpr int kLdsDoubles = (VAR & 8) ? kMaxKp * 4 : 2;
+    __shared__ __attribute__((aligned(16))) double s_vt[kLdsDoubles];
     double F[9];
     unsigned rot = 0, pairs = 0;
-    bool ok;
-    {
-        int idx[8];
-        sample8(seed, hh, M, rp.sampler, idx);
-        double x1[8], y1[8], x2[8], y2[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
-            x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
-        }
-        ok = eight_point(x1, y1, x2, y2, F, rot, pairs);
+    bool bad = false;
+    bool ok = solve_hypothesis<VAR>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+    if ((VAR & 32) && __builtin_expect(__any(bad), 0)) {
+        // an operand left the range in which the unscaled sqrt / div sequences are provably IEEE-exact:
+        // recompute this wave's hypotheses with the compiler's fully scaled sequences
+        rot = 0;
+        pairs = 0;
+        ok = solve_hypothesis<(VAR & ~32)>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
     }
 
-    // score against all M matches; the point stream is wave-uniform (scalar loads), F is per lane.
+    // score against all M matches.  Every lane reads the SAME point: the address is wave-uniform, but it is made
+    // opaque to the compiler so that it emits VECTOR loads (one cache line per wave-instruction, served by L1/L2).
+    // Scalar loads return out of order, so every batch would need s_waitcnt lgkmcnt(0) and the loop would stall on
+    // the full SMEM latency each iteration (20 % of the kernel in the first profile); vector loads retire in order
+    // and the compiler pipelines them with counted vmcnt.
     const double thr = pair_max_error_sq(b, rp, pair);
     int cnt = 0;
     double res = 0.0;
-#pragma unroll 4
-    for (int i = 0; i < M; ++i) {
-        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)i * 4);
-        const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
-        const bool in = r < thr;  // strict (estimator-RANSAC.cpp:117)
-        cnt += in ? 1 : 0;
-        res += in ? r : 0.0;  // adding +0.0 is exact: identical to the conditional add
+    if (VAR & 8) {
+        // stage the pair's M point pairs (32 B each) in LDS once per workgroup; every lane then reads the SAME
+        // address (LDS broadcast).  LDS returns in order, so the compiler keeps many reads in flight (counted
+        // lgkmcnt) instead of draining the scalar-load queue every batch.
+        const double2 *src = reinterpret_cast<const double2 *>(P);
+        double2 *dst = reinterpret_cast<double2 *>(s_vt);
+        for (int i = tid; i < 2 * M; i += kHypPerBlock)
+            dst[i] = src[i];
+        __syncthreads();
+        const double4 *L4 = reinterpret_cast<const double4 *>(s_vt);
+#pragma unroll 8
+        for (int i = 0; i < M; ++i) {
+            const double4 p = L4[i];
+            const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+            const bool in = r < thr;
+            cnt += in ? 1 : 0;
+            if (VAR & 64) {
+                // res += in ? r : 0 as ONE select + ONE fma: the mask is 1.0 or 0.0 (only the high dword differs),
+                // fma(r, 1, res) == res + r and fma(r, 0, res) == res exactly for finite r (F is finite here)
+                const double m = __hiloint2double(in ? 0x3ff00000 : 0, 0);
+                res = dfma(r, m, res);
+            } else {
+                res += in ? r : 0.0;
+            }
+        }
+    } else {
+        const double4 *P4 = reinterpret_cast<const double4 *>(P);
+#pragma unroll 8
+        for (int i = 0; i < M; ++i) {
+            const double4 p = P4[i];
+            const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+            const bool in = r < thr;  // strict (estimator-RANSAC.cpp:117)
+            cnt += in ? 1 : 0;
+            res += in ? r : 0.0;  // adding +0.0 is exact: identical to the conditional add
+        }
     }
     if (!ok || !live) {
         cnt = -1;
@@ -327,6 +378,30 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
     }
 }
 
+// diagnostics: compare the unscaled sqrt / div sequences with the compiler's IEEE ones on caller-supplied operands.
+// out[0] = sqrt mismatches among operands that pass sqrt_fast_ok, out[1] = div mismatches among operand pairs
+// inside the guarded range, out[2] / out[3] = number of operands / pairs that were inside the guards.
+__global__ __launch_bounds__(256) void fastmath_check_kernel(const double *x, const double *y, int n, unsigned long long *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const double a = x[i], b = y[i];
+    if (sqrt_fast_ok(a)) {
+        const double f = sqrt_fast(a), g = dsqrt(a);
+        atomicAdd(&out[2], 1ull);
+        if (__double_as_longlong(f) != __double_as_longlong(g) && !(f != f && g != g))
+            atomicAdd(&out[0], 1ull);
+    }
+    const double aa = dabs(a), ab = dabs(b);
+    if (ab >= 0x1p-200 && ab <= 0x1p200 && ((aa >= 0x1p-200 && aa <= 0x1p200) || a == 0.0)) {
+        const double f = div_fast(a, b), g = a / b;
+        atomicAdd(&out[3], 1ull);
+        if (__double_as_longlong(f) != __double_as_longlong(g))
+            atomicAdd(&out[1], 1ull);
+    }
+}
+
 // find_fundamental_matrix on one explicit sample (single lane); diagnostics / API parity only.
 __global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, const double *p2, double *Fout, int *okout)
 {
@@ -339,7 +414,10 @@ __global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, co
         x2[k] = p2[2 * k]; y2[k] = p2[2 * k + 1];
     }
     unsigned rot = 0, pairs = 0;
-    const bool ok = eight_point(x1, y1, x2, y2, F, rot, pairs);
+    bool bad = false;
+    bool ok = eight_point<48>(x1, y1, x2, y2, F, rot, pairs, bad);
+    if (bad)
+        ok = eight_point<16>(x1, y1, x2, y2, F, rot, pairs, bad);
 #pragma unroll
     for (int k = 0; k < 9; ++k)
         Fout[k] = F[k];
@@ -741,19 +819,40 @@ void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2,
     hipLaunchKernelGGL(prep_points_kernel, dim3((b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b, uv1, uv2);
 }
 
+static int g_ransac_variant = 120;
+void set_ransac_variant(int v) { g_ransac_variant = v; }
+int get_ransac_variant() { return g_ransac_variant; }
+
+template <int VAR>
+static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid, dim3 block, bool stats, hipStream_t stream)
+{
+    if (stats)
+        hipLaunchKernelGGL((ransac_kernel<true, VAR>), grid, block, 0, stream, b, rp);
+    else
+        hipLaunchKernelGGL((ransac_kernel<false, VAR>), grid, block, 0, stream, b, rp);
+}
+
 void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream)
 {
     const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
     const dim3 grid(G, n_active), block(kHypPerBlock);
-    if (stats)
-        hipLaunchKernelGGL(ransac_kernel<true>, grid, block, 0, stream, b, rp);
-    else
-        hipLaunchKernelGGL(ransac_kernel<false>, grid, block, 0, stream, b, rp);
+    switch (g_ransac_variant) {
+    case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
+    case 24: launch_ransac_var<24>(b, rp, grid, block, stats, stream); break;
+    case 88: launch_ransac_var<88>(b, rp, grid, block, stats, stream); break;
+    case 8: launch_ransac_var<8>(b, rp, grid, block, stats, stream); break;
+    default: launch_ransac_var<120>(b, rp, grid, block, stats, stream); break;
+    }
 }
 
 void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream)
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b, rp, mode);
+}
+
+void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fastmath_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, out);
 }
 
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream)

@@ -83,6 +83,9 @@ void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, 
 void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2, int n_active, hipStream_t stream);
 void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream);
 void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
+void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)
+int get_ransac_variant();
+void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream);
 
 }  // namespace mvs

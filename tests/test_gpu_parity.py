@@ -65,6 +65,34 @@ def test_match_preconditions(ctx):
     assert o.match_visual_features(_rand_desc(rng, 1), _rand_desc(rng, 4)) is None
 
 
+# ----------------------------------------------------------------------------- device arithmetic
+def test_unscaled_sqrt_div_are_ieee_exact(ctx):
+    """The Jacobi loop uses hipcc's correctly rounded sqrt / div sequences WITHOUT their range-scaling steps (behind a
+    range guard + recompute fallback).  Inside the guards they must be bit-identical to IEEE: checked here on 4M
+    operands spread over the whole guarded exponent range, plus zeros, infinities and guard-boundary values."""
+    import ctypes as C
+
+    rng = np.random.default_rng(99)
+    n = 1 << 22
+    mant = rng.uniform(1.0, 2.0, size=(2, n))
+    expo = rng.integers(-760, 900, size=n)
+    x = np.ldexp(mant[0], expo)                                   # sqrt operands: 2^-760 .. 2^900
+    y = np.ldexp(mant[1], rng.integers(-200, 200, size=n)) * rng.choice([-1.0, 1.0], size=n)
+    xd = np.ldexp(mant[0], rng.integers(-200, 200, size=n)) * rng.choice([-1.0, 1.0], size=n)
+    sel = rng.random(n) < 0.5
+    x = np.where(sel, x, np.abs(xd))                              # half the operands exercise the division guard
+    special = np.array([0.0, np.inf, 2.0 ** -767, 2.0 ** -766, 1.0, 4.0, 2.0 ** 200, 2.0 ** -200, 3.0, 1e-300])
+    x[:len(special)] = special
+    y[:len(special)] = [1.0, 3.0, 7.0, -2.0 ** -200, 2.0 ** 200, 3.0, 2.0 ** 200, 2.0 ** -200, -3.0, 5.0]
+    counts = (C.c_ulonglong * 4)()
+    st = capi.lib().mvs_debug_fastmath_check(ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)),
+                                             y.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(n), counts)
+    assert st == 0
+    assert counts[2] > n // 2 and counts[3] > n // 3       # the guards admitted most of the operands
+    assert counts[0] == 0, "sqrt_fast differs from IEEE sqrt on %d operands" % counts[0]
+    assert counts[1] == 0, "div_fast differs from IEEE division on %d operand pairs" % counts[1]
+
+
 # ----------------------------------------------------------------------------- 8-point
 def test_find_fundamental_bitwise(ctx):
     """The whole solve chain (normalise, A^T A, 9x9 + 3x3 Jacobi SVD, sqrt / div / fma) bit for bit."""
