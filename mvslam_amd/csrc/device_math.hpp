@@ -471,7 +471,7 @@ MVS_DEV bool normalise8(const double (&px)[8], const double (&py)[8], double (&n
     return ok;
 }
 
-// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences behind a wave-uniform range guard
+// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences (flag + recompute)
 template <int VAR>
 MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
                          double (&F)[9], unsigned &rot9, unsigned &pairs9, bool &bad)

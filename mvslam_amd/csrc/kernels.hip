@@ -266,6 +266,15 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
     // rows 1..8 of every lane's Vt (72 doubles x 256 lanes = 144 KB: one workgroup per CU, one wave per SIMD)
     constexpr int kLdsDoubles = (VAR & 8) ? kMaxKp * 4 : 2;
     __shared__ __attribute__((aligned(16))) double s_vt[kLdsDoubles];
+    if (VAR & 8) {
+        // stage the pair's M point pairs (32 B each) in LDS once per workgroup, BEFORE the solve: all four waves
+        // arrive here together, so the barrier is free (after the solve it would add the waves' run-time skew)
+        const double2 *src = reinterpret_cast<const double2 *>(P);
+        double2 *dst = reinterpret_cast<double2 *>(s_vt);
+        for (int i = tid; i < 2 * M; i += kHypPerBlock)
+            dst[i] = src[i];
+        __syncthreads();
+    }
     double F[9];
     unsigned rot = 0, pairs = 0;
     bool bad = false;
@@ -287,14 +296,8 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
     int cnt = 0;
     double res = 0.0;
     if (VAR & 8) {
-        // stage the pair's M point pairs (32 B each) in LDS once per workgroup; every lane then reads the SAME
-        // address (LDS broadcast).  LDS returns in order, so the compiler keeps many reads in flight (counted
-        // lgkmcnt) instead of draining the scalar-load queue every batch.
-        const double2 *src = reinterpret_cast<const double2 *>(P);
-        double2 *dst = reinterpret_cast<double2 *>(s_vt);
-        for (int i = tid; i < 2 * M; i += kHypPerBlock)
-            dst[i] = src[i];
-        __syncthreads();
+        // every lane reads the SAME LDS address (broadcast).  LDS returns in order, so the compiler keeps many
+        // reads in flight (counted lgkmcnt) instead of draining the scalar-load queue every batch.
         const double4 *L4 = reinterpret_cast<const double4 *>(s_vt);
 #pragma unroll 8
         for (int i = 0; i < M; ++i) {
@@ -838,9 +841,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     const dim3 grid(G, n_active), block(kHypPerBlock);
     switch (g_ransac_variant) {
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
-    case 24: launch_ransac_var<24>(b, rp, grid, block, stats, stream); break;
     case 88: launch_ransac_var<88>(b, rp, grid, block, stats, stream); break;
-    case 8: launch_ransac_var<8>(b, rp, grid, block, stats, stream); break;
     default: launch_ransac_var<120>(b, rp, grid, block, stats, stream); break;
     }
 }

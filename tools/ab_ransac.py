@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvslam_amd import capi, synth  # noqa: E402
 
-NAMES = {0: "baseline", 8: "ldspts", 24: "ldspts+inplace", 88: "ldspts+inplace+maskfma", 120: "88+fastmath"}
+NAMES = {0: "round-1 first version", 88: "ldspts+inplace+maskfma", 120: "88+unscaled sqrt/div (default)"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=128)
