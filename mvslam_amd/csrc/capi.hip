@@ -263,6 +263,9 @@ mvs_status mvs_batch_create(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_byte
     ALLOC(d.matches, P * N);
     ALLOC(d.pts, P * N * 4);
     ALLOC(d.cand_pts, P * 4 * N * 3);
+    ALLOC(d.fin, P);
+    ALLOC(d.inl, P * N);
+    ALLOC(d.okf, P * 4 * N);
     ALLOC(d.results, P);
     ALLOC(d.mask, P * N);
     ALLOC(d.points, P * N * 3);

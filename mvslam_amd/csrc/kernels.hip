@@ -23,9 +23,11 @@
 namespace mvs {
 
 // ---------------------------------------------------------------------------------------------
-// match_topk: grid (ceil(N/64), P), block 256 = 4 waves.  Lane = one query descriptor (registers),
-// wave w scans train rows of quarter w (wave-uniform addresses -> scalar loads), partial top-2
-// lists are merged through LDS with the (distance, train index) order of a sequential scan.
+// match_topk: grid (ceil(N/64), P), block 1024 = 16 waves.  Lane = one query descriptor (registers).  The train
+// descriptors are staged through LDS in 64 KB tiles with coalesced 16-byte loads; wave w scans sixteenth w of each
+// tile reading every train row with broadcast ds_read_b128 (in order -> pipelined), xor + popcount against the
+// lane's query, running top-2 per lane.  The 16 partial lists are merged through LDS in (distance, train index)
+// order, which reproduces the strict-'<' insertion of a sequential scan (OpenCV brute-force k-NN).
 // ---------------------------------------------------------------------------------------------
 struct Top2 {
     int d0, i0, d1, i1;
@@ -43,15 +45,21 @@ __device__ __forceinline__ Top2 top2_insert(Top2 t, int d, int i, bool use)
     return r;
 }
 
+constexpr int kTopkWaves = 16;
+constexpr int kTopkTileBytes = 65536;
+
 template <int DW>
-__global__ __launch_bounds__(256) void match_topk_kernel(BatchDev b, double ratio, double max_dist)
+__global__ __launch_bounds__(1024) void match_topk_kernel(BatchDev b, double ratio, double max_dist)
 {
+    constexpr int kTileRows = kTopkTileBytes / (DW * 4);
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[kTopkTileBytes / 4];
+    __shared__ int s_d0[kTopkWaves][64], s_i0[kTopkWaves][64], s_d1[kTopkWaves][64], s_i1[kTopkWaves][64];
     const int pair = blockIdx.y;
-    const int n1 = b.n1[pair], n2 = b.n2[pair];
+    const int n1 = min(b.n1[pair], b.max_kp), n2 = min(b.n2[pair], b.max_kp);
     const int q0 = blockIdx.x * 64;
     if (q0 >= n2)
         return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = q0 + lane;
     const bool live = q < n2;
     const size_t base = (size_t)pair * b.max_kp;
@@ -65,37 +73,46 @@ __global__ __launch_bounds__(256) void match_topk_kernel(BatchDev b, double rati
             qv[k] = v.x; qv[k + 1] = v.y; qv[k + 2] = v.z; qv[k + 3] = v.w;
         }
     }
-    const uint32_t *tr = b.desc1 + base * DW;
-    const int chunk = (n1 + 3) >> 2;
-    const int t0 = __builtin_amdgcn_readfirstlane(w * chunk);
-    const int t1 = min(n1, t0 + chunk);
+    const uint4 *tr4 = reinterpret_cast<const uint4 *>(b.desc1 + base * DW);
 
     int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1, i1 = -1;
+    for (int tile0 = 0; tile0 < n1; tile0 += kTileRows) {
+        const int rows = min(kTileRows, n1 - tile0);
+        __syncthreads();  // previous tile fully consumed
+        for (int i = tid; i < rows * (DW / 4); i += 1024)
+            reinterpret_cast<uint4 *>(s_tile)[i] = tr4[(size_t)tile0 * (DW / 4) + i];
+        __syncthreads();
+        const int chunk = (rows + kTopkWaves - 1) / kTopkWaves;
+        const int r0 = __builtin_amdgcn_readfirstlane(w * chunk);
+        const int r1 = min(rows, r0 + chunk);
 #pragma unroll 4
-    for (int t = t0; t < t1; ++t) {
-        const uint32_t *td = tr + (size_t)t * DW;  // wave-uniform
-        int d = 0;
+        for (int r = r0; r < r1; ++r) {
+            const uint4 *td = reinterpret_cast<const uint4 *>(s_tile + r * DW);  // wave-uniform -> LDS broadcast
+            int d = 0;
 #pragma unroll
-        for (int k = 0; k < DW; ++k)
-            d += __popc(qv[k] ^ td[k]);
-        // strict '<' insertion: equal distances keep the smaller train index first
-        if (d < d1) {
-            if (d < d0) {
-                d1 = d0; i1 = i0;
-                d0 = d;  i0 = t;
-            } else {
-                d1 = d; i1 = t;
+            for (int k = 0; k < DW; k += 4) {
+                const uint4 v = td[k / 4];
+                d += __popc(qv[k] ^ v.x) + __popc(qv[k + 1] ^ v.y) + __popc(qv[k + 2] ^ v.z) + __popc(qv[k + 3] ^ v.w);
+            }
+            const int t = tile0 + r;
+            // strict '<' insertion: equal distances keep the smaller train index first
+            if (d < d1) {
+                if (d < d0) {
+                    d1 = d0; i1 = i0;
+                    d0 = d;  i0 = t;
+                } else {
+                    d1 = d; i1 = t;
+                }
             }
         }
     }
 
-    __shared__ int s_d0[4][64], s_i0[4][64], s_d1[4][64], s_i1[4][64];
     s_d0[w][lane] = d0; s_i0[w][lane] = i0; s_d1[w][lane] = d1; s_i1[w][lane] = i1;
     __syncthreads();
     if (w == 0 && live) {
         Top2 t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < kTopkWaves; ++c) {
             const int a0 = s_d0[c][lane], j0 = s_i0[c][lane], a1 = s_d1[c][lane], j1 = s_i1[c][lane];
             t = top2_insert(t, a0, j0, j0 >= 0);
             t = top2_insert(t, a1, j1, j1 >= 0);
@@ -112,9 +129,9 @@ __global__ __launch_bounds__(256) void match_topk_kernel(BatchDev b, double rati
 }
 
 // ---------------------------------------------------------------------------------------------
-// match_compact: grid P, block 1024.  Rank sort on key = (distance << 16 | queryIdx) held in LDS
-// (every thread streams the same keys -> LDS broadcast reads), then gathers both keypoints of
-// match m and applies K^-1.  Output m-th match / m-th point pair in canonical order.
+// match_compact: grid P, block 1024.  Bitonic sort of the keys (distance << 16 | queryIdx) in LDS (unique keys,
+// rejected queries = 0xffffffff sort to the end) = the canonical (distance, queryIdx) order; then match m gathers its
+// two keypoints and applies K^-1.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void match_compact_kernel(BatchDev b)
 {
@@ -126,8 +143,10 @@ __global__ __launch_bounds__(1024) void match_compact_kernel(BatchDev b)
     const int tid = threadIdx.x;
     if (tid == 0)
         s_count = 0;
-    const int n2p = (n2 + 3) & ~3;
-    for (int q = tid; q < n2p; q += 1024) {
+    int S = 2;
+    while (S < n2)
+        S <<= 1;
+    for (int q = tid; q < S; q += 1024) {
         uint32_t key = 0xffffffffu;
         if (q < n2) {
             const int tr = b.knn_train[base + q];
@@ -137,26 +156,37 @@ __global__ __launch_bounds__(1024) void match_compact_kernel(BatchDev b)
         s_key[q] = key;
     }
     __syncthreads();
+    for (int k = 2; k <= S; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (S >> 1); t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const uint32_t x = s_key[i], y = s_key[ixj];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) {
+                    s_key[i] = y;
+                    s_key[ixj] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
     int local = 0;
     const double *Ki = b.Kinv + (size_t)pair * 9;
     const double k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5];
-    for (int q = tid; q < n2; q += 1024) {
-        const uint32_t key = s_key[q];
+    for (int m = tid; m < n2; m += 1024) {
+        const uint32_t key = s_key[m];
         if (key == 0xffffffffu)
             continue;
         ++local;
-        int rank = 0;
-        for (int j = 0; j < n2p; j += 4) {
-            const uint4 kk = *reinterpret_cast<const uint4 *>(&s_key[j]);
-            rank += (kk.x < key) + (kk.y < key) + (kk.z < key) + (kk.w < key);
-        }
+        const int q = (int)(key & 0xffffu);
         const int tr = b.knn_train[base + q];
-        mvs_match m;
-        m.queryIdx = q;
-        m.trainIdx = tr;
-        m.imgIdx = 0;
-        m.distance = (float)(key >> 16);
-        b.matches[base + rank] = m;
+        mvs_match mt;
+        mt.queryIdx = q;
+        mt.trainIdx = tr;
+        mt.imgIdx = 0;
+        mt.distance = (float)(key >> 16);
+        b.matches[base + m] = mt;
         // base_points[m] = kp1[trainIdx], pair_points[m] = kp2[queryIdx], float -> double, K^-1 (u, v, 1)
         const float2 a = *reinterpret_cast<const float2 *>(b.kp1 + (base + tr) * 2);
         const float2 c = *reinterpret_cast<const float2 *>(b.kp2 + (base + q) * 2);
@@ -166,7 +196,7 @@ __global__ __launch_bounds__(1024) void match_compact_kernel(BatchDev b)
         p.y = (k3 * u1 + k4 * v1) + k5;
         p.z = (k0 * u2 + k1 * v2) + k2;
         p.w = (k3 * u2 + k4 * v2) + k5;
-        *reinterpret_cast<double4 *>(b.pts + (base + rank) * 4) = p;
+        *reinterpret_cast<double4 *>(b.pts + (base + m) * 4) = p;
     }
     if (local)
         atomicAdd(&s_count, local);
@@ -428,27 +458,13 @@ __global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// finalize: grid P, block 256.
+// finalize, three launches so that the 4 x M_inl triangulations of ONE pair spread over the chip (a single pair
+// at a time is BASELINE configs[1]; with one workgroup per pair they took 0.19 ms of a 0.5 ms step):
+//   finalize_model   grid P          arg-best, inlier mask + ordered inlier list, E projection, decomposition
+//   triangulate      grid (x, P)     one (candidate, inlier) item per lane: 4x4 DLT + Jacobi SVD + cheirality
+//   finalize_select  grid P          candidate selection, ordered compaction, pose
 // ---------------------------------------------------------------------------------------------
 constexpr int kFinThreads = 256;
-
-struct FinShared {
-    double F[9];
-    double E[9];
-    double R[2][9];   // Ra, Rb (raw)
-    double Rr[2][9];  // rectified (SO3 ctor) -> P2
-    double T[3];
-    int wave_tot[4];
-    int n_inl;
-    int ncand;
-    int cand_cnt[4];
-    int win;
-    int proceed;
-    Cand red[4];
-    uint32_t win_group;
-    uint16_t inl[kMaxKp];
-    uint8_t okf[4][kMaxKp];
-};
 
 // ordered compaction of {i in [0, n) : pred(i)}; emit(i, position); returns the count (block-uniform)
 template <typename Pred, typename Emit>
@@ -479,21 +495,23 @@ __device__ __forceinline__ int block_compact(int n, int *s_tot, Pred pred, Emit 
     return basepos;
 }
 
-__global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunParams rp, int mode)
+__global__ __launch_bounds__(kFinThreads) void finalize_model_kernel(BatchDev b, RunParams rp, int mode)
 {
-    __shared__ FinShared s;
+    __shared__ double s_F[9], s_E[9];
+    __shared__ int s_tot[4];
+    __shared__ int s_proceed;
+    __shared__ Cand s_red[4];
+    __shared__ uint32_t s_grp[4];
     const int pair = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)pair * b.max_kp;
     const int M = min(b.M[pair], b.max_kp);
     mvs_pair_result *res = b.results + pair;
+    FinModel *fm = b.fin + pair;
     const double *P = b.pts + base * 4;
     uint8_t *mask = b.mask + base;
 
-    if (tid == 0) {
-        s.proceed = 0;
-        s.n_inl = 0;
-        s.ncand = 4;
-    }
+    if (tid == 0)
+        s_proceed = 0;
     __syncthreads();
 
     if (mode == kFinalizeFull) {
@@ -523,18 +541,17 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
                 mygroup = og;
             }
         }
-        __shared__ uint32_t s_grp[4];
         if ((tid & 63) == 0) {
-            s.red[tid >> 6] = me;
+            s_red[tid >> 6] = me;
             s_grp[tid >> 6] = mygroup;
         }
         __syncthreads();
         if (tid == 0) {
-            Cand best = s.red[0];
+            Cand best = s_red[0];
             uint32_t bg = s_grp[0];
             for (int w = 1; w < 4; ++w)
-                if (s.red[w].cnt >= 0 && (best.cnt < -1 || cand_better(s.red[w], best))) {
-                    best = s.red[w];
+                if (s_red[w].cnt >= 0 && (best.cnt < -1 || cand_better(s_red[w], best))) {
+                    best = s_red[w];
                     bg = s_grp[w];
                 }
             res->valid = 0;
@@ -548,23 +565,28 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
                 const WgBest *wb = b.wgbest + (size_t)pair * b.max_groups + bg;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    s.F[k] = wb->F[k];
+                    s_F[k] = wb->F[k];
                     res->F[k] = wb->F[k];
                 }
-                s.proceed = 1;
+                s_proceed = 1;
             }
         }
         __syncthreads();
-        if (!s.proceed) {
+        if (!s_proceed) {
             for (int i = tid; i < M; i += kFinThreads)
                 mask[i] = 0;
+            if (tid == 0) {
+                fm->proceed = 0;
+                fm->n_inl = 0;
+                fm->ncand = 0;
+            }
             return;
         }
         // ---- inlier mask of the winner (estimator-RANSAC.cpp:100-129) ----
         double F[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            F[k] = s.F[k];
+            F[k] = s_F[k];
         const double thr = pair_max_error_sq(b, rp, pair);
         for (int i = tid; i < M; i += kFinThreads) {
             const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)i * 4);
@@ -581,21 +603,23 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
     }
 
     // ---- ordered inlier list ----
+    uint16_t *inl = b.inl + base;
     const int n_inl = block_compact(
-        M, s.wave_tot, [&](int i) { return mask[i] != 0; }, [&](int i, int pos) { s.inl[pos] = (uint16_t)i; });
+        M, s_tot, [&](int i) { return mask[i] != 0; }, [&](int i, int pos) { inl[pos] = (uint16_t)i; });
 
     // ---- E projection + decomposition (single lane; sfm-solve.cpp:74-84,97-127) ----
     if (tid == 0) {
         res->n_inliers = n_inl;
         unsigned rot = 0, prs = 0;
         bool go = true;
+        int ncand = 4;
         if (mode == kFinalizeFull) {
             double Fm[3][3], w[3], U[3][3], Vt[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    Fm[i][j] = s.F[i * 3 + j];
+                    Fm[i][j] = s_F[i * 3 + j];
             svd3_full(Fm, w, U, Vt, rot, prs);
             const double v = dsqrt(w[0] * w[1]);
 #pragma unroll
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const double e = a * Vt[0][j] + c * Vt[1][j];
-                    s.E[i * 3 + j] = e;
+                    s_E[i * 3 + j] = e;
                     res->E[i * 3 + j] = e;
                 }
             }
@@ -613,7 +637,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
         } else if (mode == kFinalizeFromE) {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                s.E[k] = res->E[k];
+                s_E[k] = res->E[k];
         }
         if (mode == kFinalizeTriangulate) {
             double R[3][3];
@@ -622,25 +646,25 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     R[i][j] = res->R1to2[i * 3 + j];
-                    s.R[0][i * 3 + j] = R[i][j];
+                    fm->R[0][i * 3 + j] = R[i][j];
                 }
             rectify3(R);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    s.Rr[0][i * 3 + j] = R[i][j];
+                    fm->Rr[0][i * 3 + j] = R[i][j];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                s.T[k] = res->t1to2[k];
-            s.ncand = 1;
+                fm->T[k] = res->t1to2[k];
+            ncand = 1;
         } else if (go) {
             double Em[3][3], w[3], U[3][3], Vt[3][3], V[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    Em[i][j] = s.E[i * 3 + j];
+                    Em[i][j] = s_E[i * 3 + j];
             svd3_full(Em, w, U, Vt, rot, prs);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -668,69 +692,91 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
                 for (int j = 0; j < 3; ++j) {
                     Ra[i][j] = (U[i][1] * V[j][0] + (-U[i][0]) * V[j][1]) + U[i][2] * V[j][2];
                     Rb[i][j] = ((-U[i][1]) * V[j][0] + U[i][0] * V[j][1]) + U[i][2] * V[j][2];
-                    s.R[0][i * 3 + j] = Ra[i][j];
-                    s.R[1][i * 3 + j] = Rb[i][j];
+                    fm->R[0][i * 3 + j] = Ra[i][j];
+                    fm->R[1][i * 3 + j] = Rb[i][j];
                 }
             // S = U Z U^T, t = (-S12, S02, -S01)
-            s.T[0] = -((-U[1][1]) * U[2][0] + U[1][0] * U[2][1]);
-            s.T[1] = ((-U[0][1]) * U[2][0] + U[0][0] * U[2][1]);
-            s.T[2] = -((-U[0][1]) * U[1][0] + U[0][0] * U[1][1]);
+            fm->T[0] = -((-U[1][1]) * U[2][0] + U[1][0] * U[2][1]);
+            fm->T[1] = ((-U[0][1]) * U[2][0] + U[0][0] * U[2][1]);
+            fm->T[2] = -((-U[0][1]) * U[1][0] + U[0][0] * U[1][1]);
             rectify3(Ra);
             rectify3(Rb);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    s.Rr[0][i * 3 + j] = Ra[i][j];
-                    s.Rr[1][i * 3 + j] = Rb[i][j];
+                    fm->Rr[0][i * 3 + j] = Ra[i][j];
+                    fm->Rr[1][i * 3 + j] = Rb[i][j];
                 }
-            s.ncand = 4;
+            ncand = 4;
         }
-        s.proceed = go ? 1 : 0;
-        s.n_inl = n_inl;
-        s.cand_cnt[0] = s.cand_cnt[1] = s.cand_cnt[2] = s.cand_cnt[3] = 0;
+        fm->proceed = (go && n_inl > 0) ? 1 : 0;
+        fm->n_inl = n_inl;
+        fm->ncand = ncand;
     }
-    __syncthreads();
-    if (!s.proceed || n_inl == 0)
-        return;
+}
 
-    // ---- triangulation: item = (candidate c, inlier j); 4x4 DLT + SVD per lane (sfm-solve.cpp:134-227) ----
-    const int ncand = s.ncand;
-    double *cp = b.cand_pts + (size_t)pair * 4 * b.max_kp * 3;
-    const int items = ncand * n_inl;
-    for (int it = tid; it < items; it += kFinThreads) {
-        const int c = it / n_inl, j = it - c * n_inl;
-        const int i = s.inl[j];
-        const double *R = s.R[c >> 1], *Rr = s.Rr[c >> 1];
-        const bool flip = (c & 1) != 0;
-        const double t0 = flip ? -s.T[0] : s.T[0], t1 = flip ? -s.T[1] : s.T[1], t2 = flip ? -s.T[2] : s.T[2];
-        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)i * 4);
-        double At[4][4];  // At[col][row] of A
-        At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
-        At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
-        At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
-        At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
-        double X[4];
-        unsigned rot = 0, prs = 0;
-        svd4_last_vt_row(At, X, rot, prs);
-        bool okp = !(dabs(X[3]) < kTol);
-        const double scale = 1.0 / X[3];
-        const double px = X[0] * scale, py = X[1] * scale, pz = X[2] * scale;
-        okp = okp && !(pz < kTol);
-        const double z2 = ((R[6] * px + R[7] * py) + R[8] * pz) + t2;
-        okp = okp && !(z2 < kTol);
-        s.okf[c][j] = okp ? 1 : 0;
-        double *dst = cp + ((size_t)c * b.max_kp + j) * 3;
-        dst[0] = px; dst[1] = py; dst[2] = pz;
-    }
+// triangulation: grid (ceil(4 * max_kp / 256), P); item = (candidate c, inlier j); 4x4 DLT + SVD per lane
+// (sfm-solve.cpp:134-227)
+__global__ __launch_bounds__(256) void triangulate_kernel(BatchDev b)
+{
+    const int pair = blockIdx.y;
+    const FinModel *fm = b.fin + pair;
+    if (!fm->proceed)
+        return;
+    const int n_inl = fm->n_inl, ncand = fm->ncand;
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= ncand * n_inl)
+        return;
+    const size_t base = (size_t)pair * b.max_kp;
+    const int c = it / n_inl, j = it - c * n_inl;
+    const int i = b.inl[base + j];
+    const double *R = fm->R[c >> 1], *Rr = fm->Rr[c >> 1];
+    const bool flip = (c & 1) != 0;
+    const double t0 = flip ? -fm->T[0] : fm->T[0], t1 = flip ? -fm->T[1] : fm->T[1], t2 = flip ? -fm->T[2] : fm->T[2];
+    const double4 p = *reinterpret_cast<const double4 *>(b.pts + (base + i) * 4);
+    double At[4][4];  // At[col][row] of A
+    At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
+    At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
+    At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
+    At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
+    double X[4];
+    unsigned rot = 0, prs = 0;
+    svd4_last_vt_row(At, X, rot, prs);
+    bool okp = !(dabs(X[3]) < kTol);
+    const double scale = 1.0 / X[3];
+    const double px = X[0] * scale, py = X[1] * scale, pz = X[2] * scale;
+    okp = okp && !(pz < kTol);
+    const double z2 = ((R[6] * px + R[7] * py) + R[8] * pz) + t2;
+    okp = okp && !(z2 < kTol);
+    b.okf[((size_t)pair * 4 + c) * b.max_kp + j] = okp ? 1 : 0;
+    double *dst = b.cand_pts + (((size_t)pair * 4 + c) * b.max_kp + j) * 3;
+    dst[0] = px; dst[1] = py; dst[2] = pz;
+}
+
+__global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b)
+{
+    __shared__ int s_tot[4];
+    __shared__ int s_cnt[4];
+    __shared__ int s_win;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const FinModel *fm = b.fin + pair;
+    if (!fm->proceed)
+        return;
+    const size_t base = (size_t)pair * b.max_kp;
+    mvs_pair_result *res = b.results + pair;
+    const int n_inl = fm->n_inl, ncand = fm->ncand;
+    const uint8_t *okf = b.okf + (size_t)pair * 4 * b.max_kp;
+    if (tid < 4)
+        s_cnt[tid] = 0;
     __syncthreads();
-    // ---- candidate selection: strictly more points wins, order (Ra,t),(Ra,-t),(Rb,t),(Rb,-t) ----
+    // ---- candidate selection: strictly more points wins, order (Ra,t),(Ra,-t),(Rb,t),(Rb,-t) (sfm-solve.cpp:259-281)
     {
         int cnt[4] = {0, 0, 0, 0};
         for (int j = tid; j < n_inl; j += kFinThreads) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                cnt[c] += (c < ncand) ? s.okf[c][j] : 0;
+                cnt[c] += (c < ncand) ? okf[(size_t)c * b.max_kp + j] : 0;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -738,37 +784,39 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
             for (int o = 32; o > 0; o >>= 1)
                 cnt[c] += __shfl_xor(cnt[c], o);
             if ((tid & 63) == 0 && cnt[c])
-                atomicAdd(&s.cand_cnt[c], cnt[c]);
+                atomicAdd(&s_cnt[c], cnt[c]);
         }
     }
     __syncthreads();
     if (tid == 0) {
         int best = 0, win = -1;
         for (int c = 0; c < ncand; ++c)
-            if (s.cand_cnt[c] > best) {
-                best = s.cand_cnt[c];
+            if (s_cnt[c] > best) {
+                best = s_cnt[c];
                 win = c;
             }
-        s.win = win;
+        s_win = win;
     }
     __syncthreads();
-    const int win = s.win;
+    const int win = s_win;
     if (win < 0)
         return;  // recover_pose_and_points returned false
     // ---- compact the winner's points in index order ----
-    const double *src = cp + (size_t)win * b.max_kp * 3;
+    const double *src = b.cand_pts + ((size_t)pair * 4 + win) * b.max_kp * 3;
+    const uint8_t *okw = okf + (size_t)win * b.max_kp;
+    const uint16_t *inl = b.inl + base;
     const int n_pts = block_compact(
-        n_inl, s.wave_tot, [&](int j) { return s.okf[win][j] != 0; },
+        n_inl, s_tot, [&](int j) { return okw[j] != 0; },
         [&](int j, int pos) {
             double *d = b.points + (base + pos) * 3;
             d[0] = src[j * 3]; d[1] = src[j * 3 + 1]; d[2] = src[j * 3 + 2];
-            b.point_idx[base + pos] = s.inl[j];
+            b.point_idx[base + pos] = inl[j];
         });
     // ---- pose2in1 = SE3(SO3(R), t).inverse()  (sfm-solve.cpp:364; lie-group.hpp:212-216) ----
     if (tid == 0) {
-        const double *Rw = s.R[win >> 1];
+        const double *Rw = fm->R[win >> 1];
         const bool flip = (win & 1) != 0;
-        const double t[3] = {flip ? -s.T[0] : s.T[0], flip ? -s.T[1] : s.T[1], flip ? -s.T[2] : s.T[2]};
+        const double t[3] = {flip ? -fm->T[0] : fm->T[0], flip ? -fm->T[1] : fm->T[1], flip ? -fm->T[2] : fm->T[2]};
         double Rr[3][3], RT[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -802,7 +850,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(BatchDev b, RunPa
 // ---------------------------------------------------------------------------------------------
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
 {
-    const dim3 grid((b.max_kp + 63) / 64, n_active), block(256);
+    const dim3 grid((b.max_kp + 63) / 64, n_active), block(1024);
     const double ratio = rp.ratio, md = rp.max_dist;
     switch (b.desc_words) {
     case 4: hipLaunchKernelGGL(match_topk_kernel<4>, grid, block, 0, stream, b, ratio, md); break;
@@ -848,7 +896,9 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
 
 void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b, rp, mode);
+    hipLaunchKernelGGL(finalize_model_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b, rp, mode);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((4 * b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(finalize_select_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b);
 }
 
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream)

@@ -20,6 +20,17 @@ struct WgBest {
 };
 static_assert(sizeof(WgBest) == 88, "WgBest layout");
 
+// What finalize_model hands to triangulate / finalize_select for one pair.
+struct FinModel {
+    double R[2][9];   // Ra, Rb (raw)
+    double Rr[2][9];  // rectified (SO3 ctor) -> P2
+    double T[3];
+    int32_t n_inl;
+    int32_t ncand;
+    int32_t proceed;
+    int32_t pad;
+};
+
 // Resident state of a batch (all device pointers).  P pairs, capacity N keypoints per image.
 struct BatchDev {
     int n_pairs;
@@ -46,6 +57,9 @@ struct BatchDev {
     double *pts;         // [P][N][4]  (x1, y1, x2, y2) ideal-camera coordinates of match m
     WgBest *wgbest;      // [P][max_groups]
     double *cand_pts;    // [P][4][N][3] triangulation scratch
+    FinModel *fin;       // [P]
+    uint16_t *inl;       // [P][N] ordered inlier list
+    uint8_t *okf;        // [P][4][N] cheirality flags per candidate
 
     // outputs
     mvs_pair_result *results;  // [P]
