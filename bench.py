@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--max-error-sq", type=float, default=1e-2,
                     help="algebraic inlier threshold; 0 = the reference formula 5e-2/K00/K11 (no valid model at "
                          "0.5 px noise, see DESIGN.md)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1; 'gloo' (+ MVS_BENCH_ONE_DEVICE=1) rehearses the multi-rank path on "
+                         "a single-GPU box: every rank uses cuda:0 and the pose records are gathered through host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
     args = ap.parse_args()
@@ -115,10 +118,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if os.environ.get("MVS_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n_local = args.pairs
     first = rank * n_local  # contiguous block per rank, weak scaling
@@ -127,7 +134,7 @@ def main():
                      seed=synth.SEED_BASE)
     prm = capi.default_params(sampler=capi.SAMPLER_PHILOX, min_inliers=8, **params_kw)
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev)
     batch = capi.Batch(ctx, n_local, args.kp, 32)
     batch.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
                  data["global_index"])
@@ -139,7 +146,7 @@ def main():
         if world > 1:  # the one exchange step of the path: all-gather of the pose records over RCCL/xGMI
             batch.copy_results_device(rec_local.data_ptr())
             batch.sync()
-            return mdist.gather_records(rec_local, world)
+            return mdist.gather_records(rec_local if args.backend == "nccl" else rec_local.cpu(), world)
         return None
 
     def fence():
@@ -160,7 +167,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
