@@ -138,6 +138,25 @@ mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const doubl
                                   uint8_t *inlier_mask, int *best_hyp, int *best_count, double *best_residual,
                                   int32_t *count, double *residual);
 
+/* pnp_solve(world_points, image_points, K, pose, inlier_point_indexes) (vision/pnp-solve.cpp:16-104, decl pnp.hpp:22-26).
+ * The reference forwards to cv::solvePnPRansac(SOLVEPNP_P3P, 100, 0.05, 0.95); this is the build's own P3P-RANSAC
+ * (Grunert P3P on 3 points + 1 disambiguation point, reprojection-error inlier count over all points, first
+ * hypothesis with the most inliers, no refit).  pose = camera in world, i.e.
+ * SE3(R_world_to_camera, t).inverse() (pnp-solve.cpp:99-101).  n >= 7 (PNP_MIN_POINT_COUNT, :13) and n <= 2048.
+ * inlier_idx: capacity n, ascending.  returns MVS_OK (true) / MVS_NO_MODEL (false). */
+typedef struct mvs_pnp_params {
+    int32_t num_hypotheses; /* reference: iterationsCount = 100 (pnp-solve.cpp:47) */
+    int32_t sampler;        /* MVS_SAMPLER_* (identity = points 0..3) */
+    uint64_t seed;
+    double reproj_error;    /* 0.05 (pnp-solve.cpp:48), pixels of the given image points */
+    int32_t min_inliers;    /* 4: the model points of the RANSAC kernel */
+    int32_t reserved;
+} mvs_pnp_params;
+mvs_status mvs_pnp_params_default(mvs_pnp_params *p);
+mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *image_uv, int n, const double K[9],
+                         const mvs_pnp_params *params, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
+                         int *best_hyp);
+
 /* ---- batched, device-resident pipeline ("one image pair" = ImagePair ctor + reconstruct,
  *      front-end/image-pair.cpp:30-71,116-174, without refine()) ---------------------- */
 

@@ -58,6 +58,11 @@ RESULT_DTYPE = np.dtype([
 assert RESULT_DTYPE.itemsize == C.sizeof(PairResult)
 
 
+class PnpParams(C.Structure):
+    _fields_ = [("num_hypotheses", C.c_int32), ("sampler", C.c_int32), ("seed", C.c_uint64),
+                ("reproj_error", C.c_double), ("min_inliers", C.c_int32), ("reserved", C.c_int32)]
+
+
 class WorkStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers")]
 
@@ -68,7 +73,7 @@ EXPORTS = [
     "mvs_triangulate", "mvs_recover_pose", "mvs_find_fundamental_matrix", "mvs_ransac_fundamental",
     "mvs_batch_create", "mvs_batch_destroy", "mvs_batch_upload", "mvs_batch_run", "mvs_batch_sync",
     "mvs_batch_time", "mvs_batch_download", "mvs_batch_stats", "mvs_batch_results_device",
-    "mvs_batch_copy_results_device",
+    "mvs_batch_copy_results_device", "mvs_pnp_params_default", "mvs_pnp_solve",
 ]
 
 
@@ -107,6 +112,14 @@ def status_str(status):
 def default_params(**kw):
     p = Params()
     lib().mvs_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_pnp_params(**kw):
+    p = PnpParams()
+    lib().mvs_pnp_params_default(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -226,6 +239,19 @@ class Context:
         out = self._unpack(res, None, pts, idx, m)
         out["ok"] = st == MVS_OK
         return out
+
+    # pnp_solve(world_points, image_points, K, pose, inlier_point_indexes)
+    def pnp_solve(self, world_xyz, image_uv, K, params):
+        X, uv = _f64(world_xyz).reshape(-1, 3), _f64(image_uv).reshape(-1, 2)
+        n = len(X)
+        R, t = np.zeros((3, 3)), np.zeros(3)
+        idx = np.zeros(max(n, 1), dtype=np.int64)
+        ni, bh = C.c_int(0), C.c_int(-1)
+        st = lib().mvs_pnp_solve(self._h, _ptr(X, C.c_double), _ptr(uv, C.c_double), C.c_int(n),
+                                 _ptr(_f64(K, (9,)), C.c_double), C.byref(params), _ptr(R, C.c_double),
+                                 _ptr(t, C.c_double), _ptr(idx, C.c_int64), C.byref(ni), C.byref(bh))
+        self._check(st, "mvs_pnp_solve", allow_no_model=True)
+        return dict(ok=st == MVS_OK, R=R, t=t, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
 
     def find_fundamental_matrix(self, p1, p2):
         p1, p2 = _f64(p1, (16,)), _f64(p2, (16,))

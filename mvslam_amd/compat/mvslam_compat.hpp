@@ -540,6 +540,52 @@ inline void sfm_triangulate(const std::vector<ImagePoint> &p1, const std::vector
     point_indexes.swap(I);
 }
 
+// ---- vision/pnp.hpp:22-26 -------------------------------------------------------------------------
+namespace hip
+{
+struct PnpConfig  // what the reference hard-codes in pnp-solve.cpp:47-49
+{
+    int num_hypotheses = 100;
+    int sampler = MVS_SAMPLER_PHILOX;
+    uint64_t seed = 0;
+    double reproj_error = 0.05;
+};
+inline PnpConfig &pnp_config()
+{
+    static thread_local PnpConfig cfg;
+    return cfg;
+}
+}  // namespace hip
+
+inline bool pnp_solve(const std::vector<Point3> &world_points, const std::vector<ImagePoint> &image_points,
+                      const CameraIntrinsics &K, Transformation &pose, std::vector<size_t> &inlier_point_indexes)
+{
+    assert(world_points.size() >= 7);  // PNP_MIN_POINT_COUNT, pnp-solve.cpp:13,22
+    assert(world_points.size() == image_points.size());
+    const int n = (int)world_points.size();
+    static_assert(sizeof(Point3) == 3 * sizeof(double), "Point3 is three packed doubles");
+    mvs_pnp_params prm;
+    mvs_pnp_params_default(&prm);
+    const auto &cfg = hip::pnp_config();
+    prm.num_hypotheses = cfg.num_hypotheses;
+    prm.sampler = cfg.sampler;
+    prm.seed = cfg.seed;
+    prm.reproj_error = cfg.reproj_error;
+    std::vector<int64_t> idx(n);
+    double R[9], t[3];
+    int ni = 0;
+    const mvs_status st = mvs_pnp_solve(hip::context(), world_points[0].v, &image_points[0].x, n, K.data(), &prm, R, t,
+                                        idx.data(), &ni, nullptr);
+    hip::check(st, "pnp_solve");
+    if (st != MVS_OK)
+        return false;
+    inlier_point_indexes.reserve(inlier_point_indexes.size() + ni);  // the reference appends (pnp-solve.cpp:69-73)
+    for (int i = 0; i < ni; ++i)
+        inlier_point_indexes.push_back((size_t)idx[i]);
+    pose = se3_from_arrays_(R, t);  // already SE3(R, t).inverse() (pnp-solve.cpp:99-101)
+    return true;
+}
+
 // ---- front-end/image-pair.{hpp,cpp} (ctor + reconstruct; refine() is GTSAM, out of scope) ---------
 struct Frame
 {

@@ -21,6 +21,8 @@ struct mvs_ctx {
     double *d_uv1 = nullptr, *d_uv2 = nullptr;
     int uv_cap = 0;
     double *d_small = nullptr;  // 64 doubles of staging (fundamental_kernel)
+    void *d_pnp = nullptr;      // pnp_solve workspace
+    size_t pnp_bytes = 0;
 };
 
 struct mvs_batch {
@@ -213,6 +215,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_uv1) (void)hipFree(ctx->d_uv1);
     if (ctx->d_uv2) (void)hipFree(ctx->d_uv2);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -899,6 +902,94 @@ mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const doubl
     if (best_count) *best_count = res.best_count;
     if (best_residual) *best_residual = res.best_residual;
     return res.best_count > 0 ? MVS_OK : MVS_NO_MODEL;  // estimator-RANSAC.cpp:89
+}
+
+mvs_status mvs_pnp_params_default(mvs_pnp_params *p)
+{
+    if (!p)
+        return MVS_ERR_INVALID_ARG;
+    p->num_hypotheses = 100;  // pnp-solve.cpp:47
+    p->sampler = MVS_SAMPLER_PHILOX;
+    p->seed = 0;
+    p->reproj_error = 0.05;   // pnp-solve.cpp:48
+    p->min_inliers = 4;
+    p->reserved = 0;
+    return MVS_OK;
+}
+
+mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *image_uv, int n, const double K[9],
+                         const mvs_pnp_params *params, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
+                         int *best_hyp)
+{
+    if (!ctx || !world_xyz || !image_uv || !K || !params || !n_inliers)
+        return MVS_ERR_INVALID_ARG;
+    *n_inliers = 0;
+    if (best_hyp)
+        *best_hyp = -1;
+    if (n < 7 || params->num_hypotheses < 1 || !(params->reproj_error > 0.0))  // pnp-solve.cpp:13,22-23 (assert)
+        return MVS_ERR_INVALID_ARG;
+    if (params->sampler != MVS_SAMPLER_IDENTITY && params->sampler != MVS_SAMPLER_PHILOX)
+        return MVS_ERR_INVALID_ARG;
+    if (n > kPnpMaxPoints)
+        return MVS_ERR_CAPACITY;
+    if (!affine_K(K))
+        return MVS_ERR_BAD_INTRINSICS;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int G = (params->num_hypotheses + 255) / 256;
+    // workspace layout: X[3n] uv[2n] xy[2n] fb[3n] | rec[G] | out | inliers[n]
+    const size_t nd = (size_t)n * 10 * sizeof(double);
+    const size_t off_rec = (nd + 63) & ~size_t(63);
+    const size_t off_out = (off_rec + (size_t)G * sizeof(PnpRec) + 63) & ~size_t(63);
+    const size_t off_inl = (off_out + sizeof(PnpOut) + 63) & ~size_t(63);
+    const size_t total = off_inl + (size_t)n * sizeof(int32_t);
+    if (ctx->pnp_bytes < total) {
+        if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
+        ctx->d_pnp = nullptr;
+        ctx->pnp_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_pnp, total));
+        ctx->pnp_bytes = total;
+    }
+    char *base = static_cast<char *>(ctx->d_pnp);
+    double *dX = reinterpret_cast<double *>(base), *duv = dX + 3 * (size_t)n, *dxy = duv + 2 * (size_t)n, *dfb = dxy + 2 * (size_t)n;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(dX, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(duv, image_uv, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    PnpDev p{};
+    p.n = n;
+    p.num_hypotheses = params->num_hypotheses;
+    p.sampler = params->sampler;
+    p.min_inliers = params->min_inliers;
+    p.seed = params->seed;
+    p.fx2 = K[0] * K[0];
+    p.fy2 = K[4] * K[4];
+    p.thr2 = params->reproj_error * params->reproj_error;
+    mat3_inverse(K, p.Kinv);
+    p.X = dX;
+    p.uv = duv;
+    p.xy = dxy;
+    p.fb = dfb;
+    p.rec = reinterpret_cast<PnpRec *>(base + off_rec);
+    p.out = reinterpret_cast<PnpOut *>(base + off_out);
+    p.inliers = reinterpret_cast<int32_t *>(base + off_inl);
+    launch_pnp(p, s);
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    PnpOut out;
+    HIP_TRY(ctx, hipMemcpy(&out, p.out, sizeof(out), hipMemcpyDeviceToHost));
+    if (best_hyp)
+        *best_hyp = out.best_hyp;
+    if (!out.ok)
+        return MVS_NO_MODEL;
+    if (R) std::memcpy(R, out.R, sizeof(out.R));
+    if (t) std::memcpy(t, out.t, sizeof(out.t));
+    *n_inliers = out.n_inliers;
+    if (inlier_idx && out.n_inliers > 0) {
+        std::vector<int32_t> tmp(out.n_inliers);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), p.inliers, (size_t)out.n_inliers * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < out.n_inliers; ++i)
+            inlier_idx[i] = tmp[i];
+    }
+    return MVS_OK;
 }
 
 }  // extern "C"

@@ -91,6 +91,46 @@ struct RunParams {
     int min_inliers;
 };
 
+// ---- pnp_solve (row f1) ----------------------------------------------------------------------------
+constexpr int kPnpMaxPoints = 2048;  // LDS-staged point stream: 48 B per point
+
+struct PnpRec {  // best hypothesis of one RANSAC workgroup
+    int32_t count;
+    uint32_t hyp;
+    double R[9];
+    double t[3];
+};
+
+struct PnpOut {
+    int32_t ok;
+    int32_t n_inliers;
+    int32_t best_hyp;
+    int32_t pad;
+    double R[9];     // camera in world = SE3(SO3(Rw2c), tw2c).inverse()
+    double t[3];
+    double Rw2c[9];
+    double tw2c[3];
+};
+
+struct PnpDev {
+    int n;
+    int num_hypotheses;
+    int sampler;
+    int min_inliers;
+    uint64_t seed;
+    double fx2, fy2, thr2;
+    double Kinv[9];
+    const double *X;   // [n][3] world points
+    const double *uv;  // [n][2] image points
+    double *xy;        // [n][2] ideal-camera coordinates
+    double *fb;        // [n][3] unit bearings
+    PnpRec *rec;       // [ceil(H/256)]
+    int32_t *inliers;  // [n]
+    PnpOut *out;
+};
+
+void launch_pnp(const PnpDev &p, hipStream_t stream);
+
 // launch wrappers (all asynchronous on `stream`)
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
 void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);

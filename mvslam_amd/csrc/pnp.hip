@@ -1,0 +1,428 @@
+// pnp.hip -- pnp_solve (vision/pnp-solve.cpp:16-104) as a batched P3P-RANSAC.
+//
+// The reference forwards to cv::solvePnPRansac(SOLVEPNP_P3P, 100 iterations, reprojection error 0.05, confidence
+// 0.95) and inverts the pose.  OpenCV's RANSAC kernel, RNG and final EPnP refit are third-party and differ between
+// the 3.x versions the reference admits, so this is the build's own algorithm, written with
+// + - * / sqrt only so that it matches the CPU oracle bit for bit:
+//   pnp_prep      K^-1 (u, v, 1) and unit bearings                                   thread per point
+//   pnp_ransac    one hypothesis per LANE: sample 4 -> Grunert P3P on 3 (quartic by Ferrari, resolvent cubic by
+//                 64 bisections) -> pick among <= 4 solutions with the 4th point -> division-free reprojection
+//                 test on all n points (point stream staged in LDS, broadcast reads) -> workgroup arg-best
+//   pnp_finalize  arg-best over workgroups (most inliers, then first hypothesis: cv::RANSACPointSetRegistrator's
+//                 rule), ordered inlier list, pose = SE3(SO3(R), t).inverse()          (pnp-solve.cpp:99-101)
+#include "kernels.hpp"
+
+#include "device_math.hpp"
+
+namespace mvs {
+
+// 4 distinct indices in [0, n): Philox block 2 (blocks 0 / 1 belong to the 8-of-M sampler), same draw rule
+__device__ __forceinline__ void sample4(uint64_t seed, uint32_t hyp, int n, int sampler, int (&idx)[4])
+{
+    if (sampler == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            idx[k] = k;
+        return;
+    }
+    uint32_t w[4];
+    philox4x32_10(hyp, 2u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    int sorted[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        sorted[k] = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t r = __umulhi(w[k], (uint32_t)(n - k));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < k && r >= (uint32_t)sorted[t])
+                ++r;
+        idx[k] = (int)r;
+        int carry = (int)r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t <= k) {
+                const int cur = sorted[t];
+                const bool sw = carry < cur;
+                sorted[t] = sw ? carry : cur;
+                carry = sw ? cur : carry;
+            }
+        }
+    }
+}
+
+// real roots of x^4 + b x^3 + c x^2 + d x + e in fixed slots (valid flags), order: factor sg=+1 (larger, smaller),
+// then sg=-1 (larger, smaller); biquadratic case: +-sqrt(y2a), +-sqrt(y2b)
+__device__ __forceinline__ void quartic_real_roots(double b, double c, double d, double e, double (&roots)[4],
+                                                   bool (&valid)[4])
+{
+    const double p = c - 3.0 * b * b / 8.0;
+    const double q = d - b * c / 2.0 + b * b * b / 8.0;
+    const double r = e - b * d / 4.0 + b * b * c / 16.0 - 3.0 * b * b * b * b / 256.0;
+    const double sh = b / 4.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        roots[k] = 0.0;
+        valid[k] = false;
+    }
+    if (q == 0.0) {
+        const double disc = p * p - 4.0 * r;
+        if (disc >= 0.0) {
+            const double sd = dsqrt(disc);
+            const double y2a = (-p + sd) / 2.0, y2b = (-p - sd) / 2.0;
+            if (y2a >= 0.0) {
+                const double y = dsqrt(y2a);
+                roots[0] = y - sh;
+                roots[1] = -y - sh;
+                valid[0] = valid[1] = true;
+            }
+            if (y2b >= 0.0) {
+                const double y = dsqrt(y2b);
+                roots[2] = y - sh;
+                roots[3] = -y - sh;
+                valid[2] = valid[3] = true;
+            }
+        }
+        return;
+    }
+    const double c1 = 2.0 * p * p - 8.0 * r, c0 = q * q;
+    double hi = dabs(p);
+    const double h1 = dabs(c1 / 8.0), h2 = dabs(c0 / 8.0);
+    if (h1 > hi) hi = h1;
+    if (h2 > hi) hi = h2;
+    hi = hi + 1.0;
+    double lo = 0.0;
+    for (int it = 0; it < 64; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const double fm = ((8.0 * mid + 8.0 * p) * mid + c1) * mid - c0;
+        const bool pos = fm > 0.0;
+        hi = pos ? mid : hi;
+        lo = pos ? lo : mid;
+    }
+    const double m = 0.5 * (lo + hi);
+    const double s = dsqrt(2.0 * m);
+    const double t = q / (2.0 * s);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double sg = k == 0 ? 1.0 : -1.0;
+        const double cc = p / 2.0 + m + sg * t;
+        const double disc = s * s - 4.0 * cc;
+        if (disc >= 0.0) {
+            const double sd = dsqrt(disc);
+            roots[2 * k] = (sg * s + sd) / 2.0 - sh;
+            roots[2 * k + 1] = (sg * s - sd) / 2.0 - sh;
+            valid[2 * k] = valid[2 * k + 1] = true;
+        }
+    }
+}
+
+__device__ __forceinline__ double dot3r(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+// orthonormal frame of a triangle P (3 points, row-major), columns e1, e2, e3
+__device__ __forceinline__ void tri_frame(const double (&P)[9], double (&Fm)[9])
+{
+    double e1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
+    const double n1 = dsqrt((e1[0] * e1[0] + e1[1] * e1[1]) + e1[2] * e1[2]);
+    e1[0] = e1[0] / n1; e1[1] = e1[1] / n1; e1[2] = e1[2] / n1;
+    const double d[3] = {P[6] - P[0], P[7] - P[1], P[8] - P[2]};
+    double e3[3] = {e1[1] * d[2] - e1[2] * d[1], e1[2] * d[0] - e1[0] * d[2], e1[0] * d[1] - e1[1] * d[0]};
+    const double n3 = dsqrt((e3[0] * e3[0] + e3[1] * e3[1]) + e3[2] * e3[2]);
+    e3[0] = e3[0] / n3; e3[1] = e3[1] / n3; e3[2] = e3[2] / n3;
+    const double e2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Fm[k * 3 + 0] = e1[k];
+        Fm[k * 3 + 1] = e2[k];
+        Fm[k * 3 + 2] = e3[k];
+    }
+}
+
+// division-free reprojection test (squared pixel error times zc^2 against err^2 zc^2, and zc > 0)
+__device__ __forceinline__ bool pnp_inlier(const double (&R)[9], const double (&t)[3], double X0, double X1, double X2,
+                                           double xi, double yi, double fx2, double fy2, double thr2, double &lhs,
+                                           double &rhs)
+{
+    const double xc = dfma(R[0], X0, dfma(R[1], X1, dfma(R[2], X2, t[0])));
+    const double yc = dfma(R[3], X0, dfma(R[4], X1, dfma(R[5], X2, t[1])));
+    const double zc = dfma(R[6], X0, dfma(R[7], X1, dfma(R[8], X2, t[2])));
+    const double dx = dfma(-xi, zc, xc), dy = dfma(-yi, zc, yc);
+    lhs = dfma(fy2, dy * dy, fx2 * (dx * dx));
+    rhs = thr2 * (zc * zc);
+    return (zc > 0.0) && (lhs <= rhs);
+}
+
+// Grunert's P3P on 3 bearings / world points + disambiguation by a 4th correspondence.  returns false if no solution.
+__device__ __forceinline__ bool p3p_select(const double (&f)[9], const double (&X)[9], const double (&X4)[3], double x4,
+                                           double y4, double fx2, double fy2, double thr2, double (&Rb)[9],
+                                           double (&tb)[3])
+{
+    const double d12[3] = {X[0] - X[3], X[1] - X[4], X[2] - X[5]};
+    const double d13[3] = {X[0] - X[6], X[1] - X[7], X[2] - X[8]};
+    const double d23[3] = {X[3] - X[6], X[4] - X[7], X[5] - X[8]};
+    const double a2 = dot3r(d23, d23), b2 = dot3r(d13, d13), c2 = dot3r(d12, d12);
+    const double ca = dot3r(&f[3], &f[6]), cb = dot3r(&f[0], &f[6]), cg = dot3r(&f[0], &f[3]);
+    const double k1 = (a2 - c2) / b2, k2 = (a2 + c2) / b2, k3 = (b2 - c2) / b2, k4 = (b2 - a2) / b2;
+    const double A4 = (k1 - 1.0) * (k1 - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (k1 * (1.0 - k1) * cb - (1.0 - k2) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (k1 * k1 - 1.0 + 2.0 * k1 * k1 * cb * cb + 2.0 * k3 * ca * ca - 4.0 * k2 * ca * cb * cg +
+                             2.0 * k4 * cg * cg);
+    const double A1 = 4.0 * (-k1 * (1.0 + k1) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - k2) * ca * cg);
+    const double A0 = (1.0 + k1) * (1.0 + k1) - 4.0 * a2 / b2 * cg * cg;
+    double roots[4];
+    bool valid[4];
+    quartic_real_roots(A3 / A4, A2 / A4, A1 / A4, A0 / A4, roots, valid);
+    double Fw[9];
+    tri_frame(X, Fw);
+    bool have = false;
+    double sel_lhs = 0.0, sel_rhs = 1.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double v = roots[k];
+        bool ok = valid[k] && (v > 0.0);
+        const double u = ((-1.0 + k1) * v * v - 2.0 * k1 * cb * v + 1.0 + k1) / (2.0 * (cg - v * ca));
+        ok = ok && (u > 0.0);
+        if (ok) {  // divergent, but each branch is ~150 instructions and runs for most lanes of at most 2-4 slots
+            const double s1 = dsqrt(c2 / (1.0 + u * u - 2.0 * u * cg));
+            const double s2 = u * s1, s3 = v * s1;
+            const double Pc[9] = {s1 * f[0], s1 * f[1], s1 * f[2], s2 * f[3], s2 * f[4], s2 * f[5],
+                                  s3 * f[6], s3 * f[7], s3 * f[8]};
+            double Fc[9], Rk[9], tk[3];
+            tri_frame(Pc, Fc);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Rk[i * 3 + j] = (Fc[i * 3 + 0] * Fw[j * 3 + 0] + Fc[i * 3 + 1] * Fw[j * 3 + 1]) + Fc[i * 3 + 2] * Fw[j * 3 + 2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                tk[i] = Pc[i] - dot3r(&Rk[3 * i], &X[0]);
+            double lhs, rhs;
+            pnp_inlier(Rk, tk, X4[0], X4[1], X4[2], x4, y4, fx2, fy2, thr2, lhs, rhs);
+            // smallest squared pixel error on the 4th point, compared without dividing (rhs = err^2 zc^2 > 0)
+            if ((rhs > 0.0) && (!have || lhs * sel_rhs < sel_lhs * rhs)) {
+                have = true;
+                sel_lhs = lhs;
+                sel_rhs = rhs;
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    Rb[i] = Rk[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    tb[i] = tk[i];
+            }
+        }
+    }
+    return have;
+}
+
+// thread per point: ideal-camera coordinates and unit bearings
+__global__ __launch_bounds__(256) void pnp_prep_kernel(PnpDev p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n)
+        return;
+    const double u = p.uv[2 * i], v = p.uv[2 * i + 1];
+    const double x = (p.Kinv[0] * u + p.Kinv[1] * v) + p.Kinv[2];
+    const double y = (p.Kinv[3] * u + p.Kinv[4] * v) + p.Kinv[5];
+    const double nn = dsqrt((x * x + y * y) + 1.0);
+    p.xy[2 * i] = x;
+    p.xy[2 * i + 1] = y;
+    p.fb[3 * i] = x / nn;
+    p.fb[3 * i + 1] = y / nn;
+    p.fb[3 * i + 2] = 1.0 / nn;
+}
+
+// grid ceil(H/256), block 256
+__global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
+{
+    __shared__ __attribute__((aligned(16))) double s_pts[kPnpMaxPoints * 6];  // X0 X1 X2 x y pad
+    __shared__ int s_cnt[4];
+    __shared__ uint32_t s_hyp[4];
+    __shared__ uint32_t s_win;
+    const int tid = threadIdx.x, n = p.n;
+    for (int i = tid; i < n; i += 256) {
+        s_pts[6 * i + 0] = p.X[3 * i];
+        s_pts[6 * i + 1] = p.X[3 * i + 1];
+        s_pts[6 * i + 2] = p.X[3 * i + 2];
+        s_pts[6 * i + 3] = p.xy[2 * i];
+        s_pts[6 * i + 4] = p.xy[2 * i + 1];
+        s_pts[6 * i + 5] = 0.0;
+    }
+    __syncthreads();
+    const uint32_t h = blockIdx.x * 256 + tid;
+    const bool live = h < (uint32_t)p.num_hypotheses;
+    const uint32_t hh = live ? h : (uint32_t)(p.num_hypotheses - 1);
+    int idx[4];
+    sample4(p.seed, hh, n, p.sampler, idx);
+    double f3[9], X3[9], X4[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f3[3 * k + c] = p.fb[3 * idx[k] + c];
+            X3[3 * k + c] = p.X[3 * idx[k] + c];
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        X4[c] = p.X[3 * idx[3] + c];
+    double R[9], t[3];
+    const bool have = p3p_select(f3, X3, X4, p.xy[2 * idx[3]], p.xy[2 * idx[3] + 1], p.fx2, p.fy2, p.thr2, R, t);
+    int cnt = 0;
+    if (__any(have)) {
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+            const double *q = &s_pts[6 * i];  // wave-uniform address: LDS broadcast
+            double lhs, rhs;
+            cnt += pnp_inlier(R, t, q[0], q[1], q[2], q[3], q[4], p.fx2, p.fy2, p.thr2, lhs, rhs) ? 1 : 0;
+        }
+    }
+    if (!have || !live)
+        cnt = -1;
+    // workgroup arg-best: most inliers, then the smaller hypothesis id (first maximum of the sequential loop)
+    int bc = cnt;
+    uint32_t bh = h;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int oc = __shfl_xor(bc, o);
+        const uint32_t oh = __shfl_xor(bh, o);
+        if (oc > bc || (oc == bc && oh < bh)) {
+            bc = oc;
+            bh = oh;
+        }
+    }
+    if ((tid & 63) == 0) {
+        s_cnt[tid >> 6] = bc;
+        s_hyp[tid >> 6] = bh;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_cnt[w] > bc || (s_cnt[w] == bc && s_hyp[w] < bh)) {
+                bc = s_cnt[w];
+                bh = s_hyp[w];
+            }
+        s_win = bh;
+        p.rec[blockIdx.x].count = bc;
+        p.rec[blockIdx.x].hyp = bh;
+    }
+    __syncthreads();
+    if (h == s_win) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            p.rec[blockIdx.x].R[i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            p.rec[blockIdx.x].t[i] = t[i];
+    }
+}
+
+// one block of 256
+__global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
+{
+    __shared__ int s_tot[4];
+    __shared__ double s_R[9], s_t[3];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, n = p.n;
+    const int G = (p.num_hypotheses + 255) / 256;
+    if (tid == 0) {
+        int bc = -1, bg = -1;
+        uint32_t bh = 0xffffffffu;
+        for (int g = 0; g < G; ++g) {
+            const int c = p.rec[g].count;
+            const uint32_t h = p.rec[g].hyp;
+            if (c >= 0 && (c > bc || (c == bc && h < bh))) {
+                bc = c;
+                bh = h;
+                bg = g;
+            }
+        }
+        const bool ok = bg >= 0 && bc >= p.min_inliers;
+        s_ok = ok ? 1 : 0;
+        p.out->ok = ok ? 1 : 0;
+        p.out->best_hyp = bg >= 0 ? (int)bh : -1;
+        p.out->n_inliers = 0;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                s_R[i] = p.rec[bg].R[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                s_t[i] = p.rec[bg].t[i];
+        }
+    }
+    __syncthreads();
+    if (!s_ok)
+        return;
+    double R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        R[i] = s_R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        t[i] = s_t[i];
+    // ordered inlier list
+    const int lane = tid & 63, w = tid >> 6;
+    int basepos = 0;
+    for (int start = 0; start < n; start += 256) {
+        const int i = start + tid;
+        bool flag = false;
+        if (i < n) {
+            double lhs, rhs;
+            flag = pnp_inlier(R, t, p.X[3 * i], p.X[3 * i + 1], p.X[3 * i + 2], p.xy[2 * i], p.xy[2 * i + 1], p.fx2, p.fy2,
+                              p.thr2, lhs, rhs);
+        }
+        const unsigned long long bal = __ballot(flag);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_tot[w] = __popcll(bal);
+        __syncthreads();
+        int off = basepos, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = s_tot[k];
+            off += (k < w) ? v : 0;
+            tot += v;
+        }
+        if (flag)
+            p.inliers[off + pre] = i;
+        basepos += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.out->n_inliers = basepos;
+        // pose = SE3(SO3(R), t).inverse() (pnp-solve.cpp:99-101; lie-group.hpp:31-36,212-216)
+        double Rr[3][3], RT[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Rr[i][j] = R[i * 3 + j];
+                p.out->Rw2c[i * 3 + j] = R[i * 3 + j];
+            }
+        rectify3(Rr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                RT[i][j] = Rr[j][i];
+        rectify3(RT);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            p.out->tw2c[i] = t[i];
+            p.out->t[i] = -((RT[i][0] * t[0] + RT[i][1] * t[1]) + RT[i][2] * t[2]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                p.out->R[i * 3 + j] = RT[i][j];
+        }
+    }
+}
+
+void launch_pnp(const PnpDev &p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pnp_prep_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3((p.num_hypotheses + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
+}
+
+}  // namespace mvs

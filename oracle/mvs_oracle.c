@@ -1027,3 +1027,250 @@ int orc_image_pair(const uint8_t *base_desc, const float *base_kp, int n_base, c
     free(uv2);
     return ok;
 }
+
+/* ------------------------------------------------------------------------- */
+/* vision/pnp-solve.cpp (row f1): P3P-RANSAC, the build's own (see mvs_oracle.h) */
+/* ------------------------------------------------------------------------- */
+void orc_sample4(uint64_t seed, uint32_t hyp, int n, int sampler, int idx[4])
+{
+    if (sampler == ORC_SAMPLER_IDENTITY) {
+        for (int k = 0; k < 4; ++k)
+            idx[k] = k;
+        return;
+    }
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    uint32_t c0[4] = {hyp, 2, 0, 0}; /* block 2: blocks 0 and 1 belong to the 8-of-M sampler */
+    orc_philox4x32_10(c0, key, w);
+    int sorted[4];
+    for (int k = 0; k < 4; ++k) {
+        uint32_t r = (uint32_t)(((uint64_t)w[k] * (uint32_t)(n - k)) >> 32);
+        int pos = 0;
+        for (int t = 0; t < k; ++t)
+            if (r >= (uint32_t)sorted[t]) {
+                ++r;
+                pos = t + 1;
+            }
+        for (int t = k; t > pos; --t)
+            sorted[t] = sorted[t - 1];
+        sorted[pos] = (int)r;
+        idx[k] = (int)r;
+    }
+}
+
+/* real roots of x^4 + b x^3 + c x^2 + d x + e (Ferrari; the resolvent cubic's positive root by 64 bisections).
+ * Root order: quadratic factor with sg = +1 (larger, smaller), then sg = -1 (larger, smaller). */
+static int quartic_real_roots(double b, double c, double d, double e, double roots[4])
+{
+    const double p = c - 3.0 * b * b / 8.0;
+    const double q = d - b * c / 2.0 + b * b * b / 8.0;
+    const double r = e - b * d / 4.0 + b * b * c / 16.0 - 3.0 * b * b * b * b / 256.0;
+    const double sh = b / 4.0;
+    int n = 0;
+    if (q == 0.0) { /* biquadratic */
+        const double disc = p * p - 4.0 * r;
+        if (disc >= 0.0) {
+            const double sd = sqrt(disc);
+            const double y2a = (-p + sd) / 2.0, y2b = (-p - sd) / 2.0;
+            if (y2a >= 0.0) {
+                const double y = sqrt(y2a);
+                roots[n++] = y - sh;
+                roots[n++] = -y - sh;
+            }
+            if (y2b >= 0.0) {
+                const double y = sqrt(y2b);
+                roots[n++] = y - sh;
+                roots[n++] = -y - sh;
+            }
+        }
+        return n;
+    }
+    /* 8 m^3 + 8 p m^2 + (2 p^2 - 8 r) m - q^2 = 0 has a root in (0, hi): f(0) = -q^2 < 0 */
+    const double c1 = 2.0 * p * p - 8.0 * r, c0 = q * q;
+    double hi = fabs(p);
+    const double h1 = fabs(c1 / 8.0), h2 = fabs(c0 / 8.0);
+    if (h1 > hi) hi = h1;
+    if (h2 > hi) hi = h2;
+    hi = hi + 1.0;
+    double lo = 0.0;
+    for (int it = 0; it < 64; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const double fm = ((8.0 * mid + 8.0 * p) * mid + c1) * mid - c0;
+        if (fm > 0.0)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    const double m = 0.5 * (lo + hi);
+    const double s = sqrt(2.0 * m);
+    const double t = q / (2.0 * s);
+    for (int k = 0; k < 2; ++k) {
+        const double sg = k == 0 ? 1.0 : -1.0;
+        const double cc = p / 2.0 + m + sg * t; /* y^2 - sg s y + cc = 0 */
+        const double disc = s * s - 4.0 * cc;
+        if (disc >= 0.0) {
+            const double sd = sqrt(disc);
+            roots[n++] = (sg * s + sd) / 2.0 - sh;
+            roots[n++] = (sg * s - sd) / 2.0 - sh;
+        }
+    }
+    return n;
+}
+
+static void tri_frame(const double P[9], double Fm[9])
+{ /* orthonormal frame of a triangle, columns e1, e2, e3 */
+    double e1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
+    const double n1 = sqrt((e1[0] * e1[0] + e1[1] * e1[1]) + e1[2] * e1[2]);
+    e1[0] = e1[0] / n1; e1[1] = e1[1] / n1; e1[2] = e1[2] / n1;
+    const double d[3] = {P[6] - P[0], P[7] - P[1], P[8] - P[2]};
+    double e3[3] = {e1[1] * d[2] - e1[2] * d[1], e1[2] * d[0] - e1[0] * d[2], e1[0] * d[1] - e1[1] * d[0]};
+    const double n3 = sqrt((e3[0] * e3[0] + e3[1] * e3[1]) + e3[2] * e3[2]);
+    e3[0] = e3[0] / n3; e3[1] = e3[1] / n3; e3[2] = e3[2] / n3;
+    const double e2[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    for (int k = 0; k < 3; ++k) {
+        Fm[k * 3 + 0] = e1[k];
+        Fm[k * 3 + 1] = e2[k];
+        Fm[k * 3 + 2] = e3[k];
+    }
+}
+
+/* Grunert's P3P (coefficients as in Haralick et al., "Review and analysis of solutions of the three point
+ * perspective pose estimation problem", 1994): distances s1, s2 = u s1, s3 = v s1, quartic in v. */
+int orc_p3p(const double f[9], const double X[9], double R[4][9], double t[4][3])
+{
+    const double d12[3] = {X[0] - X[3], X[1] - X[4], X[2] - X[5]};
+    const double d13[3] = {X[0] - X[6], X[1] - X[7], X[2] - X[8]};
+    const double d23[3] = {X[3] - X[6], X[4] - X[7], X[5] - X[8]};
+    const double a2 = dot3(d23, d23), b2 = dot3(d13, d13), c2 = dot3(d12, d12);
+    const double ca = dot3(f + 3, f + 6), cb = dot3(f, f + 6), cg = dot3(f, f + 3);
+    const double k1 = (a2 - c2) / b2, k2 = (a2 + c2) / b2, k3 = (b2 - c2) / b2, k4 = (b2 - a2) / b2;
+    const double A4 = (k1 - 1.0) * (k1 - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (k1 * (1.0 - k1) * cb - (1.0 - k2) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (k1 * k1 - 1.0 + 2.0 * k1 * k1 * cb * cb + 2.0 * k3 * ca * ca - 4.0 * k2 * ca * cb * cg +
+                             2.0 * k4 * cg * cg);
+    const double A1 = 4.0 * (-k1 * (1.0 + k1) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - k2) * ca * cg);
+    const double A0 = (1.0 + k1) * (1.0 + k1) - 4.0 * a2 / b2 * cg * cg;
+    double roots[4];
+    const int nr = quartic_real_roots(A3 / A4, A2 / A4, A1 / A4, A0 / A4, roots);
+    double Fw[9];
+    tri_frame(X, Fw);
+    int ns = 0;
+    for (int k = 0; k < nr; ++k) {
+        const double v = roots[k];
+        if (!(v > 0.0))
+            continue;
+        const double u = ((-1.0 + k1) * v * v - 2.0 * k1 * cb * v + 1.0 + k1) / (2.0 * (cg - v * ca));
+        if (!(u > 0.0))
+            continue;
+        const double s1 = sqrt(c2 / (1.0 + u * u - 2.0 * u * cg));
+        const double s2 = u * s1, s3 = v * s1;
+        const double Pc[9] = {s1 * f[0], s1 * f[1], s1 * f[2], s2 * f[3], s2 * f[4], s2 * f[5],
+                              s3 * f[6], s3 * f[7], s3 * f[8]};
+        double Fc[9];
+        tri_frame(Pc, Fc);
+        for (int i = 0; i < 3; ++i) /* R = Fc * Fw^T */
+            for (int j = 0; j < 3; ++j)
+                R[ns][i * 3 + j] = (Fc[i * 3 + 0] * Fw[j * 3 + 0] + Fc[i * 3 + 1] * Fw[j * 3 + 1]) + Fc[i * 3 + 2] * Fw[j * 3 + 2];
+        for (int i = 0; i < 3; ++i)
+            t[ns][i] = Pc[i] - dot3(R[ns] + 3 * i, X);
+        ++ns;
+    }
+    return ns;
+}
+
+/* division-free reprojection test: lhs = fx^2 dx^2 + fy^2 dy^2 (squared pixel error times zc^2), rhs = err^2 zc^2 */
+static int pnp_inlier(const double R[9], const double t[3], const double X[3], double xi, double yi, double fx2,
+                      double fy2, double thr2, double *lhs_out, double *rhs_out)
+{
+    const double xc = fma(R[0], X[0], fma(R[1], X[1], fma(R[2], X[2], t[0])));
+    const double yc = fma(R[3], X[0], fma(R[4], X[1], fma(R[5], X[2], t[1])));
+    const double zc = fma(R[6], X[0], fma(R[7], X[1], fma(R[8], X[2], t[2])));
+    const double dx = fma(-xi, zc, xc), dy = fma(-yi, zc, yc);
+    const double lhs = fma(fy2, dy * dy, fx2 * (dx * dx));
+    const double rhs = thr2 * (zc * zc);
+    if (lhs_out) *lhs_out = lhs;
+    if (rhs_out) *rhs_out = rhs;
+    return (zc > 0.0) && (lhs <= rhs);
+}
+
+int orc_pnp_solve(const double *world_xyz, const double *image_uv, int n, const double K[9],
+                  const orc_pnp_params *prm, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
+                  double Rw2c[9], double tw2c[3], int *best_hyp_out)
+{
+    *n_inliers = 0;
+    if (best_hyp_out) *best_hyp_out = -1;
+    if (n < 7) /* pnp-solve.cpp:13,22 PNP_MIN_POINT_COUNT (assert) */
+        return 0;
+    double Kinv[9];
+    orc_mat3_inverse(K, Kinv);
+    double *xy = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *fb = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    orc_normalize_points(Kinv, image_uv, n, xy);
+    for (int i = 0; i < n; ++i) { /* unit bearing of (x, y, 1) */
+        const double x = xy[2 * i], y = xy[2 * i + 1];
+        const double nn = sqrt((x * x + y * y) + 1.0);
+        fb[3 * i] = x / nn;
+        fb[3 * i + 1] = y / nn;
+        fb[3 * i + 2] = 1.0 / nn;
+    }
+    const double fx2 = K[0] * K[0], fy2 = K[4] * K[4];
+    const double thr2 = prm->reproj_error * prm->reproj_error;
+    int best_cnt = -1, best_hyp = -1;
+    double bR[9] = {0}, bt[3] = {0};
+    for (int h = 0; h < prm->num_hypotheses; ++h) {
+        int idx[4];
+        orc_sample4(prm->seed, (uint32_t)h, n, prm->sampler, idx);
+        double f3[9], X3[9];
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) {
+                f3[3 * k + c] = fb[3 * idx[k] + c];
+                X3[3 * k + c] = world_xyz[3 * idx[k] + c];
+            }
+        double Rs[4][9], ts[4][3];
+        const int ns = orc_p3p(f3, X3, Rs, ts);
+        /* disambiguate with the 4th point: smallest squared pixel error, compared without dividing:
+         * lhs_k / rhs_k < lhs_sel / rhs_sel  <=>  lhs_k * rhs_sel < lhs_sel * rhs_k  (rhs = err^2 zc^2 > 0) */
+        int sel = -1;
+        double sel_lhs = 0.0, sel_rhs = 1.0;
+        for (int k = 0; k < ns; ++k) {
+            double lhs, rhs;
+            pnp_inlier(Rs[k], ts[k], world_xyz + 3 * idx[3], xy[2 * idx[3]], xy[2 * idx[3] + 1], fx2, fy2, thr2, &lhs, &rhs);
+            if (!(rhs > 0.0))
+                continue;
+            if (sel < 0 || lhs * sel_rhs < sel_lhs * rhs) {
+                sel = k;
+                sel_lhs = lhs;
+                sel_rhs = rhs;
+            }
+        }
+        if (sel < 0)
+            continue;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i)
+            cnt += pnp_inlier(Rs[sel], ts[sel], world_xyz + 3 * i, xy[2 * i], xy[2 * i + 1], fx2, fy2, thr2, NULL, NULL);
+        if (cnt > best_cnt) { /* first hypothesis with the most inliers wins */
+            best_cnt = cnt;
+            best_hyp = h;
+            memcpy(bR, Rs[sel], sizeof(bR));
+            memcpy(bt, ts[sel], sizeof(bt));
+        }
+    }
+    int ok = 0;
+    if (best_hyp >= 0 && best_cnt >= prm->min_inliers) {
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (pnp_inlier(bR, bt, world_xyz + 3 * i, xy[2 * i], xy[2 * i + 1], fx2, fy2, thr2, NULL, NULL))
+                inlier_idx[m++] = i;
+        *n_inliers = m;
+        if (Rw2c) memcpy(Rw2c, bR, sizeof(bR));
+        if (tw2c) memcpy(tw2c, bt, sizeof(bt));
+        double Rr[9];
+        orc_so3_from_matrix(bR, Rr);   /* SE3(SO3(R), t) */
+        orc_se3_inverse(Rr, bt, R, t); /* .inverse(): camera in world (pnp-solve.cpp:101) */
+        ok = 1;
+    }
+    if (best_hyp_out) *best_hyp_out = best_hyp;
+    free(xy);
+    free(fb);
+    return ok;
+}

@@ -154,6 +154,32 @@ int orc_image_pair(const uint8_t *base_desc, const float *base_kp, int n_base, c
                    const double K[9], const orc_params *prm, orc_match *matches, orc_two_view_result *res,
                    uint8_t *mask, double *points, int64_t *idx);
 
+/* ---- vision/pnp-solve.cpp:16-104 (row f1 of SURVEY section 8) ----
+ * The reference forwards to cv::solvePnPRansac(SOLVEPNP_P3P, 100 iterations, reprojectionError 0.05, confidence 0.95)
+ * and inverts the pose (:99-101).  OpenCV's RANSAC kernel / RNG / final EPnP refit are third-party and changed
+ * across the 3.x versions the reference admits, so this is the BUILD'S OWN P3P-RANSAC (parity-unpinned by OpenCV,
+ * pinned by the reference's pnp_solve_cube test and analytic ground truth):
+ *   sample 4 distinct points (3 for Grunert's P3P, the 4th picks among its <= 4 solutions), score by the
+ *   division-free reprojection test  fx^2 dx^2 + fy^2 dy^2 <= err^2 zc^2, zc > 0  on all points, keep the first
+ *   hypothesis with the most inliers (cv::RANSACPointSetRegistrator's rule), no refit.
+ * Only + - * / sqrt are used, so the GPU path can match bit for bit. */
+typedef struct {
+    int32_t num_hypotheses; /* reference: iterationsCount = 100 (pnp-solve.cpp:47) */
+    int32_t sampler;        /* ORC_SAMPLER_* (identity = points 0..3) */
+    uint64_t seed;
+    double reproj_error;    /* 0.05 (pnp-solve.cpp:48), in pixels of the given image points */
+    int32_t min_inliers;    /* 4 = model points of the P3P RANSAC kernel */
+} orc_pnp_params;
+
+void orc_sample4(uint64_t seed, uint32_t hyp, int n, int sampler, int idx[4]);
+/* f: 3 unit bearings (row-major 3x3), X: 3 world points; R/t: up to 4 solutions of R X + t = s f. returns count */
+int orc_p3p(const double f[9], const double X[9], double R[4][9], double t[4][3]);
+/* returns 1 on success.  R, t: pose of the camera in the world frame (= SE3(R_w2c, t_w2c).inverse(), :101).
+ * inlier_idx: capacity n, ascending.  Rw2c / tw2c / best_hyp may be NULL. */
+int orc_pnp_solve(const double *world_xyz, const double *image_uv, int n, const double K[9],
+                  const orc_pnp_params *prm, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
+                  double Rw2c[9], double tw2c[3], int *best_hyp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,6 +186,23 @@ static void ransac_estimator_and_image_pair()
     hip::ransac_config() = hip::RansacConfig();
 }
 
+static void pnp_solve_cube()
+{   // test/test-pnp.cpp:14-60
+    const ScalarType tol = 0.001;
+    CameraIntrinsics K = Matrix3Type::Identity();
+    Vector6Type se3{1, 0, 0, 0, 0, 0};
+    CameraExtrinsics P(SE3::exp(se3).inverse());
+    PinholeCamera c(K, P);
+    std::vector<Point3> world = get_rig_points(RIG_TYPE::CUBE, SO3(0.0, 0.0, 0.0), Vector3Type(0.6, 0.0, 3.0), 1.0);
+    std::vector<ImagePoint> image = c.project_points(world);
+    Transformation pose;
+    std::vector<size_t> inliers;
+    ASSERT_TRUE(pnp_solve(world, image, K, pose, inliers));
+    ASSERT_TRUE(inliers.size() == world.size());
+    const Vector6Type got = pose.ln();
+    for (int i = 0; i < 6; ++i) ASSERT_EQUAL(se3[i], got[i], tol);
+}
+
 int main()
 {
     try {
@@ -195,6 +212,7 @@ int main()
         RUN(sfm_solve_too_few_points_returns_false);
         RUN(match_visual_features_planted);
         RUN(ransac_estimator_and_image_pair);
+        RUN(pnp_solve_cube);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION: %s\n", e.what());
         return 2;

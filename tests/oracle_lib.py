@@ -360,3 +360,39 @@ def counters_get():
     c = Counters()
     lib().orc_counters_get(C.byref(c))
     return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+
+# ---- pnp-solve (row f1) ----------------------------------------------------------
+class PnpParams(C.Structure):
+    _fields_ = [("num_hypotheses", C.c_int32), ("sampler", C.c_int32), ("seed", C.c_uint64),
+                ("reproj_error", C.c_double), ("min_inliers", C.c_int32)]
+
+
+def make_pnp_params(num_hypotheses=100, sampler=SAMPLER_PHILOX, seed=0, reproj_error=0.05, min_inliers=4):
+    return PnpParams(int(num_hypotheses), int(sampler), int(seed), float(reproj_error), int(min_inliers))
+
+
+def sample4(seed, hyp, n, sampler=SAMPLER_PHILOX):
+    idx = np.empty(4, dtype=np.int32)
+    lib().orc_sample4(C.c_uint64(seed), C.c_uint32(hyp), C.c_int(n), C.c_int(sampler), _p(idx, C.c_int))
+    return idx
+
+
+def p3p(f, X):
+    f, X = _f64(f, (3, 3)), _f64(X, (3, 3))
+    R, t = np.zeros((4, 3, 3)), np.zeros((4, 3))
+    lib().orc_p3p.restype = C.c_int
+    n = lib().orc_p3p(_p(f), _p(X), _p(R), _p(t))
+    return R[:n].copy(), t[:n].copy()
+
+
+def pnp_solve(world_xyz, image_uv, K, params):
+    X, uv = _f64(world_xyz).reshape(-1, 3), _f64(image_uv).reshape(-1, 2)
+    n = len(X)
+    R, t, Rw, tw = np.zeros((3, 3)), np.zeros(3), np.zeros((3, 3)), np.zeros(3)
+    idx = np.zeros(max(n, 1), dtype=np.int64)
+    ni, bh = C.c_int(0), C.c_int(-1)
+    lib().orc_pnp_solve.restype = C.c_int
+    ok = lib().orc_pnp_solve(_p(X), _p(uv), C.c_int(n), _p(_f64(K, (3, 3))), C.byref(params), _p(R), _p(t),
+                             _p(idx, C.c_int64), C.byref(ni), _p(Rw), _p(tw), C.byref(bh))
+    return dict(ok=bool(ok), R=R, t=t, Rw2c=Rw, tw2c=tw, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
