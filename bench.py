@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1; 'gloo' (+ MVS_BENCH_ONE_DEVICE=1) rehearses the multi-rank path on "
                          "a single-GPU box: every rank uses cuda:0 and the pose records are gathered through host memory")
+    ap.add_argument("--pcie", action="store_true", help="also time upload + run + download of the whole batch (host "
+                    "buffers over PCIe); reported as pcie_inclusive_pairs_per_s, never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
     args = ap.parse_args()
@@ -226,6 +228,15 @@ def main():
             tot, _ = b1.time(prm, steps=20, warmup=3, per_kernel=False)
             out["single_pair_ms"] = round(tot / 20, 4)  # BASELINE configs[1]: one pair at a time
             b1.close()
+        if args.pcie:
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                batch.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"],
+                             data["K"], data["global_index"])
+                batch.run(prm)
+                batch.download()
+            out["pcie_inclusive_pairs_per_s"] = round(n_local * reps / (time.perf_counter() - t0), 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, params_kw, n_local)
         print(json.dumps(out), flush=True)

@@ -366,3 +366,29 @@ def test_full_size_properties(ctx):
         assert (res[inl] < 1e-2 * (1 + 1e-9)).all() and (res[~inl] > 1e-2 * (1 - 1e-9)).all()
         assert abs(np.linalg.norm(r["t1to2"]) - 1.0) < 1e-9
         assert np.abs(r["R"] @ r["R"].T - np.eye(3)).max() < 1e-9
+
+
+# ----------------------------------------------------------------------------- capacity / odd sizes
+@pytest.mark.parametrize("n_kp,H,desc_bytes", [(4096, 300, 32), (1000, 1, 32), (777, 257, 16), (513, 1025, 64)])
+def test_batch_capacity_and_odd_sizes(ctx, n_kp, H, desc_bytes):
+    """Maximum keypoint capacity (4096: more than 2048 matches go through the LDS point stream and the 2-pass bitonic
+    sort), hypothesis counts that are not multiples of the workgroup size, 128- and 512-bit descriptors."""
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=31337, max_error_sq=1e-2)
+    count = 2
+    data = synth.make_batch(500, count, n_kp=n_kp, desc_bytes=desc_bytes, common_frac=0.9)
+    b = capi.Batch(ctx, count, n_kp, desc_bytes)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+             data["global_index"])
+    b.run(prm)
+    out = b.download()
+    b.close()
+    _check_batch_against_oracle(data, out, prm)
+    if n_kp == 4096:
+        assert (out["results"]["n_matches"] > 2048).all()
+
+
+def test_batch_capacity_errors(ctx):
+    with pytest.raises(capi.MvsError):
+        capi.Batch(ctx, 1, 4097, 32)          # beyond the LDS-resident capacity
+    with pytest.raises(capi.MvsError):
+        capi.Batch(ctx, 1, 100, 24)           # descriptor size not 16 / 32 / 64 bytes
