@@ -190,6 +190,12 @@ def main():
         achieved = flops / ransac_s / 1e12
         m_avg = float(res["n_matches"].mean())
         bytes_pair = algorithmic_bytes(args.kp, m_avg, float(res["n_inliers"].mean()), float(res["n_points"].mean()))
+        # HBM bytes of the RANSAC launch from the PMC run committed under profiles/ ((2*FETCH_SIZE + WRITE_SIZE) KB per
+        # MI355X_MICROARCH.md, measured with rocprofv3 --pmc in its own pass); only valid for the default workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_ransac_hbm_traffic.json")
+        if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000:
+            traffic = int(json.load(open(tpath))["hbm_bytes_per_pair"] * n_local)
         out = {
             "metric": "image-pairs/sec (2k kp, 50k RANSAC hyp)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -204,7 +210,9 @@ def main():
                 "bound": "mfma", "kernel": "ransac_kernel",
                 "bound_detail": "fp64 VALU (vector FMA); MI355X fp64 vector peak = fp64 MFMA dense peak = 78.6 TFLOP/s",
                 "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from profiles/r01_pmc_summary_opt1.json (algorithmic: %d)"
+                                % int((m_avg * 32 + 88 * ((args.hyp + 255) // 256)) * n_local),
                 "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3)},
             "hbm_roofline": {
                 "achieved": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9, 3), "peak": HBM_PEAK_GBS,
