@@ -209,6 +209,43 @@ mvs_status mvs_batch_results_device(mvs_batch *b, void **dev_ptr, size_t *record
  * into caller-owned DEVICE memory, e.g. a torch tensor that is then all-gathered over RCCL. */
 mvs_status mvs_batch_copy_results_device(mvs_batch *b, int first, int count, void *dst_device);
 
+/* ---- frame sequences, device resident -------------------------------------------------
+ * What VisualOdometer::add_frame chains per frame (front-end/visual-odometer.cpp:129-194,384-445,502-615):
+ * ImagePair(prev, new) and track_pnp on the 3-D points the previous pair triangulated.  Every frame is uploaded ONCE;
+ * pair k = (base = frame k, pair = frame k + 1) is a zero-copy view into the frame arrays (frame k is `pair` of pair
+ * k-1 and `base` of pair k).  Track q (q = 0 .. n_frames-3) joins, on the device, the points of pair q (expressed in
+ * frame q's camera) to their observations in frame q + 2 through pair q + 1's matches (the vf-index join of
+ * visual-odometer.cpp:528-556) and runs pnp_solve on them: pose of frame q + 2 in frame q's camera frame.
+ * The VO state machine itself (initialisation gates, scale propagation, BA) stays on the host / out of scope. */
+typedef struct mvs_seq mvs_seq;
+typedef struct mvs_track_result {
+    int32_t ok;        /* pnp_solve returned true */
+    int32_t n_corr;    /* 3-D / 2-D correspondences found by the join */
+    int32_t n_inliers;
+    int32_t best_hyp;
+    double R[9];       /* pose of frame q + 2 in frame q's camera frame (pnp-solve.cpp:99-101 convention) */
+    double t[3];
+} mvs_track_result;
+
+mvs_status mvs_seq_create(mvs_ctx *ctx, int n_frames, int max_kp, int desc_bytes, mvs_seq **out);
+void mvs_seq_destroy(mvs_seq *s);
+/* frames [first, first + count): desc count x max_kp x desc_bytes, kp count x max_kp x 2 float, n_kp count; one camera K */
+mvs_status mvs_seq_upload(mvs_seq *s, int first, int count, const uint8_t *desc, const float *kp, const int32_t *n_kp,
+                          const double K[9]);
+/* all pairs (batched two-view pipeline) + all tracks (join + batched PnP), asynchronous on the ctx stream */
+mvs_status mvs_seq_run(mvs_seq *s, const mvs_params *two_view, const mvs_pnp_params *pnp);
+mvs_status mvs_seq_sync(mvs_seq *s);
+/* `steps` timed passes after `warmup`; ms_total = wall ms of the timed passes (HIP events on the ctx stream) */
+mvs_status mvs_seq_time(mvs_seq *s, const mvs_params *two_view, const mvs_pnp_params *pnp, int warmup, int steps,
+                        float *ms_total);
+/* pairs [first, first + count) of the n_frames - 1 pairs: same layout as mvs_batch_download */
+mvs_status mvs_seq_download_pairs(mvs_seq *s, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                                  uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx);
+/* tracks [first, first + count) of the n_frames - 2 tracks.  corr_xyz / corr_uv: count x max_kp x 3 / 2 (the joined
+ * correspondences, may be NULL); inlier_idx: count x max_kp (indices into the correspondences, may be NULL) */
+mvs_status mvs_seq_download_tracks(mvs_seq *s, int first, int count, mvs_track_result *tracks, double *corr_xyz,
+                                   double *corr_uv, int64_t *inlier_idx);
+
 #ifdef __cplusplus
 }
 #endif

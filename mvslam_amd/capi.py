@@ -63,6 +63,10 @@ class PnpParams(C.Structure):
                 ("reproj_error", C.c_double), ("min_inliers", C.c_int32), ("reserved", C.c_int32)]
 
 
+TRACK_DTYPE = np.dtype([("ok", "<i4"), ("n_corr", "<i4"), ("n_inliers", "<i4"), ("best_hyp", "<i4"),
+                        ("R", "<f8", (3, 3)), ("t", "<f8", (3,))])
+
+
 class WorkStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers")]
 
@@ -73,7 +77,8 @@ EXPORTS = [
     "mvs_triangulate", "mvs_recover_pose", "mvs_find_fundamental_matrix", "mvs_ransac_fundamental",
     "mvs_batch_create", "mvs_batch_destroy", "mvs_batch_upload", "mvs_batch_run", "mvs_batch_sync",
     "mvs_batch_time", "mvs_batch_download", "mvs_batch_stats", "mvs_batch_results_device",
-    "mvs_batch_copy_results_device", "mvs_pnp_params_default", "mvs_pnp_solve",
+    "mvs_batch_copy_results_device", "mvs_pnp_params_default", "mvs_pnp_solve", "mvs_seq_create", "mvs_seq_destroy",
+    "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
 ]
 
 
@@ -102,6 +107,7 @@ def lib():
         _lib.mvs_ctx_stream.argtypes = [C.c_void_p]
         _lib.mvs_ctx_destroy.argtypes = [C.c_void_p]
         _lib.mvs_batch_destroy.argtypes = [C.c_void_p]
+        _lib.mvs_seq_destroy.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -368,3 +374,68 @@ class Batch:
         sz = C.c_size_t(0)
         self.ctx._check(lib().mvs_batch_results_device(self._h, C.byref(p), C.byref(sz)), "mvs_batch_results_device")
         return p.value, sz.value
+
+
+class Sequence:
+    """Device-resident frame sequence (row f2): pair k = frames (k, k+1); track q = pnp_solve of frame q+2 against the
+    points pair q triangulated, joined on the device through pair q+1's matches."""
+
+    def __init__(self, ctx, n_frames, max_kp, desc_bytes=32):
+        self.ctx, self.n_frames, self.max_kp, self.desc_bytes = ctx, n_frames, max_kp, desc_bytes
+        self._h = C.c_void_p()
+        ctx._check(lib().mvs_seq_create(ctx._h, C.c_int(n_frames), C.c_int(max_kp), C.c_int(desc_bytes),
+                                        C.byref(self._h)), "mvs_seq_create")
+
+    def close(self):
+        if self._h:
+            lib().mvs_seq_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, first, desc, kp, n_kp, K):
+        count = len(n_kp)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(count, self.max_kp, self.desc_bytes)
+        kp = np.ascontiguousarray(kp, dtype=np.float32).reshape(count, self.max_kp, 2)
+        n_kp = np.ascontiguousarray(n_kp, dtype=np.int32)
+        st = lib().mvs_seq_upload(self._h, C.c_int(first), C.c_int(count), _ptr(desc, C.c_uint8), _ptr(kp, C.c_float),
+                                  _ptr(n_kp, C.c_int32), _ptr(_f64(K, (9,)), C.c_double))
+        self.ctx._check(st, "mvs_seq_upload")
+
+    def run(self, params, pnp_params):
+        self.ctx._check(lib().mvs_seq_run(self._h, C.byref(params), C.byref(pnp_params)), "mvs_seq_run")
+        self.ctx._check(lib().mvs_seq_sync(self._h), "mvs_seq_sync")
+
+    def time(self, params, pnp_params, steps, warmup):
+        ms = C.c_float(0)
+        st = lib().mvs_seq_time(self._h, C.byref(params), C.byref(pnp_params), C.c_int(warmup), C.c_int(steps), C.byref(ms))
+        self.ctx._check(st, "mvs_seq_time")
+        return ms.value
+
+    def download_pairs(self):
+        P, N = self.n_frames - 1, self.max_kp
+        res = np.zeros(P, dtype=RESULT_DTYPE)
+        mt = np.zeros((P, N), dtype=MATCH_DTYPE)
+        mk = np.zeros((P, N), dtype=np.uint8)
+        pts = np.zeros((P, N, 3))
+        idx = np.zeros((P, N), dtype=np.int64)
+        st = lib().mvs_seq_download_pairs(self._h, C.c_int(0), C.c_int(P), res.ctypes.data_as(C.c_void_p),
+                                          mt.ctypes.data_as(C.c_void_p), _ptr(mk, C.c_uint8), _ptr(pts, C.c_double),
+                                          _ptr(idx, C.c_int64))
+        self.ctx._check(st, "mvs_seq_download_pairs")
+        return dict(results=res, matches=mt, mask=mk, points=pts, point_idx=idx)
+
+    def download_tracks(self):
+        T, N = self.n_frames - 2, self.max_kp
+        tr = np.zeros(T, dtype=TRACK_DTYPE)
+        X = np.zeros((T, N, 3))
+        uv = np.zeros((T, N, 2))
+        inl = np.zeros((T, N), dtype=np.int64)
+        st = lib().mvs_seq_download_tracks(self._h, C.c_int(0), C.c_int(T), tr.ctypes.data_as(C.c_void_p),
+                                           _ptr(X, C.c_double), _ptr(uv, C.c_double), _ptr(inl, C.c_int64))
+        self.ctx._check(st, "mvs_seq_download_tracks")
+        return dict(tracks=tr, corr_xyz=X, corr_uv=uv, inlier_idx=inl)

@@ -25,6 +25,8 @@ struct mvs_ctx {
     size_t pnp_bytes = 0;
 };
 
+struct mvs_seq;
+
 struct mvs_batch {
     mvs_ctx *ctx = nullptr;
     BatchDev d{};
@@ -33,6 +35,15 @@ struct mvs_batch {
     int32_t *allocs_hc = nullptr;
     double *allocs_hr = nullptr;
     hipEvent_t ev[8]{};
+};
+
+struct mvs_seq {
+    mvs_ctx *ctx = nullptr;
+    mvs_batch *batch = nullptr;  // n_frames - 1 pairs viewing the frame arrays
+    int n_frames = 0, n_tracks = 0, stride = 0, rec_groups = 0;
+    SeqJoinDev join{};
+    PnpDev pnp{};
+    std::vector<void *> allocs;
 };
 
 #define HIP_TRY(ctx_, expr)                                                                    \
@@ -80,6 +91,16 @@ static mvs_status dev_alloc(mvs_batch *b, T **ptr, size_t count)
     void *p = nullptr;
     HIP_TRY(b->ctx, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
     b->allocs.push_back(p);
+    *ptr = static_cast<T *>(p);
+    return MVS_OK;
+}
+
+template <typename T>
+static mvs_status seq_alloc(mvs_seq *q, T **ptr, size_t count)
+{
+    void *p = nullptr;
+    HIP_TRY(q->ctx, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    q->allocs.push_back(p);
     *ptr = static_cast<T *>(p);
     return MVS_OK;
 }
@@ -226,7 +247,16 @@ void *mvs_ctx_stream(mvs_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr;
 // ---------------------------------------------------------------------------------------------
 // batches
 // ---------------------------------------------------------------------------------------------
+// n_frames == 0: every pair owns its two images.  n_frames == n_pairs + 1: the images are the frames of a sequence,
+// stored once; pair k = (frame k, frame k + 1) is a view into the frame arrays (row f2).
+static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_bytes, int n_frames, mvs_batch **out);
+
 mvs_status mvs_batch_create(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_bytes, mvs_batch **out)
+{
+    return batch_create_impl(ctx, n_pairs, max_kp, desc_bytes, 0, out);
+}
+
+static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_bytes, int n_frames, mvs_batch **out)
 {
     if (!ctx || !out || n_pairs < 1 || max_kp < 1)
         return MVS_ERR_INVALID_ARG;
@@ -251,12 +281,19 @@ mvs_status mvs_batch_create(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_byte
     int64_t *gidx;
 #define ALLOC(ptr, cnt)                                \
     if (st == MVS_OK) st = dev_alloc(b, &(ptr), (cnt));
-    ALLOC(desc1, P * N * d.desc_words);
-    ALLOC(desc2, P * N * d.desc_words);
-    ALLOC(kp1, P * N * 2);
-    ALLOC(kp2, P * N * 2);
-    ALLOC(n1, P);
-    ALLOC(n2, P);
+    const size_t NI = n_frames ? (size_t)n_frames : P;  // images held by desc1 / kp1 / n1
+    ALLOC(desc1, NI * N * d.desc_words);
+    ALLOC(kp1, NI * N * 2);
+    ALLOC(n1, NI);
+    if (n_frames) {  // pair k's second image is frame k + 1
+        desc2 = desc1 + N * d.desc_words;
+        kp2 = kp1 + N * 2;
+        n2 = n1 + 1;
+    } else {
+        ALLOC(desc2, P * N * d.desc_words);
+        ALLOC(kp2, P * N * 2);
+        ALLOC(n2, P);
+    }
     ALLOC(Kinv, P * 9);
     ALLOC(K, P * 9);
     ALLOC(gidx, P);
@@ -286,12 +323,14 @@ mvs_status mvs_batch_create(mvs_ctx *ctx, int n_pairs, int max_kp, int desc_byte
     d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;
     // deterministic contents for rows the caller never uploads
-    (void)hipMemsetAsync(desc1, 0, P * N * d.desc_words * 4, s);
-    (void)hipMemsetAsync(desc2, 0, P * N * d.desc_words * 4, s);
-    (void)hipMemsetAsync(kp1, 0, P * N * 2 * sizeof(float), s);
-    (void)hipMemsetAsync(kp2, 0, P * N * 2 * sizeof(float), s);
-    (void)hipMemsetAsync(n1, 0, P * sizeof(int32_t), s);
-    (void)hipMemsetAsync(n2, 0, P * sizeof(int32_t), s);
+    (void)hipMemsetAsync(desc1, 0, NI * N * d.desc_words * 4, s);
+    (void)hipMemsetAsync(kp1, 0, NI * N * 2 * sizeof(float), s);
+    (void)hipMemsetAsync(n1, 0, NI * sizeof(int32_t), s);
+    if (!n_frames) {
+        (void)hipMemsetAsync(desc2, 0, P * N * d.desc_words * 4, s);
+        (void)hipMemsetAsync(kp2, 0, P * N * 2 * sizeof(float), s);
+        (void)hipMemsetAsync(n2, 0, P * sizeof(int32_t), s);
+    }
     (void)hipMemsetAsync(gidx, 0, P * sizeof(int64_t), s);
     (void)hipMemsetAsync(d.M, 0, P * sizeof(int32_t), s);
     (void)hipMemsetAsync(d.results, 0, P * sizeof(mvs_pair_result), s);
@@ -904,6 +943,282 @@ mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const doubl
     return res.best_count > 0 ? MVS_OK : MVS_NO_MODEL;  // estimator-RANSAC.cpp:89
 }
 
+// ---------------------------------------------------------------------------------------------
+// frame sequences (row f2)
+// ---------------------------------------------------------------------------------------------
+mvs_status mvs_seq_create(mvs_ctx *ctx, int n_frames, int max_kp, int desc_bytes, mvs_seq **out)
+{
+    if (!ctx || !out || n_frames < 3)
+        return MVS_ERR_INVALID_ARG;
+    *out = nullptr;
+    mvs_seq *q = new mvs_seq();
+    q->ctx = ctx;
+    q->n_frames = n_frames;
+    q->n_tracks = n_frames - 2;
+    mvs_status st = batch_create_impl(ctx, n_frames - 1, max_kp, desc_bytes, n_frames, &q->batch);
+    if (st != MVS_OK) {
+        delete q;
+        return st;
+    }
+    q->stride = std::min(max_kp, kPnpMaxPoints);
+    const size_t T = q->n_tracks, S = q->stride;
+    double *X, *uv, *xy, *fb, *K, *Kinv;
+    int32_t *n_corr, *inl;
+    int64_t *gidx;
+    PnpOut *po;
+#define SALLOC(ptr, cnt) if (st == MVS_OK) st = seq_alloc(q, &(ptr), (cnt));
+    SALLOC(X, T * S * 3);
+    SALLOC(uv, T * S * 2);
+    SALLOC(xy, T * S * 2);
+    SALLOC(fb, T * S * 3);
+    SALLOC(K, T * 9);
+    SALLOC(Kinv, T * 9);
+    SALLOC(n_corr, T);
+    SALLOC(inl, T * S);
+    SALLOC(gidx, T);
+    SALLOC(po, T);
+#undef SALLOC
+    if (st != MVS_OK) {
+        mvs_seq_destroy(q);
+        return st;
+    }
+    std::vector<int64_t> g(T);
+    for (size_t i = 0; i < T; ++i)
+        g[i] = (int64_t)i;
+    HIP_TRY(ctx, hipMemcpy(gidx, g.data(), T * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(n_corr, 0, T * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemset(po, 0, T * sizeof(PnpOut)));
+    const BatchDev &d = q->batch->d;
+    q->join.n_tracks = q->n_tracks;
+    q->join.max_kp = d.max_kp;
+    q->join.stride = q->stride;
+    q->join.results = d.results;
+    q->join.matches = d.matches;
+    q->join.M = d.M;
+    q->join.points = d.points;
+    q->join.point_idx = d.point_idx;
+    q->join.kp = d.kp1;
+    q->join.X = X;
+    q->join.uv = uv;
+    q->join.n_corr = n_corr;
+    q->pnp.n_problems = q->n_tracks;
+    q->pnp.stride = q->stride;
+    q->pnp.n = n_corr;
+    q->pnp.gidx = gidx;
+    q->pnp.K = K;
+    q->pnp.Kinv = Kinv;
+    q->pnp.X = X;
+    q->pnp.uv = uv;
+    q->pnp.xy = xy;
+    q->pnp.fb = fb;
+    q->pnp.inliers = inl;
+    q->pnp.out = po;
+    q->pnp.rec = nullptr;
+    q->pnp.max_groups = 0;
+    *out = q;
+    return MVS_OK;
+}
+
+void mvs_seq_destroy(mvs_seq *q)
+{
+    if (!q)
+        return;
+    (void)hipSetDevice(q->ctx->device);
+    (void)hipStreamSynchronize(q->ctx->stream);
+    if (q->batch)
+        mvs_batch_destroy(q->batch);
+    for (void *p : q->allocs)
+        (void)hipFree(p);
+    delete q;
+}
+
+mvs_status mvs_seq_upload(mvs_seq *q, int first, int count, const uint8_t *desc, const float *kp, const int32_t *n_kp,
+                          const double K[9])
+{
+    if (!q || first < 0 || count < 1 || first + count > q->n_frames)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = q->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BatchDev &d = q->batch->d;
+    hipStream_t s = ctx->stream;
+    const size_t N = d.max_kp, DW = d.desc_words, off = first;
+    if (n_kp)
+        for (int i = 0; i < count; ++i)
+            if (n_kp[i] < 0 || n_kp[i] > (int)N)
+                return MVS_ERR_CAPACITY;
+    if (desc)
+        HIP_TRY(ctx, hipMemcpyAsync((char *)d.desc1 + off * N * DW * 4, desc, (size_t)count * N * DW * 4, hipMemcpyHostToDevice, s));
+    if (kp)
+        HIP_TRY(ctx, hipMemcpyAsync((char *)d.kp1 + off * N * 2 * sizeof(float), kp, (size_t)count * N * 2 * sizeof(float),
+                                    hipMemcpyHostToDevice, s));
+    if (n_kp)
+        HIP_TRY(ctx, hipMemcpyAsync((char *)d.n1 + off * sizeof(int32_t), n_kp, (size_t)count * sizeof(int32_t),
+                                    hipMemcpyHostToDevice, s));
+    std::vector<double> kk, ki;
+    std::vector<int64_t> gi;
+    if (K) {
+        if (!affine_K(K))
+            return MVS_ERR_BAD_INTRINSICS;
+        double inv[9];
+        mat3_inverse(K, inv);
+        const size_t P = d.n_pairs;
+        kk.resize(P * 9);
+        ki.resize(P * 9);
+        gi.resize(P);
+        for (size_t i = 0; i < P; ++i) {
+            std::memcpy(&kk[9 * i], K, 9 * sizeof(double));
+            std::memcpy(&ki[9 * i], inv, 9 * sizeof(double));
+            gi[i] = (int64_t)i;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(d.K), kk.data(), P * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(d.Kinv), ki.data(), P * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<int64_t *>(d.gidx), gi.data(), P * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        const size_t T = q->n_tracks;
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(q->pnp.K), kk.data(), T * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(q->pnp.Kinv), ki.data(), T * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MVS_OK;
+}
+
+static mvs_status seq_prepare(mvs_seq *q, const mvs_params *tv, const mvs_pnp_params *pp)
+{
+    if (!q || !pp || pp->num_hypotheses < 1 || !(pp->reproj_error > 0.0))
+        return MVS_ERR_INVALID_ARG;
+    if (pp->sampler != MVS_SAMPLER_IDENTITY && pp->sampler != MVS_SAMPLER_PHILOX)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(tv);
+    if (st != MVS_OK)
+        return st;
+    HIP_TRY(q->ctx, hipSetDevice(q->ctx->device));
+    if ((st = ensure_groups(q->batch, tv->num_hypotheses)) != MVS_OK)
+        return st;
+    const int G = (pp->num_hypotheses + 255) / 256;
+    if (G > q->rec_groups) {
+        HIP_TRY(q->ctx, hipStreamSynchronize(q->ctx->stream));
+        PnpRec *rec;
+        if ((st = seq_alloc(q, &rec, (size_t)q->n_tracks * G)) != MVS_OK)
+            return st;
+        q->pnp.rec = rec;
+        q->pnp.max_groups = G;
+        q->rec_groups = G;
+    }
+    q->batch->d.hyp_count = nullptr;
+    q->batch->d.hyp_residual = nullptr;
+    q->pnp.num_hypotheses = pp->num_hypotheses;
+    q->pnp.sampler = pp->sampler;
+    q->pnp.min_inliers = pp->min_inliers;
+    q->pnp.seed = pp->seed;
+    q->pnp.thr2 = pp->reproj_error * pp->reproj_error;
+    return MVS_OK;
+}
+
+static mvs_status seq_enqueue(mvs_seq *q, const RunParams &rp)
+{
+    mvs_status st = enqueue_pipeline(q->batch, rp, q->n_frames - 1, false, nullptr);
+    if (st != MVS_OK)
+        return st;
+    launch_seq_join(q->join, q->ctx->stream);
+    launch_pnp(q->pnp, q->ctx->stream);
+    HIP_TRY(q->ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+mvs_status mvs_seq_run(mvs_seq *q, const mvs_params *two_view, const mvs_pnp_params *pnp)
+{
+    mvs_status st = seq_prepare(q, two_view, pnp);
+    if (st != MVS_OK)
+        return st;
+    return seq_enqueue(q, to_run(*two_view));
+}
+
+mvs_status mvs_seq_sync(mvs_seq *q)
+{
+    if (!q)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(q->ctx, hipStreamSynchronize(q->ctx->stream));
+    return MVS_OK;
+}
+
+mvs_status mvs_seq_time(mvs_seq *q, const mvs_params *two_view, const mvs_pnp_params *pnp, int warmup, int steps,
+                        float *ms_total)
+{
+    if (steps < 1 || warmup < 0 || !ms_total)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = seq_prepare(q, two_view, pnp);
+    if (st != MVS_OK)
+        return st;
+    const RunParams rp = to_run(*two_view);
+    hipStream_t s = q->ctx->stream;
+    for (int i = 0; i < warmup; ++i)
+        if ((st = seq_enqueue(q, rp)) != MVS_OK)
+            return st;
+    HIP_TRY(q->ctx, hipStreamSynchronize(s));
+    HIP_TRY(q->ctx, hipEventRecord(q->batch->ev[5], s));
+    for (int i = 0; i < steps; ++i)
+        if ((st = seq_enqueue(q, rp)) != MVS_OK)
+            return st;
+    HIP_TRY(q->ctx, hipEventRecord(q->batch->ev[6], s));
+    HIP_TRY(q->ctx, hipEventSynchronize(q->batch->ev[6]));
+    HIP_TRY(q->ctx, hipEventElapsedTime(ms_total, q->batch->ev[5], q->batch->ev[6]));
+    return MVS_OK;
+}
+
+mvs_status mvs_seq_download_pairs(mvs_seq *q, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                                  uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx)
+{
+    if (!q)
+        return MVS_ERR_INVALID_ARG;
+    return mvs_batch_download(q->batch, first, count, results, matches, inlier_mask, points_xyz, point_idx);
+}
+
+mvs_status mvs_seq_download_tracks(mvs_seq *q, int first, int count, mvs_track_result *tracks, double *corr_xyz,
+                                   double *corr_uv, int64_t *inlier_idx)
+{
+    if (!q || first < 0 || count < 1 || first + count > q->n_tracks)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = q->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t S = q->stride, N = q->batch->d.max_kp, off = first, cnt = count;
+    if (tracks) {
+        std::vector<PnpOut> po(cnt);
+        std::vector<int32_t> nc(cnt);
+        HIP_TRY(ctx, hipMemcpy(po.data(), q->pnp.out + off, cnt * sizeof(PnpOut), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(nc.data(), q->pnp.n + off, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i) {
+            mvs_track_result &t = tracks[i];
+            t.ok = nc[i] >= 7 ? po[i].ok : 0;
+            t.n_corr = nc[i];
+            t.n_inliers = t.ok ? po[i].n_inliers : 0;
+            t.best_hyp = nc[i] >= 7 ? po[i].best_hyp : -1;
+            std::memcpy(t.R, po[i].R, sizeof(t.R));
+            std::memcpy(t.t, po[i].t, sizeof(t.t));
+        }
+    }
+    // device layout has `stride` slots per track, the host layout max_kp
+    auto fetch = [&](const void *dev, size_t elem_bytes, size_t per, void *host) -> mvs_status {
+        std::vector<char> tmp(cnt * S * per * elem_bytes);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), (const char *)dev + off * S * per * elem_bytes, tmp.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i)
+            std::memcpy((char *)host + i * N * per * elem_bytes, tmp.data() + i * S * per * elem_bytes, S * per * elem_bytes);
+        return MVS_OK;
+    };
+    mvs_status st = MVS_OK;
+    if (corr_xyz && (st = fetch(q->pnp.X, sizeof(double), 3, corr_xyz)) != MVS_OK)
+        return st;
+    if (corr_uv && (st = fetch(q->pnp.uv, sizeof(double), 2, corr_uv)) != MVS_OK)
+        return st;
+    if (inlier_idx) {
+        std::vector<int32_t> tmp(cnt * S);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), q->pnp.inliers + off * S, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i)
+            for (size_t k = 0; k < S; ++k)
+                inlier_idx[i * N + k] = tmp[i * S + k];
+    }
+    return MVS_OK;
+}
+
 mvs_status mvs_pnp_params_default(mvs_pnp_params *p)
 {
     if (!p)
@@ -936,12 +1251,13 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
         return MVS_ERR_BAD_INTRINSICS;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int G = (params->num_hypotheses + 255) / 256;
-    // workspace layout: X[3n] uv[2n] xy[2n] fb[3n] | rec[G] | out | inliers[n]
+    // workspace layout: X[3n] uv[2n] xy[2n] fb[3n] | K[9] Kinv[9] | rec[G] | out | inliers[n] n
     const size_t nd = (size_t)n * 10 * sizeof(double);
-    const size_t off_rec = (nd + 63) & ~size_t(63);
+    const size_t off_k = (nd + 63) & ~size_t(63);
+    const size_t off_rec = (off_k + 18 * sizeof(double) + 63) & ~size_t(63);
     const size_t off_out = (off_rec + (size_t)G * sizeof(PnpRec) + 63) & ~size_t(63);
     const size_t off_inl = (off_out + sizeof(PnpOut) + 63) & ~size_t(63);
-    const size_t total = off_inl + (size_t)n * sizeof(int32_t);
+    const size_t total = off_inl + ((size_t)n + 1) * sizeof(int32_t);
     if (ctx->pnp_bytes < total) {
         if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
         ctx->d_pnp = nullptr;
@@ -951,26 +1267,38 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
     }
     char *base = static_cast<char *>(ctx->d_pnp);
     double *dX = reinterpret_cast<double *>(base), *duv = dX + 3 * (size_t)n, *dxy = duv + 2 * (size_t)n, *dfb = dxy + 2 * (size_t)n;
+    double *dK = reinterpret_cast<double *>(base + off_k);
+    int32_t *dinl = reinterpret_cast<int32_t *>(base + off_inl);
     hipStream_t s = ctx->stream;
+    double kk[18];
+    std::memcpy(kk, K, 9 * sizeof(double));
+    mat3_inverse(K, kk + 9);
+    const int32_t n32 = n;
     HIP_TRY(ctx, hipMemcpyAsync(dX, world_xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(duv, image_uv, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dK, kk, sizeof(kk), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dinl + n, &n32, sizeof(n32), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     PnpDev p{};
-    p.n = n;
+    p.n_problems = 1;
+    p.stride = n;
     p.num_hypotheses = params->num_hypotheses;
     p.sampler = params->sampler;
     p.min_inliers = params->min_inliers;
+    p.max_groups = G;
     p.seed = params->seed;
-    p.fx2 = K[0] * K[0];
-    p.fy2 = K[4] * K[4];
     p.thr2 = params->reproj_error * params->reproj_error;
-    mat3_inverse(K, p.Kinv);
+    p.n = dinl + n;
+    p.gidx = nullptr;
+    p.K = dK;
+    p.Kinv = dK + 9;
     p.X = dX;
     p.uv = duv;
     p.xy = dxy;
     p.fb = dfb;
     p.rec = reinterpret_cast<PnpRec *>(base + off_rec);
     p.out = reinterpret_cast<PnpOut *>(base + off_out);
-    p.inliers = reinterpret_cast<int32_t *>(base + off_inl);
+    p.inliers = dinl;
     launch_pnp(p, s);
     HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipGetLastError());

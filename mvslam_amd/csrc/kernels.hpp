@@ -112,24 +112,46 @@ struct PnpOut {
     double tw2c[3];
 };
 
-struct PnpDev {
-    int n;
+struct PnpDev {       // a batch of PnP problems; problem q owns slice [q * stride, q * stride + n[q])
+    int n_problems;
+    int stride;       // capacity (points) of one problem, <= kPnpMaxPoints
     int num_hypotheses;
     int sampler;
     int min_inliers;
-    uint64_t seed;
-    double fx2, fy2, thr2;
-    double Kinv[9];
-    const double *X;   // [n][3] world points
-    const double *uv;  // [n][2] image points
-    double *xy;        // [n][2] ideal-camera coordinates
-    double *fb;        // [n][3] unit bearings
-    PnpRec *rec;       // [ceil(H/256)]
-    int32_t *inliers;  // [n]
-    PnpOut *out;
+    int max_groups;   // records per problem
+    uint64_t seed;    // problem q uses seed + gidx[q]
+    double thr2;      // reproj_error^2
+    const int32_t *n;       // [Q] points of each problem (< 7: no model)
+    const int64_t *gidx;    // [Q] sampler key offsets (may be null = 0)
+    const double *K;        // [Q][9]
+    const double *Kinv;     // [Q][9]
+    const double *X;        // [Q][stride][3] world points
+    const double *uv;       // [Q][stride][2] image points
+    double *xy;             // [Q][stride][2] ideal-camera coordinates
+    double *fb;             // [Q][stride][3] unit bearings
+    PnpRec *rec;            // [Q][max_groups]
+    int32_t *inliers;       // [Q][stride]
+    PnpOut *out;            // [Q]
 };
 
 void launch_pnp(const PnpDev &p, hipStream_t stream);
+
+// ---- frame sequences (row f2): join of pair q's points with their observations in frame q + 2 ------------------
+struct SeqJoinDev {
+    int n_tracks;      // n_frames - 2
+    int max_kp;
+    int stride;        // capacity of one PnP problem = min(max_kp, kPnpMaxPoints)
+    const mvs_pair_result *results;  // [n_frames - 1]
+    const mvs_match *matches;        // [n_frames - 1][max_kp]
+    const int32_t *M;                // [n_frames - 1]
+    const double *points;            // [n_frames - 1][max_kp][3]
+    const int32_t *point_idx;        // [n_frames - 1][max_kp]
+    const float *kp;                 // [n_frames][max_kp][2]
+    double *X;                       // [n_tracks][stride][3]
+    double *uv;                      // [n_tracks][stride][2]
+    int32_t *n_corr;                 // [n_tracks]
+};
+void launch_seq_join(const SeqJoinDev &j, hipStream_t stream);
 
 // launch wrappers (all asynchronous on `stream`)
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);

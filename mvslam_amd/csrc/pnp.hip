@@ -216,65 +216,81 @@ __device__ __forceinline__ bool p3p_select(const double (&f)[9], const double (&
     return have;
 }
 
-// thread per point: ideal-camera coordinates and unit bearings
+// grid (ceil(stride/256), Q): ideal-camera coordinates and unit bearings
 __global__ __launch_bounds__(256) void pnp_prep_kernel(PnpDev p)
 {
+    const int q = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n)
+    if (i >= p.n[q])
         return;
-    const double u = p.uv[2 * i], v = p.uv[2 * i + 1];
-    const double x = (p.Kinv[0] * u + p.Kinv[1] * v) + p.Kinv[2];
-    const double y = (p.Kinv[3] * u + p.Kinv[4] * v) + p.Kinv[5];
+    const size_t o = (size_t)q * p.stride + i;
+    const double *Ki = p.Kinv + (size_t)q * 9;
+    const double u = p.uv[2 * o], v = p.uv[2 * o + 1];
+    const double x = (Ki[0] * u + Ki[1] * v) + Ki[2];
+    const double y = (Ki[3] * u + Ki[4] * v) + Ki[5];
     const double nn = dsqrt((x * x + y * y) + 1.0);
-    p.xy[2 * i] = x;
-    p.xy[2 * i + 1] = y;
-    p.fb[3 * i] = x / nn;
-    p.fb[3 * i + 1] = y / nn;
-    p.fb[3 * i + 2] = 1.0 / nn;
+    p.xy[2 * o] = x;
+    p.xy[2 * o + 1] = y;
+    p.fb[3 * o] = x / nn;
+    p.fb[3 * o + 1] = y / nn;
+    p.fb[3 * o + 2] = 1.0 / nn;
 }
 
-// grid ceil(H/256), block 256
+// grid (ceil(H/256), Q), block 256
 __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
 {
     __shared__ __attribute__((aligned(16))) double s_pts[kPnpMaxPoints * 6];  // X0 X1 X2 x y pad
     __shared__ int s_cnt[4];
     __shared__ uint32_t s_hyp[4];
     __shared__ uint32_t s_win;
-    const int tid = threadIdx.x, n = p.n;
+    const int tid = threadIdx.x, q = blockIdx.y, n = p.n[q];
+    PnpRec *rec = p.rec + (size_t)q * p.max_groups + blockIdx.x;
+    if (n < 7) {  // pnp-solve.cpp:13,22 (the reference asserts)
+        if (tid == 0) {
+            rec->count = -1;
+            rec->hyp = 0xffffffffu;
+        }
+        return;
+    }
+    const size_t o = (size_t)q * p.stride;
+    const double *X = p.X + 3 * o, *xy = p.xy + 2 * o, *fb = p.fb + 3 * o;
+    const double *K = p.K + (size_t)q * 9;
+    const double fx2 = K[0] * K[0], fy2 = K[4] * K[4], thr2 = p.thr2;
     for (int i = tid; i < n; i += 256) {
-        s_pts[6 * i + 0] = p.X[3 * i];
-        s_pts[6 * i + 1] = p.X[3 * i + 1];
-        s_pts[6 * i + 2] = p.X[3 * i + 2];
-        s_pts[6 * i + 3] = p.xy[2 * i];
-        s_pts[6 * i + 4] = p.xy[2 * i + 1];
+        s_pts[6 * i + 0] = X[3 * i];
+        s_pts[6 * i + 1] = X[3 * i + 1];
+        s_pts[6 * i + 2] = X[3 * i + 2];
+        s_pts[6 * i + 3] = xy[2 * i];
+        s_pts[6 * i + 4] = xy[2 * i + 1];
         s_pts[6 * i + 5] = 0.0;
     }
     __syncthreads();
     const uint32_t h = blockIdx.x * 256 + tid;
     const bool live = h < (uint32_t)p.num_hypotheses;
     const uint32_t hh = live ? h : (uint32_t)(p.num_hypotheses - 1);
+    const uint64_t seed = p.seed + (p.gidx ? (uint64_t)p.gidx[q] : 0ull);
     int idx[4];
-    sample4(p.seed, hh, n, p.sampler, idx);
+    sample4(seed, hh, n, p.sampler, idx);
     double f3[9], X3[9], X4[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            f3[3 * k + c] = p.fb[3 * idx[k] + c];
-            X3[3 * k + c] = p.X[3 * idx[k] + c];
+            f3[3 * k + c] = fb[3 * idx[k] + c];
+            X3[3 * k + c] = X[3 * idx[k] + c];
         }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        X4[c] = p.X[3 * idx[3] + c];
+        X4[c] = X[3 * idx[3] + c];
     double R[9], t[3];
-    const bool have = p3p_select(f3, X3, X4, p.xy[2 * idx[3]], p.xy[2 * idx[3] + 1], p.fx2, p.fy2, p.thr2, R, t);
+    const bool have = p3p_select(f3, X3, X4, xy[2 * idx[3]], xy[2 * idx[3] + 1], fx2, fy2, thr2, R, t);
     int cnt = 0;
     if (__any(have)) {
 #pragma unroll 4
         for (int i = 0; i < n; ++i) {
-            const double *q = &s_pts[6 * i];  // wave-uniform address: LDS broadcast
+            const double *pt = &s_pts[6 * i];  // wave-uniform address: LDS broadcast
             double lhs, rhs;
-            cnt += pnp_inlier(R, t, q[0], q[1], q[2], q[3], q[4], p.fx2, p.fy2, p.thr2, lhs, rhs) ? 1 : 0;
+            cnt += pnp_inlier(R, t, pt[0], pt[1], pt[2], pt[3], pt[4], fx2, fy2, thr2, lhs, rhs) ? 1 : 0;
         }
     }
     if (!have || !live)
@@ -283,9 +299,9 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
     int bc = cnt;
     uint32_t bh = h;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int oc = __shfl_xor(bc, o);
-        const uint32_t oh = __shfl_xor(bh, o);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const int oc = __shfl_xor(bc, o2);
+        const uint32_t oh = __shfl_xor(bh, o2);
         if (oc > bc || (oc == bc && oh < bh)) {
             bc = oc;
             bh = oh;
@@ -303,52 +319,56 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
                 bh = s_hyp[w];
             }
         s_win = bh;
-        p.rec[blockIdx.x].count = bc;
-        p.rec[blockIdx.x].hyp = bh;
+        rec->count = bc;
+        rec->hyp = bh;
     }
     __syncthreads();
     if (h == s_win) {
 #pragma unroll
         for (int i = 0; i < 9; ++i)
-            p.rec[blockIdx.x].R[i] = R[i];
+            rec->R[i] = R[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            p.rec[blockIdx.x].t[i] = t[i];
+            rec->t[i] = t[i];
     }
 }
 
-// one block of 256
+// grid Q, block 256
 __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
 {
     __shared__ int s_tot[4];
     __shared__ double s_R[9], s_t[3];
     __shared__ int s_ok;
-    const int tid = threadIdx.x, n = p.n;
+    const int tid = threadIdx.x, q = blockIdx.x, n = p.n[q];
     const int G = (p.num_hypotheses + 255) / 256;
+    const PnpRec *rec = p.rec + (size_t)q * p.max_groups;
+    PnpOut *out = p.out + q;
     if (tid == 0) {
         int bc = -1, bg = -1;
         uint32_t bh = 0xffffffffu;
-        for (int g = 0; g < G; ++g) {
-            const int c = p.rec[g].count;
-            const uint32_t h = p.rec[g].hyp;
-            if (c >= 0 && (c > bc || (c == bc && h < bh))) {
-                bc = c;
-                bh = h;
-                bg = g;
+        if (n >= 7) {
+            for (int g = 0; g < G; ++g) {
+                const int c = rec[g].count;
+                const uint32_t h = rec[g].hyp;
+                if (c >= 0 && (c > bc || (c == bc && h < bh))) {
+                    bc = c;
+                    bh = h;
+                    bg = g;
+                }
             }
         }
         const bool ok = bg >= 0 && bc >= p.min_inliers;
         s_ok = ok ? 1 : 0;
-        p.out->ok = ok ? 1 : 0;
-        p.out->best_hyp = bg >= 0 ? (int)bh : -1;
-        p.out->n_inliers = 0;
+        out->ok = ok ? 1 : 0;
+        out->best_hyp = bg >= 0 ? (int)bh : -1;
+        out->n_inliers = 0;
         if (ok) {
 #pragma unroll
             for (int i = 0; i < 9; ++i)
-                s_R[i] = p.rec[bg].R[i];
+                s_R[i] = rec[bg].R[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                s_t[i] = p.rec[bg].t[i];
+                s_t[i] = rec[bg].t[i];
         }
     }
     __syncthreads();
@@ -361,6 +381,11 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         t[i] = s_t[i];
+    const size_t o = (size_t)q * p.stride;
+    const double *X = p.X + 3 * o, *xy = p.xy + 2 * o;
+    const double *K = p.K + (size_t)q * 9;
+    const double fx2 = K[0] * K[0], fy2 = K[4] * K[4];
+    int32_t *inl = p.inliers + o;
     // ordered inlier list
     const int lane = tid & 63, w = tid >> 6;
     int basepos = 0;
@@ -369,8 +394,7 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
         bool flag = false;
         if (i < n) {
             double lhs, rhs;
-            flag = pnp_inlier(R, t, p.X[3 * i], p.X[3 * i + 1], p.X[3 * i + 2], p.xy[2 * i], p.xy[2 * i + 1], p.fx2, p.fy2,
-                              p.thr2, lhs, rhs);
+            flag = pnp_inlier(R, t, X[3 * i], X[3 * i + 1], X[3 * i + 2], xy[2 * i], xy[2 * i + 1], fx2, fy2, p.thr2, lhs, rhs);
         }
         const unsigned long long bal = __ballot(flag);
         const int pre = __popcll(bal & ((1ull << lane) - 1ull));
@@ -385,12 +409,12 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
             tot += v;
         }
         if (flag)
-            p.inliers[off + pre] = i;
+            inl[off + pre] = i;
         basepos += tot;
         __syncthreads();
     }
     if (tid == 0) {
-        p.out->n_inliers = basepos;
+        out->n_inliers = basepos;
         // pose = SE3(SO3(R), t).inverse() (pnp-solve.cpp:99-101; lie-group.hpp:31-36,212-216)
         double Rr[3][3], RT[3][3];
 #pragma unroll
@@ -398,7 +422,7 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 Rr[i][j] = R[i * 3 + j];
-                p.out->Rw2c[i * 3 + j] = R[i * 3 + j];
+                out->Rw2c[i * 3 + j] = R[i * 3 + j];
             }
         rectify3(Rr);
 #pragma unroll
@@ -409,20 +433,88 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
         rectify3(RT);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            p.out->tw2c[i] = t[i];
-            p.out->t[i] = -((RT[i][0] * t[0] + RT[i][1] * t[1]) + RT[i][2] * t[2]);
+            out->tw2c[i] = t[i];
+            out->t[i] = -((RT[i][0] * t[0] + RT[i][1] * t[1]) + RT[i][2] * t[2]);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                p.out->R[i * 3 + j] = RT[i][j];
+                out->R[i * 3 + j] = RT[i][j];
         }
     }
 }
 
+// grid n_tracks, block 256.  Track q: pair a = q (frames q, q+1), pair b = q + 1 (frames q+1, q+2).
+// point j of pair a belongs to match m = point_idx[a][j], whose queryIdx is a keypoint index of frame q+1; every
+// match m' of pair b whose trainIdx is that keypoint observes the same point in frame q+2 (queryIdx of m').
+// Correspondences are emitted in the order of pair b's match list (visual-odometer.cpp:528-556 restated as a join).
+__global__ __launch_bounds__(256) void seq_join_kernel(SeqJoinDev j)
+{
+    __shared__ int16_t s_tbl[kMaxKp];
+    __shared__ int s_tot[4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int a = q, b = q + 1;
+    const size_t N = j.max_kp;
+    const bool valid = j.results[a].valid != 0;
+    const int npts = valid ? j.results[a].n_points : 0;
+    const int Mb = min(j.M[b], j.max_kp);
+    for (int i = tid; i < j.max_kp; i += 256)
+        s_tbl[i] = -1;
+    __syncthreads();
+    for (int p = tid; p < npts; p += 256) {
+        const int m = j.point_idx[a * N + p];
+        s_tbl[j.matches[a * N + m].queryIdx] = (int16_t)p;  // queryIdx values are unique within one match list
+    }
+    __syncthreads();
+    const float *kp2 = j.kp + (size_t)(q + 2) * N * 2;
+    double *X = j.X + (size_t)q * j.stride * 3, *uv = j.uv + (size_t)q * j.stride * 2;
+    int basepos = 0;
+    for (int start = 0; start < Mb; start += 256) {
+        const int m = start + tid;
+        int p = -1, qi = 0;
+        if (m < Mb) {
+            const mvs_match mt = j.matches[b * N + m];
+            p = s_tbl[mt.trainIdx];
+            qi = mt.queryIdx;
+        }
+        const bool flag = p >= 0;
+        const unsigned long long bal = __ballot(flag);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_tot[w] = __popcll(bal);
+        __syncthreads();
+        int off = basepos, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = s_tot[k];
+            off += (k < w) ? v : 0;
+            tot += v;
+        }
+        const int pos = off + pre;
+        if (flag && pos < j.stride) {
+            const double *src = j.points + ((size_t)a * N + p) * 3;
+            X[3 * pos] = src[0];
+            X[3 * pos + 1] = src[1];
+            X[3 * pos + 2] = src[2];
+            uv[2 * pos] = (double)kp2[2 * qi];       // visual-feature.cpp:179-190 float -> double
+            uv[2 * pos + 1] = (double)kp2[2 * qi + 1];
+        }
+        basepos += tot;
+        __syncthreads();
+    }
+    if (tid == 0)
+        j.n_corr[q] = min(basepos, j.stride);
+}
+
+void launch_seq_join(const SeqJoinDev &j, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_join_kernel, dim3(j.n_tracks), dim3(256), 0, stream, j);
+}
+
 void launch_pnp(const PnpDev &p, hipStream_t stream)
 {
-    hipLaunchKernelGGL(pnp_prep_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(pnp_ransac_kernel, dim3((p.num_hypotheses + 255) / 256), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
+    const int Q = p.n_problems;
+    hipLaunchKernelGGL(pnp_prep_kernel, dim3((p.stride + 255) / 256, Q), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3((p.num_hypotheses + 255) / 256, Q), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(Q), dim3(256), 0, stream, p);
 }
 
 }  // namespace mvs

@@ -94,3 +94,47 @@ def make_batch(first, count, n_kp=2000, **kw):
         out["desc1"][i], out["kp1"][i], out["desc2"][i], out["kp2"][i] = p["desc1"], p["kp1"], p["desc2"], p["kp2"]
         out["K"][i] = p["K"].reshape(9)
     return out
+
+
+def make_sequence(n_frames, n_kp=2000, n_map=20000, noise_px=0.5, flip_p=0.02, seed=0x5E9, width=640, height=480,
+                  desc_bytes=32, K=K_DEFAULT, step=0.05, yaw_step=0.005):
+    """BASELINE configs[4]: a camera moving `step` m per frame (forward-lateral, small yaw) over a persistent map of
+    `n_map` points; every frame keeps up to 0.8 * n_kp visible map points (noisy projections, the point's descriptor
+    with per-frame bit flips) and pads to n_kp with clutter.  Returns desc [F, n_kp, B], kp [F, n_kp, 2] float32,
+    n_kp [F], K, and the ground-truth camera poses (R_w2c, t_w2c) per frame."""
+    rng = np.random.default_rng(seed)
+    nbits = desc_bytes * 8
+    # the map lies in a corridor in front of the trajectory
+    L = step * n_frames
+    Xw = np.stack([rng.uniform(-6, 6 + 0.5 * L, n_map), rng.uniform(-3, 3, n_map), rng.uniform(2, 12 + L, n_map)], axis=1)
+    map_bits = rng.integers(0, 2, size=(n_map, nbits), dtype=np.uint8)
+    desc = np.empty((n_frames, n_kp, desc_bytes), dtype=np.uint8)
+    kp = np.empty((n_frames, n_kp, 2), dtype=np.float32)
+    poses = []
+    n_vis_max = int(0.8 * n_kp)
+    for f in range(n_frames):
+        yaw = yaw_step * f
+        R = np.array([[np.cos(yaw), 0, -np.sin(yaw)], [0, 1, 0], [np.sin(yaw), 0, np.cos(yaw)]])   # world -> camera
+        c = np.array([0.5 * step * f, 0.0, step * f * 0.866])                                      # camera centre
+        t = -R @ c
+        Xc = (R @ Xw.T).T + t
+        z = Xc[:, 2]
+        uvp = (K @ Xc.T).T
+        uv = uvp[:, :2] / np.where(z[:, None] > 0.1, uvp[:, 2:3], 1.0)
+        vis = (z > 1.0) & (uv[:, 0] >= 1) & (uv[:, 0] < width - 1) & (uv[:, 1] >= 1) & (uv[:, 1] < height - 1)
+        ids = np.nonzero(vis)[0]
+        if len(ids) > n_vis_max:
+            ids = ids[np.argsort((ids * 2654435761) % 1000003)[:n_vis_max]]     # a stable pseudo-random subset
+        nv = len(ids)
+        pts = uv[ids] + rng.normal(scale=noise_px, size=(nv, 2)) if noise_px > 0 else uv[ids]
+        bits = map_bits[ids] ^ (rng.random((nv, nbits)) < flip_p).astype(np.uint8)
+        fk = np.empty((n_kp, 2))
+        fb = rng.integers(0, 2, size=(n_kp, nbits), dtype=np.uint8)
+        fk[:nv] = np.clip(pts, 0, [width - 1e-3, height - 1e-3])
+        fb[:nv] = bits
+        fk[nv:] = np.stack([rng.uniform(0, width, n_kp - nv), rng.uniform(0, height, n_kp - nv)], axis=1)
+        perm = rng.permutation(n_kp)
+        kp[f] = fk[perm].astype(np.float32)
+        desc[f] = np.packbits(fb[perm], axis=1, bitorder="little")
+        poses.append((R, t))
+    return dict(desc=desc, kp=kp, n_kp=np.full(n_frames, n_kp, dtype=np.int32), K=K.copy(), poses=poses)

@@ -1,0 +1,115 @@
+"""Row f2: device-resident frame sequence = batched ImagePair over consecutive frames + on-device join + batched
+pnp_solve.  The oracle side composes image_pair -> (numpy join) -> pnp_solve per frame."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib as o
+from mvslam_amd import synth
+
+
+def oracle_sequence(seq, prm, pprm, ratio=0.7, max_dist=10.0):
+    F = len(seq["n_kp"])
+    K = seq["K"]
+    pairs = []
+    for k in range(F - 1):
+        op = o.make_params(prm["H"], o.SAMPLER_PHILOX, prm["seed"] + k, prm["thr"])
+        a, b = seq["n_kp"][k], seq["n_kp"][k + 1]
+        pairs.append(o.image_pair(seq["desc"][k][:a], seq["kp"][k][:a], seq["desc"][k + 1][:b], seq["kp"][k + 1][:b], K,
+                                  op, ratio, max_dist))
+    tracks = []
+    for q in range(F - 2):
+        pa, pb = pairs[q], pairs[q + 1]
+        tbl = {}
+        if pa["ok"]:
+            for j, m in enumerate(pa["point_idx"]):
+                tbl[int(pa["matches"]["queryIdx"][m])] = j
+        X, uv = [], []
+        for mt in pb["matches"]:
+            j = tbl.get(int(mt["trainIdx"]))
+            if j is not None:
+                X.append(pa["points"][j])
+                uv.append(seq["kp"][q + 2][mt["queryIdx"]].astype(np.float64))
+        X, uv = np.array(X).reshape(-1, 3), np.array(uv).reshape(-1, 2)
+        r = dict(ok=False, inliers=np.zeros(0, np.int64), best_hyp=-1)
+        if len(X) >= 7:
+            r = o.pnp_solve(X, uv, K, o.make_pnp_params(pprm["H"], o.SAMPLER_PHILOX, pprm["seed"] + q, pprm["err"]))
+        r["X"], r["uv"] = X, uv
+        tracks.append(r)
+    return pairs, tracks
+
+
+def test_sequence_generator_is_consistent():
+    s = synth.make_sequence(4, n_kp=300, n_map=3000)
+    assert s["desc"].shape == (4, 300, 32) and s["kp"].dtype == np.float32
+    s2 = synth.make_sequence(4, n_kp=300, n_map=3000)
+    assert np.array_equal(s["desc"], s2["desc"]) and np.array_equal(s["kp"], s2["kp"])
+    # consecutive frames share most of their map points: the matcher finds them
+    m = o.match_visual_features(s["desc"][0], s["desc"][1], 0.7, 10.0)
+    assert len(m) > 100
+
+
+@pytest.mark.gpu
+def test_gpu_sequence_matches_oracle(ctx):
+    from mvslam_amd import capi
+
+    F, N = 6, 500
+    seq = synth.make_sequence(F, n_kp=N, n_map=6000, noise_px=0.3)
+    prm = dict(H=600, seed=4242, thr=1e-2)
+    pprm = dict(H=300, seed=99, err=2.0)
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    s.run(capi.default_params(num_hypotheses=prm["H"], sampler=capi.SAMPLER_PHILOX, seed=prm["seed"], max_error_sq=prm["thr"]),
+          capi.default_pnp_params(num_hypotheses=pprm["H"], seed=pprm["seed"], reproj_error=pprm["err"]))
+    gp, gt = s.download_pairs(), s.download_tracks()
+    s.close()
+    pairs, tracks = oracle_sequence(seq, prm, pprm)
+    for k, ref in enumerate(pairs):                                   # the zero-copy pair views behave like a batch
+        r = gp["results"][k]
+        M = ref["n_matches"]
+        assert r["n_matches"] == M and gp["matches"][k][:M].tobytes() == ref["matches"].tobytes()
+        assert bool(r["valid"]) == ref["ok"] and np.array_equal(gp["mask"][k][:M], ref["mask"])
+        if ref["ok"]:
+            n = ref["n_points"]
+            assert np.array_equal(gp["point_idx"][k][:n], ref["point_idx"])
+            assert gp["points"][k][:n].tobytes() == ref["points"].tobytes()
+    n_ok = 0
+    for q, ref in enumerate(tracks):
+        t = gt["tracks"][q]
+        nc = len(ref["X"])
+        assert t["n_corr"] == nc                                       # the join: same correspondences, same order
+        assert gt["corr_xyz"][q][:nc].tobytes() == ref["X"].tobytes()
+        assert gt["corr_uv"][q][:nc].tobytes() == ref["uv"].tobytes()
+        assert bool(t["ok"]) == ref["ok"] and t["best_hyp"] == ref["best_hyp"]
+        if ref["ok"]:
+            n_ok += 1
+            ni = len(ref["inliers"])
+            assert t["n_inliers"] == ni and np.array_equal(gt["inlier_idx"][q][:ni], ref["inliers"])   # bit-exact
+            assert helpers.rel_err(t["R"], ref["R"]) <= 1e-4 and helpers.rel_err(t["t"], ref["t"]) <= 1e-4
+            assert t["R"].tobytes() == ref["R"].tobytes() and t["t"].tobytes() == ref["t"].tobytes()
+    assert n_ok >= F - 3                                                # the tracks actually solve
+
+
+@pytest.mark.gpu
+def test_gpu_sequence_recovers_motion(ctx):
+    """Ground truth: the PnP pose of frame q+2 in frame q's camera frame matches the synthetic trajectory up to the
+    unknown two-view scale (|t| of pair q is normalised to 1)."""
+    from mvslam_amd import capi
+
+    F, N = 5, 800
+    seq = synth.make_sequence(F, n_kp=N, n_map=8000, noise_px=0.1, step=0.15)
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    s.run(capi.default_params(num_hypotheses=4096, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=2e-3),
+          capi.default_pnp_params(num_hypotheses=512, seed=2, reproj_error=1.0))
+    gp, gt = s.download_pairs(), s.download_tracks()
+    s.close()
+    for q in range(F - 2):
+        t = gt["tracks"][q]
+        assert t["ok"] and t["n_inliers"] >= 30
+        (R0, t0), (R1, t1), (R2, t2) = seq["poses"][q], seq["poses"][q + 1], seq["poses"][q + 2]
+        scale = np.linalg.norm(R1 @ (-R0.T @ t0) + t1)                  # true baseline of pair q
+        Rrel = R0 @ R2.T                                                 # frame q+2 camera in frame q coordinates
+        crel = R0 @ (-R2.T @ t2) + t0
+        assert np.abs(t["R"] - Rrel).max() < 0.02
+        assert np.abs(t["t"] * scale - crel).max() < 0.05 * max(1.0, np.linalg.norm(crel))
