@@ -11,14 +11,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvslam_amd import capi, synth  # noqa: E402
 
-NAMES = {0: "round-1 first version", 88: "ldspts+inplace+maskfma", 120: "88+unscaled sqrt/div (default)"}
+NAMES = {0: "round-1 first version", 120: "LDS point stream + in-place rotation + mask-fma + unscaled sqrt/div (default)"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=128)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--hyp", type=int, default=50000)
 ap.add_argument("--kp", type=int, default=2000)
-ap.add_argument("--variants", default="0,88,120")
+ap.add_argument("--variants", default="0,120")
 args = ap.parse_args()
 variants = [int(v) for v in args.variants.split(",")]
 
@@ -44,3 +44,5 @@ for v in variants:
     a = np.array(t[v])
     print("variant %d %-18s ransac ms/launch: median %.3f  min %.3f  (%d pairs -> %.1f us/pair)"
           % (v, NAMES.get(v, "?"), np.median(a), a.min(), args.pairs, np.median(a) * 1e3 / args.pairs))
+b.close()
+ctx.close()

@@ -13,6 +13,7 @@ ap.add_argument("--kp", type=int, default=2000)
 ap.add_argument("--hyp", type=int, default=50000)
 ap.add_argument("--pnp-hyp", type=int, default=100)      # the reference's iterationsCount (pnp-solve.cpp:47)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the same sequence timed through the CPU oracle (0 = skip)")
 args = ap.parse_args()
 
 t0 = time.time()
@@ -27,6 +28,32 @@ ms = s.time(prm, pprm, steps=args.steps, warmup=1) / args.steps
 s.run(prm, pprm)
 gp, gt = s.download_pairs(), s.download_tracks()
 res, tr = gp["results"], gt["tracks"]
+s.close()      # release the device objects explicitly, before any host threads / interpreter teardown
+ctx.close()
+cpu = None
+if args.cpu_frames >= 3:
+    # the CPU oracle on the first frames of the same sequence, one frame-step per host thread (test infrastructure
+    # used as the timed baseline only, like bench.py's cpu_baseline leg)
+    import threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_lib as o
+    from test_sequence import oracle_sequence
+    nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+    chunk = max(3, args.cpu_frames // nthr + 2)   # frames per thread: chunk - 1 pairs and chunk - 2 tracks
+
+    def work(k0):
+        sub = dict(desc=seq["desc"][k0:k0 + chunk], kp=seq["kp"][k0:k0 + chunk], n_kp=seq["n_kp"][k0:k0 + chunk], K=seq["K"])
+        oracle_sequence(sub, dict(H=args.hyp, seed=synth.SEED_BASE + k0, thr=1e-2), dict(H=args.pnp_hyp, seed=7, err=2.0))
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(i * chunk,)) for i in range(nthr) if (i + 1) * chunk <= args.frames]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    steps_done = len(ths) * (chunk - 1)           # one frame step = one pair (+ its track)
+    cpu = {"value": round(steps_done / dt, 2), "unit": "frames/s", "cores": len(ths), "kind": "port",
+           "sample": "%d threads x %d consecutive frames of the same sequence (%d frame steps, full hypothesis counts)"
+                     % (len(ths), chunk, steps_done)}
 print(json.dumps({
     "metric": "frames/sec, 1000-frame synthetic sequence (match + two-view + PnP + triangulate per frame, no BA)",
     "value": round(args.frames / (ms * 1e-3), 1), "unit": "frames/s", "ms_per_sequence": round(ms, 2),
@@ -34,4 +61,4 @@ print(json.dumps({
     "valid_pairs": int(res["valid"].sum()), "avg_matches": round(float(res["n_matches"].mean()), 1),
     "avg_points": round(float(res["n_points"].mean()), 1), "tracks_ok": int(tr["ok"].sum()),
     "avg_corr": round(float(tr["n_corr"].mean()), 1), "avg_pnp_inliers": round(float(tr["n_inliers"].mean()), 1),
-    "data_generation_s": round(gen_s, 1)}))
+    "data_generation_s": round(gen_s, 1), "cpu_baseline": cpu}))

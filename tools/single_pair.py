@@ -12,3 +12,4 @@ for n in (1, 2, 8):
     tot, k = b.time(prm, steps=20, warmup=3)
     print("pairs=%d  total %.3f ms/step  kernels(ms/step): %s" % (n, tot / 20, {a: round(v / 20, 4) for a, v in k.items()}))
     b.close()
+ctx.close()
