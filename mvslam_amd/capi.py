@@ -6,6 +6,7 @@ calls raise.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -145,12 +146,15 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
+        self._children = weakref.WeakSet()  # batches / sequences must be destroyed before their context
         st = lib().mvs_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h))
         if st != MVS_OK:
             raise MvsError(st, "mvs_ctx_create")
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
             lib().mvs_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -295,10 +299,12 @@ class Batch:
         self._h = C.c_void_p()
         st = lib().mvs_batch_create(ctx._h, C.c_int(n_pairs), C.c_int(max_kp), C.c_int(desc_bytes), C.byref(self._h))
         ctx._check(st, "mvs_batch_create")
+        ctx._children.add(self)
 
     def close(self):
         if self._h:
-            lib().mvs_batch_destroy(self._h)
+            if self.ctx._h:  # never touch a batch whose context is already gone
+                lib().mvs_batch_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -385,10 +391,12 @@ class Sequence:
         self._h = C.c_void_p()
         ctx._check(lib().mvs_seq_create(ctx._h, C.c_int(n_frames), C.c_int(max_kp), C.c_int(desc_bytes),
                                         C.byref(self._h)), "mvs_seq_create")
+        ctx._children.add(self)
 
     def close(self):
         if self._h:
-            lib().mvs_seq_destroy(self._h)
+            if self.ctx._h:
+                lib().mvs_seq_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -73,6 +73,17 @@ def main():
                         L_t=rl["t"], L_points=rl["points"], L_F=rl["F"], cube_uv1=cube["uv1"], cube_uv2=cube["uv2"],
                         cube_X=cube["X"], cube_R12=cube["T1to2"][0], cube_t12=cube["T1to2"][1], cube_points=tp,
                         cube_idx=ti)
+    # ---- pnp_solve (row f1): the reference's cube rig + a noisy scene with outliers
+    import test_pnp as TP
+
+    Kc, Xc, uvc = TP._cube_rig()
+    rc = o.pnp_solve(Xc, uvc, Kc, o.make_pnp_params(100, o.SAMPLER_PHILOX, 0))
+    Ks, Xs, uvs, Rs, ts, bad = TP._scene(77, 200, 0.01, 40)
+    rs = o.pnp_solve(Xs, uvs, Ks, o.make_pnp_params(256, o.SAMPLER_PHILOX, 5))
+    np.savez_compressed(os.path.join(HERE, "pnp_small.npz"), cube_X=Xc, cube_uv=uvc, cube_R=rc["R"], cube_t=rc["t"],
+                        cube_inliers=rc["inliers"], K=Ks, X=Xs, uv=uvs, H=256, seed=np.uint64(5), R=rs["R"], t=rs["t"],
+                        inliers=rs["inliers"], best_hyp=rs["best_hyp"],
+                        samples=np.stack([o.sample4(5, h, 200) for h in range(256)]))
     print("golden vectors written to", HERE)
 
 

@@ -392,3 +392,38 @@ def test_batch_capacity_errors(ctx):
         capi.Batch(ctx, 1, 4097, 32)          # beyond the LDS-resident capacity
     with pytest.raises(capi.MvsError):
         capi.Batch(ctx, 1, 100, 24)           # descriptor size not 16 / 32 / 64 bytes
+
+
+# ----------------------------------------------------------------------------- golden vectors (oracle-free)
+def test_gpu_against_golden_vectors(ctx):
+    """The committed expected outputs of tests/golden/ (match list, RANSAC tables, full image pairs) without the oracle."""
+    import os
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "match_small.npz"))
+    for tag in "abc":
+        ratio, md = g["params_" + tag]
+        assert ctx.match_hamming(g["train"], g["query"], float(ratio), float(md)).tobytes() == g["matches_" + tag].tobytes()
+    g = np.load(os.path.join(gold, "ransac_small.npz"))
+    r = ctx.ransac_fundamental(g["p1"], g["p2"], float(g["thr"]), int(g["H"]), capi.SAMPLER_PHILOX, int(g["seed"]), True)
+    assert np.array_equal(r["count"], g["count"]) and r["residual"].tobytes() == g["residual"].tobytes()
+    assert r["F"].tobytes() == g["F"].tobytes() and np.array_equal(r["mask"], g["mask"])
+    assert [r["best_hyp"], r["best_count"]] == g["best"].tolist()
+    g = np.load(os.path.join(gold, "image_pair_small.npz"))
+    n_kp = g["desc1"].shape[1]
+    b = capi.Batch(ctx, 2, n_kp, 32)
+    ones = np.full(2, n_kp, dtype=np.int32)
+    b.upload(0, g["desc1"], g["kp1"], ones, g["desc2"], g["kp2"], ones, g["K"], g["global_index"])
+    b.run(capi.default_params(num_hypotheses=int(g["H"]), sampler=capi.SAMPLER_PHILOX, seed=int(g["seed"]),
+                              max_error_sq=float(g["max_error_sq"])))
+    out = b.download()
+    b.close()
+    for i in range(2):
+        ok, M, ninl, npts, bh, bc = g["scalars_%d" % i].tolist()
+        r = out["results"][i]
+        assert [int(r["valid"]), r["n_matches"], r["n_inliers"], r["n_points"], r["best_hyp"], r["best_count"]] == [ok, M, ninl, npts, bh, bc]
+        assert out["matches"][i][:M].tobytes() == g["matches_%d" % i].tobytes()
+        assert np.array_equal(out["mask"][i][:M], g["mask_%d" % i])
+        assert np.array_equal(out["point_idx"][i][:npts], g["point_idx_%d" % i])
+        assert out["points"][i][:npts].tobytes() == g["points_%d" % i].tobytes()
+        assert r["R"].tobytes() == g["R_%d" % i].tobytes() and r["t"].tobytes() == g["t_%d" % i].tobytes()

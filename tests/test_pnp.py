@@ -75,7 +75,32 @@ def test_oracle_pnp_preconditions_and_sampler():
     assert o.sample4(1, 0, 9, o.SAMPLER_IDENTITY).tolist() == [0, 1, 2, 3]
 
 
+def test_golden_pnp():
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pnp_small.npz"))
+    rc = o.pnp_solve(g["cube_X"], g["cube_uv"], np.eye(3), o.make_pnp_params(100, o.SAMPLER_PHILOX, 0))
+    assert rc["R"].tobytes() == g["cube_R"].tobytes() and rc["t"].tobytes() == g["cube_t"].tobytes()
+    rs = o.pnp_solve(g["X"], g["uv"], g["K"], o.make_pnp_params(int(g["H"]), o.SAMPLER_PHILOX, int(g["seed"])))
+    assert rs["best_hyp"] == int(g["best_hyp"]) and np.array_equal(rs["inliers"], g["inliers"])
+    assert rs["R"].tobytes() == g["R"].tobytes() and rs["t"].tobytes() == g["t"].tobytes()
+    for h in (0, 100, 255):
+        assert o.sample4(int(g["seed"]), h, len(g["X"])).tolist() == g["samples"][h].tolist()
+
+
 # ------------------------------------------------------------------------------------------- GPU parity
+@pytest.mark.gpu
+def test_gpu_pnp_against_golden(ctx):
+    """Oracle-free: the committed expected outputs (tests/golden/pnp_small.npz)."""
+    import os
+    from mvslam_amd import capi
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pnp_small.npz"))
+    got = ctx.pnp_solve(g["X"], g["uv"], g["K"], capi.default_pnp_params(num_hypotheses=int(g["H"]), seed=int(g["seed"])))
+    assert got["ok"] and got["best_hyp"] == int(g["best_hyp"]) and np.array_equal(got["inliers"], g["inliers"])
+    assert got["R"].tobytes() == g["R"].tobytes() and got["t"].tobytes() == g["t"].tobytes()
+
+
 @pytest.mark.gpu
 def test_gpu_pnp_solve_cube(ctx):
     from mvslam_amd import capi
