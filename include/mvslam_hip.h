@@ -246,6 +246,57 @@ mvs_status mvs_seq_download_pairs(mvs_seq *s, int first, int count, mvs_pair_res
 mvs_status mvs_seq_download_tracks(mvs_seq *s, int first, int count, mvs_track_result *tracks, double *corr_xyz,
                                    double *corr_uv, int64_t *inlier_idx);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row f4: refinement.  Replaces sfm_refine (vision/sfm.hpp:56-76, sfm-refine.cpp:20-139) and
+ * pnp_refine (vision/pnp.hpp:28-46, pnp-refine.cpp:14-108), i.e. the two callers of ba_frame_pose_and_point
+ * (vision/ba.cpp:26-156, GTSAM LevenbergMarquardtOptimizer + Marginals).  The library minimises the same cost
+ *   1/2 [ pose priors + point priors + reprojection residuals, each in its Mahalanobis norm ]
+ * with its own batched Schur-complement Levenberg-Marquardt kernel and returns the minimiser, the marginal covariances
+ * of the linearised problem (ba.cpp:127,141,152) and the final error (ba.cpp:155).  Pose tangent order is GTSAM's:
+ * (rotation, translation), right perturbation.  DESIGN.md section 4.7. */
+typedef struct mvs_refine_params {
+    int32_t max_iterations;  /* 100 = gtsam::LevenbergMarquardtParams default */
+    int32_t reserved;
+    double lambda_initial;   /* 1e-5 */
+    double lambda_factor;    /* 10 */
+    double lambda_upper;     /* 1e5 */
+    double rel_tol;          /* 1e-12: stop when the error decrease is below rel_tol * error ... */
+    double abs_tol;          /* 1e-12: ... or below abs_tol (GTSAM's defaults are 1e-5 / 1e-5) */
+    double anchor_sigma[2];  /* sfm-refine.cpp:11-14: prior on camera 1, diagonal entries {0-2, 3-5} = {1e-5, 1e-5} */
+    double pose_sigma[2];    /* sfm-refine.cpp:15-18, pnp-refine.cpp:9-12: regulator on the moving camera {1e-2, 1e-2} */
+    double point_sigma;      /* sfm-refine.cpp:86-94: regulator on every point, 1e-2 */
+} mvs_refine_params;
+void mvs_refine_params_default(mvs_refine_params *p);
+
+typedef struct mvs_refine_result {
+    int32_t ok;          /* 1: converged or stopped by the iteration / lambda limits with a finite error */
+    int32_t iterations;  /* linear solves performed */
+    double error;        /* 1/2 sum of squared Mahalanobis residuals at the estimate (optimizer.error()) */
+    double R[9];         /* the moving camera in the world frame (sfm: pose2in1) */
+    double t[3];
+    double pose_cov[36]; /* its marginal covariance, row-major 6 x 6, order (rotation, translation) */
+} mvs_refine_result;
+
+/* sfm_refine.  p1 / p2: m x 2 image points (host), cov1 / cov2: m x 4 (row-major 2 x 2 covariances) or NULL = identity,
+ * K affine, (R_guess, t_guess) = pose2in1 guess, points_guess m x 3 in camera 1.  points_out: m x 3, point_cov_out:
+ * m x 9 (may be NULL).  1 <= m <= 4096.  MVS_NO_MODEL if the problem could not be solved. */
+mvs_status mvs_sfm_refine(mvs_ctx *ctx, const double *p1, const double *cov1, const double *p2, const double *cov2, int m,
+                          const double K[9], const double R_guess[9], const double t_guess[3],
+                          const double *points_guess, const mvs_refine_params *params, mvs_refine_result *result,
+                          double *points_out, double *point_cov_out);
+/* pnp_refine.  world: m x 3 with covariances world_cov m x 9 (the point priors), image points m x 2 with covariances
+ * image_cov m x 4 or NULL = identity; (R_guess, t_guess) = camera in world. */
+mvs_status mvs_pnp_refine(mvs_ctx *ctx, const double *world, const double *world_cov, const double *image,
+                          const double *image_cov, int m, const double K[9], const double R_guess[9],
+                          const double t_guess[3], const mvs_refine_params *params, mvs_refine_result *result);
+/* Batched ImagePair::refine (front-end/image-pair.cpp:176-238) on a batch that has been run: every valid pair is refined
+ * from its own results on the device (observations = the matched keypoints, covariance (sigma_px)^2 I as
+ * VisualFeature::get_point_estimates gives an octave-0 ORB keypoint: sigma_px = 0.5, visual-feature.cpp:193-207).
+ * Asynchronous on the ctx stream; results stay resident until downloaded. */
+mvs_status mvs_batch_refine(mvs_batch *b, const mvs_refine_params *params, double sigma_px);
+/* refined[n_pairs]; points_xyz / point_cov: n_pairs x max_kp x 3 / 9 (NULL to skip), rows [0, results[p].n_points) */
+mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, double *points_xyz, double *point_cov);
+
 #ifdef __cplusplus
 }
 #endif

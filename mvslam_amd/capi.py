@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmvslam_hip.so")
 
 MVS_OK = 0
 MVS_NO_MODEL = 1
+MVS_ERR_INVALID_ARG, MVS_ERR_NO_DEVICE, MVS_ERR_HIP, MVS_ERR_CAPACITY, MVS_ERR_BAD_INTRINSICS = -1, -2, -3, -4, -5
 SAMPLER_IDENTITY = 0
 SAMPLER_PHILOX = 1
 
@@ -68,6 +69,17 @@ TRACK_DTYPE = np.dtype([("ok", "<i4"), ("n_corr", "<i4"), ("n_inliers", "<i4"), 
                         ("R", "<f8", (3, 3)), ("t", "<f8", (3,))])
 
 
+class RefineParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("reserved", C.c_int32), ("lambda_initial", C.c_double),
+                ("lambda_factor", C.c_double), ("lambda_upper", C.c_double), ("rel_tol", C.c_double),
+                ("abs_tol", C.c_double), ("anchor_sigma", C.c_double * 2), ("pose_sigma", C.c_double * 2),
+                ("point_sigma", C.c_double)]
+
+
+REFINE_DTYPE = np.dtype([("ok", "<i4"), ("iterations", "<i4"), ("error", "<f8"), ("R", "<f8", (3, 3)),
+                         ("t", "<f8", (3,)), ("pose_cov", "<f8", (6, 6))])
+
+
 class WorkStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers")]
 
@@ -80,6 +92,7 @@ EXPORTS = [
     "mvs_batch_time", "mvs_batch_download", "mvs_batch_stats", "mvs_batch_results_device",
     "mvs_batch_copy_results_device", "mvs_pnp_params_default", "mvs_pnp_solve", "mvs_seq_create", "mvs_seq_destroy",
     "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
+    "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
 ]
 
 
@@ -129,6 +142,17 @@ def default_pnp_params(**kw):
     lib().mvs_pnp_params_default(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
+    return p
+
+
+def default_refine_params(**kw):
+    p = RefineParams()
+    lib().mvs_refine_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k in ("anchor_sigma", "pose_sigma"):
+            getattr(p, k)[0], getattr(p, k)[1] = float(v[0]), float(v[1])
+        else:
+            setattr(p, k, v)
     return p
 
 
@@ -263,6 +287,43 @@ class Context:
         self._check(st, "mvs_pnp_solve", allow_no_model=True)
         return dict(ok=st == MVS_OK, R=R, t=t, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
 
+    # sfm_refine(p1_estimates, p2_estimates, K, pose2in1_guess, pointsin1_guess, pose2in1_estimate, pointsin1_estimate, error)
+    def sfm_refine(self, p1, cov1, p2, cov2, K, R_guess, t_guess, points_guess, params=None, point_cov=True):
+        p1, p2, pg = _f64(p1).reshape(-1, 2), _f64(p2).reshape(-1, 2), _f64(points_guess).reshape(-1, 3)
+        m = len(p1)
+        params = params or default_refine_params()
+        c1 = None if cov1 is None else _f64(cov1, (m, 4))
+        c2 = None if cov2 is None else _f64(cov2, (m, 4))
+        res = np.zeros(1, dtype=REFINE_DTYPE)
+        pts = np.zeros((m, 3))
+        ptc = np.zeros((m, 3, 3)) if point_cov else None
+        st = lib().mvs_sfm_refine(self._h, _ptr(p1, C.c_double), _ptr(c1, C.c_double), _ptr(p2, C.c_double),
+                                  _ptr(c2, C.c_double), C.c_int(m), _ptr(_f64(K, (9,)), C.c_double),
+                                  _ptr(_f64(R_guess, (9,)), C.c_double), _ptr(_f64(t_guess, (3,)), C.c_double),
+                                  _ptr(pg, C.c_double), C.byref(params), res.ctypes.data_as(C.c_void_p),
+                                  _ptr(pts, C.c_double), _ptr(ptc, C.c_double))
+        self._check(st, "mvs_sfm_refine", allow_no_model=True)
+        r = res[0]
+        return dict(ok=st == MVS_OK, R=r["R"].copy(), t=r["t"].copy(), pose_cov=r["pose_cov"].copy(), points=pts,
+                    point_cov=ptc, error=float(r["error"]), iterations=int(r["iterations"]))
+
+    # pnp_refine(world_point_estimates, image_point_estimates, K, pose_guess, pose_estimate, error)
+    def pnp_refine(self, world, world_cov, image, image_cov, K, R_guess, t_guess, params=None):
+        X, uv = _f64(world).reshape(-1, 3), _f64(image).reshape(-1, 2)
+        m = len(X)
+        params = params or default_refine_params()
+        wc = _f64(world_cov, (m, 9))
+        ic = None if image_cov is None else _f64(image_cov, (m, 4))
+        res = np.zeros(1, dtype=REFINE_DTYPE)
+        st = lib().mvs_pnp_refine(self._h, _ptr(X, C.c_double), _ptr(wc, C.c_double), _ptr(uv, C.c_double),
+                                  _ptr(ic, C.c_double), C.c_int(m), _ptr(_f64(K, (9,)), C.c_double),
+                                  _ptr(_f64(R_guess, (9,)), C.c_double), _ptr(_f64(t_guess, (3,)), C.c_double),
+                                  C.byref(params), res.ctypes.data_as(C.c_void_p))
+        self._check(st, "mvs_pnp_refine", allow_no_model=True)
+        r = res[0]
+        return dict(ok=st == MVS_OK, R=r["R"].copy(), t=r["t"].copy(), pose_cov=r["pose_cov"].copy(),
+                    error=float(r["error"]), iterations=int(r["iterations"]))
+
     def find_fundamental_matrix(self, p1, p2):
         p1, p2 = _f64(p1, (16,)), _f64(p2, (16,))
         F = np.zeros((3, 3))
@@ -368,6 +429,21 @@ class Batch:
                                       _ptr(pts, C.c_double), _ptr(idx, C.c_int64))
         self.ctx._check(st, "mvs_batch_download")
         return dict(results=res, matches=mt, mask=mk, points=pts, point_idx=idx)
+
+    def refine(self, params=None, sigma_px=0.5):
+        """ImagePair::refine of every valid pair, on the device, from the batch's own results (asynchronous)"""
+        params = params or default_refine_params()
+        self.ctx._check(lib().mvs_batch_refine(self._h, C.byref(params), C.c_double(sigma_px)), "mvs_batch_refine")
+
+    def download_refined(self, points=True, point_cov=False):
+        P, N = self.n_pairs, self.max_kp
+        res = np.zeros(P, dtype=REFINE_DTYPE)
+        pts = np.zeros((P, N, 3)) if points else None
+        pc = np.zeros((P, N, 3, 3)) if point_cov else None
+        st = lib().mvs_batch_download_refined(self._h, res.ctypes.data_as(C.c_void_p), _ptr(pts, C.c_double),
+                                              _ptr(pc, C.c_double))
+        self.ctx._check(st, "mvs_batch_download_refined")
+        return dict(refined=res, points=pts, point_cov=pc)
 
     def copy_results_device(self, dst_ptr, first=0, count=None):
         """async D2D copy of the fixed-size result records into caller-owned device memory (e.g. a torch tensor)"""

@@ -23,6 +23,8 @@ struct mvs_ctx {
     double *d_small = nullptr;  // 64 doubles of staging (fundamental_kernel)
     void *d_pnp = nullptr;      // pnp_solve workspace
     size_t pnp_bytes = 0;
+    void *d_ref = nullptr;      // sfm_refine / pnp_refine workspace
+    size_t ref_bytes = 0;
 };
 
 struct mvs_seq;
@@ -35,6 +37,8 @@ struct mvs_batch {
     int32_t *allocs_hc = nullptr;
     double *allocs_hr = nullptr;
     hipEvent_t ev[8]{};
+    RefineDev refine{};     // allocated by the first mvs_batch_refine
+    bool refine_ready = false, refine_ran = false;
 };
 
 struct mvs_seq {
@@ -237,6 +241,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_uv2) (void)hipFree(ctx->d_uv2);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
+    if (ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1317,6 +1322,245 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
         for (int i = 0; i < out.n_inliers; ++i)
             inlier_idx[i] = tmp[i];
     }
+    return MVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement (row f4)
+void mvs_refine_params_default(mvs_refine_params *p)
+{
+    if (!p)
+        return;
+    p->max_iterations = 100;
+    p->reserved = 0;
+    p->lambda_initial = 1e-5;
+    p->lambda_factor = 10.0;
+    p->lambda_upper = 1e5;
+    p->rel_tol = 1e-12;
+    p->abs_tol = 1e-12;
+    p->anchor_sigma[0] = p->anchor_sigma[1] = 1e-5;
+    p->pose_sigma[0] = p->pose_sigma[1] = 1e-2;
+    p->point_sigma = 1e-2;
+}
+
+static bool refine_params_ok(const mvs_refine_params *p)
+{
+    return p && p->max_iterations >= 0 && p->lambda_initial >= 0.0 && p->lambda_factor > 1.0 &&
+           p->lambda_upper > 0.0 && p->anchor_sigma[0] > 0.0 && p->anchor_sigma[1] > 0.0 && p->pose_sigma[0] > 0.0 &&
+           p->pose_sigma[1] > 0.0 && p->point_sigma > 0.0;
+}
+
+static RefineCfg to_cfg(const mvs_refine_params &p, int n_frames)
+{
+    RefineCfg c{};
+    c.max_iterations = p.max_iterations;
+    c.lambda_initial = p.lambda_initial;
+    c.lambda_factor = p.lambda_factor;
+    c.lambda_upper = p.lambda_upper;
+    c.rel_tol = p.rel_tol;
+    c.abs_tol = p.abs_tol;
+    // the reference fills diagonal entries 0-2 with its "position" and 3-5 with its "orientation" sigma
+    // (sfm-refine.cpp:62-66); GTSAM reads the first three as rotation.  Kept as is: entry k gets sigma[k / 3].
+    for (int k = 0; k < 6; ++k) {
+        const double a = p.anchor_sigma[k / 3], m = p.pose_sigma[k / 3];
+        if (n_frames == 2) {
+            c.w[0][k] = 1.0 / (a * a);
+            c.w[1][k] = 1.0 / (m * m);
+        } else {
+            c.w[0][k] = 1.0 / (m * m);
+            c.w[1][k] = 0.0;
+        }
+    }
+    return c;
+}
+
+// one problem through the ctx workspace.  frames: 2 = sfm_refine (obs_a = camera 1, obs_b = camera 2), 1 = pnp_refine
+static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, const double *cov_a, const double *obs_b,
+                                const double *cov_b, const double *pts0, const double *cov3, int m, const double K[9],
+                                const double R_guess[9], const double t_guess[3], const mvs_refine_params *params,
+                                mvs_refine_result *result, double *points_out, double *point_cov_out)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t M = (size_t)m;
+    // doubles: obs0 2 obs1 2 oinfo0 3 oinfo1 3 pts0 3 pinfo 6 pts 3 tmp 3 pcov 9 cov2a 4 cov2b 4 cov3 9 = 51 per point
+    const size_t nd = M * 51 + 9 + 12;
+    const size_t off_out = (nd * sizeof(double) + 63) & ~size_t(63);
+    const size_t off_m = (off_out + sizeof(mvs_refine_result) + 63) & ~size_t(63);
+    const size_t total = off_m + 64;
+    if (ctx->ref_bytes < total) {
+        if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+        ctx->d_ref = nullptr;
+        ctx->ref_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_ref, total));
+        ctx->ref_bytes = total;
+    }
+    char *base = static_cast<char *>(ctx->d_ref);
+    double *w = reinterpret_cast<double *>(base);
+    double *obs0 = w, *obs1 = obs0 + 2 * M, *oinfo0 = obs1 + 2 * M, *oinfo1 = oinfo0 + 3 * M, *dp0 = oinfo1 + 3 * M;
+    double *pinfo = dp0 + 3 * M, *dpts = pinfo + 6 * M, *dtmp = dpts + 3 * M, *dpcov = dtmp + 3 * M;
+    double *c2a = dpcov + 9 * M, *c2b = c2a + 4 * M, *c3 = c2b + 4 * M, *dK = c3 + 9 * M, *dpose = dK + 9;
+    int32_t *dm = reinterpret_cast<int32_t *>(base + off_m);
+    hipStream_t s = ctx->stream;
+    const int32_t m32 = m;
+    double pose[12];
+    std::memcpy(pose, R_guess, 9 * sizeof(double));
+    std::memcpy(pose + 9, t_guess, 3 * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(obs0, obs_a, M * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (frames == 2)
+        HIP_TRY(ctx, hipMemcpyAsync(obs1, obs_b, M * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (cov_a)
+        HIP_TRY(ctx, hipMemcpyAsync(c2a, cov_a, M * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (frames == 2 && cov_b)
+        HIP_TRY(ctx, hipMemcpyAsync(c2b, cov_b, M * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (cov3)
+        HIP_TRY(ctx, hipMemcpyAsync(c3, cov3, M * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dp0, pts0, M * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dpose, pose, sizeof(pose), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dm, &m32, sizeof(m32), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));  // the staging buffers above live on this frame
+    RefineDev d{};
+    d.n_problems = 1;
+    d.stride = m;
+    d.n_frames = frames;
+    d.cfg = to_cfg(*params, frames);
+    d.m = dm;
+    d.K = dK;
+    d.pose0 = dpose;
+    d.obs[0] = obs0;
+    d.obs[1] = obs1;
+    d.oinfo[0] = oinfo0;
+    d.oinfo[1] = oinfo1;
+    d.pts0 = dp0;
+    d.pinfo = pinfo;
+    d.pts = dpts;
+    d.pts_tmp = dtmp;
+    d.point_cov = point_cov_out ? dpcov : nullptr;
+    d.out = reinterpret_cast<mvs_refine_result *>(base + off_out);
+    launch_refine_prep(d, cov_a ? c2a : nullptr, (frames == 2 && cov_b) ? c2b : nullptr, cov3 ? c3 : nullptr,
+                       1.0 / (params->point_sigma * params->point_sigma), oinfo0, oinfo1, pinfo, s);
+    launch_refine(d, s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(result, d.out, sizeof(*result), hipMemcpyDeviceToHost, s));
+    if (points_out)
+        HIP_TRY(ctx, hipMemcpyAsync(points_out, dpts, M * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (point_cov_out)
+        HIP_TRY(ctx, hipMemcpyAsync(point_cov_out, dpcov, M * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return result->ok ? MVS_OK : MVS_NO_MODEL;
+}
+
+mvs_status mvs_sfm_refine(mvs_ctx *ctx, const double *p1, const double *cov1, const double *p2, const double *cov2, int m,
+                          const double K[9], const double R_guess[9], const double t_guess[3],
+                          const double *points_guess, const mvs_refine_params *params, mvs_refine_result *result,
+                          double *points_out, double *point_cov_out)
+{
+    if (!ctx || !p1 || !p2 || !K || !R_guess || !t_guess || !points_guess || !result || !refine_params_ok(params))
+        return MVS_ERR_INVALID_ARG;
+    std::memset(result, 0, sizeof(*result));
+    if (m < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (m > kMaxKp)
+        return MVS_ERR_CAPACITY;
+    if (!affine_K(K))
+        return MVS_ERR_BAD_INTRINSICS;
+    return refine_single(ctx, 2, p1, cov1, p2, cov2, points_guess, nullptr, m, K, R_guess, t_guess, params, result,
+                         points_out, point_cov_out);
+}
+
+mvs_status mvs_pnp_refine(mvs_ctx *ctx, const double *world, const double *world_cov, const double *image,
+                          const double *image_cov, int m, const double K[9], const double R_guess[9],
+                          const double t_guess[3], const mvs_refine_params *params, mvs_refine_result *result)
+{
+    if (!ctx || !world || !world_cov || !image || !K || !R_guess || !t_guess || !result || !refine_params_ok(params))
+        return MVS_ERR_INVALID_ARG;
+    std::memset(result, 0, sizeof(*result));
+    if (m < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (m > kMaxKp)
+        return MVS_ERR_CAPACITY;
+    if (!affine_K(K))
+        return MVS_ERR_BAD_INTRINSICS;
+    return refine_single(ctx, 1, image, image_cov, nullptr, nullptr, world, world_cov, m, K, R_guess, t_guess, params,
+                         result, nullptr, nullptr);
+}
+
+mvs_status mvs_batch_refine(mvs_batch *b, const mvs_refine_params *params, double sigma_px)
+{
+    if (!b || !refine_params_ok(params) || !(sigma_px > 0.0))
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BatchDev &bd = b->d;
+    const size_t P = bd.n_pairs, N = bd.max_kp;
+    RefineDev &d = b->refine;
+    if (!b->refine_ready) {
+        auto grab = [&](size_t bytes, void **out) -> hipError_t {
+            hipError_t e = hipMalloc(out, bytes);
+            if (e == hipSuccess)
+                b->allocs.push_back(*out);
+            return e;
+        };
+        double *obs0, *obs1, *oi0, *oi1, *p0, *pi, *pts, *tmp, *pc, *pose;
+        int32_t *m;
+        mvs_refine_result *out;
+        HIP_TRY(ctx, grab(P * N * 2 * sizeof(double), (void **)&obs0));
+        HIP_TRY(ctx, grab(P * N * 2 * sizeof(double), (void **)&obs1));
+        HIP_TRY(ctx, grab(P * N * 3 * sizeof(double), (void **)&oi0));
+        HIP_TRY(ctx, grab(P * N * 3 * sizeof(double), (void **)&oi1));
+        HIP_TRY(ctx, grab(P * N * 3 * sizeof(double), (void **)&p0));
+        HIP_TRY(ctx, grab(P * N * 6 * sizeof(double), (void **)&pi));
+        HIP_TRY(ctx, grab(P * N * 3 * sizeof(double), (void **)&pts));
+        HIP_TRY(ctx, grab(P * N * 3 * sizeof(double), (void **)&tmp));
+        HIP_TRY(ctx, grab(P * N * 9 * sizeof(double), (void **)&pc));
+        HIP_TRY(ctx, grab(P * 12 * sizeof(double), (void **)&pose));
+        HIP_TRY(ctx, grab(P * sizeof(int32_t), (void **)&m));
+        HIP_TRY(ctx, grab(P * sizeof(mvs_refine_result), (void **)&out));
+        d.n_problems = (int)P;
+        d.stride = (int)N;
+        d.n_frames = 2;
+        d.m = m;
+        d.K = bd.K;
+        d.pose0 = pose;
+        d.obs[0] = obs0;
+        d.obs[1] = obs1;
+        d.oinfo[0] = oi0;
+        d.oinfo[1] = oi1;
+        d.pts0 = p0;
+        d.pinfo = pi;
+        d.pts = pts;
+        d.pts_tmp = tmp;
+        d.point_cov = pc;
+        d.out = out;
+        b->refine_ready = true;
+    }
+    d.cfg = to_cfg(*params, 2);
+    hipStream_t s = ctx->stream;
+    launch_refine_gather(bd, (int)P, sigma_px, params->point_sigma, d.stride, const_cast<int32_t *>(d.m),
+                         const_cast<double *>(d.pose0), const_cast<double *>(d.obs[0]), const_cast<double *>(d.obs[1]),
+                         const_cast<double *>(d.oinfo[0]), const_cast<double *>(d.oinfo[1]),
+                         const_cast<double *>(d.pts0), const_cast<double *>(d.pinfo), s);
+    launch_refine(d, s);
+    HIP_TRY(ctx, hipGetLastError());
+    b->refine_ran = true;
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, double *points_xyz, double *point_cov)
+{
+    if (!b || !refined || !b->refine_ran)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const RefineDev &d = b->refine;
+    const size_t P = d.n_problems, N = d.stride;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(refined, d.out, P * sizeof(mvs_refine_result), hipMemcpyDeviceToHost, s));
+    if (points_xyz)
+        HIP_TRY(ctx, hipMemcpyAsync(points_xyz, d.pts, P * N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (point_cov)
+        HIP_TRY(ctx, hipMemcpyAsync(point_cov, d.point_cov, P * N * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     return MVS_OK;
 }
 

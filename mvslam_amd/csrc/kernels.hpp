@@ -153,6 +153,40 @@ struct SeqJoinDev {
 };
 void launch_seq_join(const SeqJoinDev &j, hipStream_t stream);
 
+// ---- sfm_refine / pnp_refine (row f4): batched Schur-complement Levenberg-Marquardt ---------------------------
+struct RefineCfg {
+    int max_iterations;
+    double lambda_initial, lambda_factor, lambda_upper, rel_tol, abs_tol;
+    double w[2][6];   // 1 / sigma^2 of the pose priors, frame 0 and 1
+};
+
+struct RefineDev {     // G problems; problem g owns slice [g * stride, g * stride + m[g])
+    int n_problems;
+    int stride;        // point capacity of one problem
+    int n_frames;      // 2: frame 0 = camera 1 anchored at the identity, frame 1 = camera 2.  1: the moving camera
+    RefineCfg cfg;
+    const int32_t *m;        // [G] points (< 1: not solved)
+    const double *K;         // [G][9]
+    const double *pose0;     // [G][12] guess of the moving camera: R (9), t (3), camera in world
+    const double *obs[2];    // [G][stride][2] image points seen by frame f
+    const double *oinfo[2];  // [G][stride][3] their information matrices (xx xy yy)
+    const double *pts0;      // [G][stride][3] point guesses = prior means
+    const double *pinfo;     // [G][stride][6] point prior information (xx xy xz yy yz zz)
+    double *pts;             // [G][stride][3] refined points (out)
+    double *pts_tmp;         // [G][stride][3] candidate buffer
+    double *point_cov;       // [G][stride][9] marginal covariances (out), may be null
+    mvs_refine_result *out;  // [G]
+};
+// covariance -> information on the device.  cov2_[f]: [G][stride][4] or null (identity); cov3: [G][stride][9] or null
+// (isotropic weight iso3).  Writes d.oinfo / d.pinfo (cast away const by the caller's own buffers).
+void launch_refine_prep(const RefineDev &d, const double *cov2_0, const double *cov2_1, const double *cov3, double iso3,
+                        double *oinfo0, double *oinfo1, double *pinfo, hipStream_t stream);
+void launch_refine(const RefineDev &d, hipStream_t stream);
+// batch glue: build the two-view refinement problems of every pair from the batch's own results
+void launch_refine_gather(const BatchDev &b, int n_active, double sigma_px, double point_sigma, int stride, int32_t *m,
+                          double *pose0, double *obs0, double *obs1, double *oinfo0, double *oinfo1, double *pts0,
+                          double *pinfo, hipStream_t stream);
+
 // launch wrappers (all asynchronous on `stream`)
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
 void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);

@@ -180,6 +180,34 @@ int orc_pnp_solve(const double *world_xyz, const double *image_uv, int n, const 
                   const orc_pnp_params *prm, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
                   double Rw2c[9], double tw2c[3], int *best_hyp);
 
+/* ---- vision/sfm-refine.cpp:20-139, vision/pnp-refine.cpp:14-108 -> vision/ba.cpp:26-156 (row f4 of SURVEY section 8)
+ * Restated in mvs_refine_oracle.c (see its header: the least-squares problem GTSAM is handed, solved by the build's own
+ * Schur-complement Levenberg-Marquardt; parity by tolerance). */
+typedef struct {
+    int32_t max_iterations;  /* 100 = gtsam::LevenbergMarquardtParams default (ba.cpp:125 uses the defaults) */
+    int32_t reserved;
+    double lambda_initial;   /* 1e-5, GTSAM default */
+    double lambda_factor;    /* 10 */
+    double lambda_upper;     /* 1e5 */
+    double rel_tol;          /* 1e-12 (GTSAM: 1e-5; tighter so that the result is the minimiser itself) */
+    double abs_tol;          /* 1e-12 (GTSAM: 1e-5) */
+    double anchor_sigma[2];  /* sfm-refine.cpp:11-14: camera-1 prior, {diag 0-2, diag 3-5} = {1e-5, 1e-5} */
+    double pose_sigma[2];    /* sfm-refine.cpp:15-18 / pnp-refine.cpp:9-12: moving-camera regulator {1e-2, 1e-2} */
+    double point_sigma;      /* sfm-refine.cpp:15-16,86-94: point regulator 1e-2 */
+} orc_refine_params;
+void orc_refine_params_default(orc_refine_params *p);
+/* p1/p2: m x 2 image points; cov1/cov2: m x 4 (2x2 row-major) or NULL = identity; points_guess: m x 3 in camera 1.
+ * outputs: pose2in1 (R, t), its 6x6 marginal covariance (tangent order rotation, translation), refined points m x 3,
+ * their 3x3 marginal covariances m x 9, error = optimizer.error().  returns 1 on success. */
+int orc_sfm_refine(const double *p1, const double *cov1, const double *p2, const double *cov2, int m, const double K[9],
+                   const double R_guess[9], const double t_guess[3], const double *points_guess,
+                   const orc_refine_params *prm, double R[9], double t[3], double pose_cov[36], double *points,
+                   double *point_cov, double *error, int *iterations);
+/* world: m x 3 with covariances m x 9 (the point priors, pnp-refine.cpp:60-64); pose = camera in world. */
+int orc_pnp_refine(const double *world, const double *world_cov, const double *img, const double *img_cov, int m,
+                   const double K[9], const double R_guess[9], const double t_guess[3], const orc_refine_params *prm,
+                   double R[9], double t[3], double pose_cov[36], double *error, int *iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,10 +58,10 @@ class Counters(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or (
-        os.path.exists(os.path.join(ORACLE_DIR, "mvs_oracle.c"))
-        and os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(ORACLE_DIR, "mvs_oracle.c"))
-    ):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("mvs_oracle.c", "mvs_refine_oracle.c", "mvs_oracle.h")]
+    stale = not os.path.exists(_LIB_PATH) or any(
+        os.path.exists(f) and os.path.getmtime(_LIB_PATH) < os.path.getmtime(f) for f in srcs)
+    if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return _LIB_PATH
 
@@ -396,3 +396,56 @@ def pnp_solve(world_xyz, image_uv, K, params):
     ok = lib().orc_pnp_solve(_p(X), _p(uv), C.c_int(n), _p(_f64(K, (3, 3))), C.byref(params), _p(R), _p(t),
                              _p(idx, C.c_int64), C.byref(ni), _p(Rw), _p(tw), C.byref(bh))
     return dict(ok=bool(ok), R=R, t=t, Rw2c=Rw, tw2c=tw, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
+
+
+# ---- sfm-refine / pnp-refine (row f4) ----------------------------------------------
+class RefineParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("reserved", C.c_int32), ("lambda_initial", C.c_double),
+                ("lambda_factor", C.c_double), ("lambda_upper", C.c_double), ("rel_tol", C.c_double),
+                ("abs_tol", C.c_double), ("anchor_sigma", C.c_double * 2), ("pose_sigma", C.c_double * 2),
+                ("point_sigma", C.c_double)]
+
+
+def make_refine_params(**kw):
+    p = RefineParams()
+    lib().orc_refine_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k in ("anchor_sigma", "pose_sigma"):
+            getattr(p, k)[0], getattr(p, k)[1] = float(v[0]), float(v[1])
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _opt(a, shape):
+    return (None, None) if a is None else (lambda x: (x, _p(x)))(_f64(a, shape))
+
+
+def sfm_refine(p1, cov1, p2, cov2, K, R_guess, t_guess, points_guess, params=None):
+    p1, p2, pg = _f64(p1).reshape(-1, 2), _f64(p2).reshape(-1, 2), _f64(points_guess).reshape(-1, 3)
+    m = len(p1)
+    params = params or make_refine_params()
+    c1, c1p = _opt(cov1, (m, 4))
+    c2, c2p = _opt(cov2, (m, 4))
+    R, t, pc = np.zeros((3, 3)), np.zeros(3), np.zeros((6, 6))
+    pts, ptc = np.zeros((m, 3)), np.zeros((m, 3, 3))
+    err, it = C.c_double(0), C.c_int(0)
+    lib().orc_sfm_refine.restype = C.c_int
+    ok = lib().orc_sfm_refine(_p(p1), c1p, _p(p2), c2p, C.c_int(m), _p(_f64(K, (3, 3))), _p(_f64(R_guess, (3, 3))),
+                              _p(_f64(t_guess, (3,))), _p(pg), C.byref(params), _p(R), _p(t), _p(pc), _p(pts), _p(ptc),
+                              C.byref(err), C.byref(it))
+    return dict(ok=bool(ok), R=R, t=t, pose_cov=pc, points=pts, point_cov=ptc, error=err.value, iterations=it.value)
+
+
+def pnp_refine(world, world_cov, img, img_cov, K, R_guess, t_guess, params=None):
+    X, uv = _f64(world).reshape(-1, 3), _f64(img).reshape(-1, 2)
+    m = len(X)
+    params = params or make_refine_params()
+    wc = _f64(world_cov, (m, 9))
+    ic, icp = _opt(img_cov, (m, 4))
+    R, t, pc = np.zeros((3, 3)), np.zeros(3), np.zeros((6, 6))
+    err, it = C.c_double(0), C.c_int(0)
+    lib().orc_pnp_refine.restype = C.c_int
+    ok = lib().orc_pnp_refine(_p(X), _p(wc), _p(uv), icp, C.c_int(m), _p(_f64(K, (3, 3))), _p(_f64(R_guess, (3, 3))),
+                              _p(_f64(t_guess, (3,))), C.byref(params), _p(R), _p(t), _p(pc), C.byref(err), C.byref(it))
+    return dict(ok=bool(ok), R=R, t=t, pose_cov=pc, error=err.value, iterations=it.value)
