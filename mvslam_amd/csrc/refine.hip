@@ -31,6 +31,14 @@ struct Cam {
     double fx, fy, sk, cx, cy;
 };
 
+// fused building blocks (one v_fma_f64 each); the oracle uses the same ones in the same places
+__device__ __forceinline__ double fd2(double a0, double b0, double a1, double b1) { return fma(a1, b1, a0 * b0); }
+__device__ __forceinline__ double fd3(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    return fma(a2, b2, fma(a1, b1, a0 * b0));
+}
+__device__ __forceinline__ double fx2(double a, double b, double c, double d) { return fma(a, b, -(c * d)); }  // a b - c d
+
 __device__ __forceinline__ void so3_exp(const double (&w)[3], double (&R)[9])
 {
     const double th2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
@@ -94,17 +102,17 @@ __device__ __forceinline__ void so3_jrinv(const double (&w)[6], double (&J)[9])
 
 __device__ __forceinline__ void sym3_inverse(const double (&a)[6], double (&o)[6])
 {
-    const double c00 = a[3] * a[5] - a[4] * a[4];
-    const double c01 = a[2] * a[4] - a[1] * a[5];
-    const double c02 = a[1] * a[4] - a[2] * a[3];
-    const double det = (a[0] * c00 + a[1] * c01) + a[2] * c02;
+    const double c00 = fx2(a[3], a[5], a[4], a[4]);
+    const double c01 = fx2(a[2], a[4], a[1], a[5]);
+    const double c02 = fx2(a[1], a[4], a[2], a[3]);
+    const double det = fd3(a[0], c00, a[1], c01, a[2], c02);
     const double id = 1.0 / det;
     o[0] = c00 * id;
     o[1] = c01 * id;
     o[2] = c02 * id;
-    o[3] = (a[0] * a[5] - a[2] * a[2]) * id;
-    o[4] = (a[1] * a[2] - a[0] * a[4]) * id;
-    o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+    o[3] = fx2(a[0], a[5], a[2], a[2]) * id;
+    o[4] = fx2(a[1], a[2], a[0], a[4]) * id;
+    o[5] = fx2(a[0], a[3], a[1], a[1]) * id;
 }
 
 // pose prior of one frame: error e = (Log(R0^T R), R0^T (t - t0)); Jw = Jr^-1(e_w), Jv = R0^T R
@@ -138,9 +146,9 @@ __device__ __forceinline__ void project_lin(const Cam &cam, const double (&R)[9]
                                             double (&Jp)[6])
 {
     const double d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
-    const double q0 = (R[0] * d0 + R[3] * d1) + R[6] * d2;
-    const double q1 = (R[1] * d0 + R[4] * d1) + R[7] * d2;
-    const double q2 = (R[2] * d0 + R[5] * d1) + R[8] * d2;
+    const double q0 = fd3(R[0], d0, R[3], d1, R[6], d2);
+    const double q1 = fd3(R[1], d0, R[4], d1, R[7], d2);
+    const double q2 = fd3(R[2], d0, R[5], d1, R[8], d2);
     if (!(q2 > 0.0)) {
         r[0] = 2.0 * cam.fx;
         r[1] = 2.0 * cam.fx;
@@ -155,7 +163,7 @@ __device__ __forceinline__ void project_lin(const Cam &cam, const double (&R)[9]
         return;
     }
     const double iz = 1.0 / q2, xn = q0 * iz, yn = q1 * iz;
-    const double un = cam.fx * xn + cam.sk * yn, vn = cam.fy * yn;
+    const double un = fd2(cam.fx, xn, cam.sk, yn), vn = cam.fy * yn;
     r[0] = (un + cam.cx) - u;
     r[1] = (vn + cam.cy) - v;
     if (JAC) {
@@ -163,15 +171,15 @@ __device__ __forceinline__ void project_lin(const Cam &cam, const double (&R)[9]
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const double a0 = A[3 * a], a1 = A[3 * a + 1], a2 = A[3 * a + 2];
-            Jc[6 * a + 0] = a1 * q2 - a2 * q1;
-            Jc[6 * a + 1] = a2 * q0 - a0 * q2;
-            Jc[6 * a + 2] = a0 * q1 - a1 * q0;
+            Jc[6 * a + 0] = fx2(a1, q2, a2, q1);
+            Jc[6 * a + 1] = fx2(a2, q0, a0, q2);
+            Jc[6 * a + 2] = fx2(a0, q1, a1, q0);
             Jc[6 * a + 3] = -a0;
             Jc[6 * a + 4] = -a1;
             Jc[6 * a + 5] = -a2;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                Jp[3 * a + k] = (a0 * R[3 * k] + a1 * R[3 * k + 1]) + a2 * R[3 * k + 2];
+                Jp[3 * a + k] = fd3(a0, R[3 * k], a1, R[3 * k + 1], a2, R[3 * k + 2]);
         }
     }
 }
@@ -208,30 +216,30 @@ __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (
         L[k] = P.pinfo[6 * (size_t)i + k];
     const double d0 = p[0] - P.pts0[3 * (size_t)i], d1 = p[1] - P.pts0[3 * (size_t)i + 1],
                  d2 = p[2] - P.pts0[3 * (size_t)i + 2];
-    const double Ld0 = (L[0] * d0 + L[1] * d1) + L[2] * d2, Ld1 = (L[1] * d0 + L[3] * d1) + L[4] * d2,
-                 Ld2 = (L[2] * d0 + L[4] * d1) + L[5] * d2;
+    const double Ld0 = fd3(L[0], d0, L[1], d1, L[2], d2), Ld1 = fd3(L[1], d0, L[3], d1, L[4], d2),
+                 Ld2 = fd3(L[2], d0, L[4], d1, L[5], d2);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
         Hpp[k] = L[k];
     gp[0] = Ld0, gp[1] = Ld1, gp[2] = Ld2;
-    double cost = (d0 * Ld0 + d1 * Ld1) + d2 * Ld2;
+    double cost = fd3(d0, Ld0, d1, Ld1, d2, Ld2);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         double r[2], Jc[12], Jp[6];
         project_lin<true>(P.cam, R[f], t[f], p, P.obs[f][2 * (size_t)i], P.obs[f][2 * (size_t)i + 1], r, Jc, Jp);
         const double W0 = P.oinfo[f][3 * (size_t)i], W1 = P.oinfo[f][3 * (size_t)i + 1], W2 = P.oinfo[f][3 * (size_t)i + 2];
-        const double wr0 = W0 * r[0] + W1 * r[1], wr1 = W1 * r[0] + W2 * r[1];
-        cost = cost + (r[0] * wr0 + r[1] * wr1);
+        const double wr0 = fd2(W0, r[0], W1, r[1]), wr1 = fd2(W1, r[0], W2, r[1]);
+        cost = fma(r[1], wr1, fma(r[0], wr0, cost));
         double WJc[12], WJp[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            WJc[k] = W0 * Jc[k] + W1 * Jc[6 + k];
-            WJc[6 + k] = W1 * Jc[k] + W2 * Jc[6 + k];
+            WJc[k] = fd2(W0, Jc[k], W1, Jc[6 + k]);
+            WJc[6 + k] = fd2(W1, Jc[k], W2, Jc[6 + k]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            WJp[k] = W0 * Jp[k] + W1 * Jp[3 + k];
-            WJp[3 + k] = W1 * Jp[k] + W2 * Jp[3 + k];
+            WJp[k] = fd2(W0, Jp[k], W1, Jp[3 + k]);
+            WJp[3 + k] = fd2(W1, Jp[k], W2, Jp[3 + k]);
         }
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
@@ -239,22 +247,22 @@ __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (
 #pragma unroll
                 for (int b = 0; b <= a; ++b)
                     acc[lidx(6 * f + a, 6 * f + b)] =
-                        acc[lidx(6 * f + a, 6 * f + b)] + (Jc[a] * WJc[b] + Jc[6 + a] * WJc[6 + b]);
-                acc[NL + 6 * f + a] = acc[NL + 6 * f + a] - (Jc[a] * wr0 + Jc[6 + a] * wr1);
+                        acc[lidx(6 * f + a, 6 * f + b)] + fd2(Jc[a], WJc[b], Jc[6 + a], WJc[6 + b]);
+                acc[NL + 6 * f + a] = acc[NL + 6 * f + a] - fd2(Jc[a], wr0, Jc[6 + a], wr1);
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                Hcp[6 * f + a][k] = Jc[a] * WJp[k] + Jc[6 + a] * WJp[3 + k];
+                Hcp[6 * f + a][k] = fd2(Jc[a], WJp[k], Jc[6 + a], WJp[3 + k]);
         }
-        Hpp[0] = Hpp[0] + (Jp[0] * WJp[0] + Jp[3] * WJp[3]);
-        Hpp[1] = Hpp[1] + (Jp[0] * WJp[1] + Jp[3] * WJp[4]);
-        Hpp[2] = Hpp[2] + (Jp[0] * WJp[2] + Jp[3] * WJp[5]);
-        Hpp[3] = Hpp[3] + (Jp[1] * WJp[1] + Jp[4] * WJp[4]);
-        Hpp[4] = Hpp[4] + (Jp[1] * WJp[2] + Jp[4] * WJp[5]);
-        Hpp[5] = Hpp[5] + (Jp[2] * WJp[2] + Jp[5] * WJp[5]);
+        Hpp[0] = fma(Jp[3], WJp[3], fma(Jp[0], WJp[0], Hpp[0]));
+        Hpp[1] = fma(Jp[3], WJp[4], fma(Jp[0], WJp[1], Hpp[1]));
+        Hpp[2] = fma(Jp[3], WJp[5], fma(Jp[0], WJp[2], Hpp[2]));
+        Hpp[3] = fma(Jp[4], WJp[4], fma(Jp[1], WJp[1], Hpp[3]));
+        Hpp[4] = fma(Jp[4], WJp[5], fma(Jp[1], WJp[2], Hpp[4]));
+        Hpp[5] = fma(Jp[5], WJp[5], fma(Jp[2], WJp[2], Hpp[5]));
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            gp[k] = gp[k] + (Jp[k] * wr0 + Jp[3 + k] * wr1);
+            gp[k] = fma(Jp[3 + k], wr1, fma(Jp[k], wr0, gp[k]));
     }
     if (ACC)
         acc[NL + NC] = acc[NL + NC] + cost;
@@ -270,16 +278,16 @@ __device__ __forceinline__ double point_cost(const Prob<F> &P, const double (&R)
         L[k] = P.pinfo[6 * (size_t)i + k];
     const double d0 = p[0] - P.pts0[3 * (size_t)i], d1 = p[1] - P.pts0[3 * (size_t)i + 1],
                  d2 = p[2] - P.pts0[3 * (size_t)i + 2];
-    const double Ld0 = (L[0] * d0 + L[1] * d1) + L[2] * d2, Ld1 = (L[1] * d0 + L[3] * d1) + L[4] * d2,
-                 Ld2 = (L[2] * d0 + L[4] * d1) + L[5] * d2;
-    double c = (d0 * Ld0 + d1 * Ld1) + d2 * Ld2;
+    const double Ld0 = fd3(L[0], d0, L[1], d1, L[2], d2), Ld1 = fd3(L[1], d0, L[3], d1, L[4], d2),
+                 Ld2 = fd3(L[2], d0, L[4], d1, L[5], d2);
+    double c = fd3(d0, Ld0, d1, Ld1, d2, Ld2);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         double r[2], Jc[12], Jp[6];
         project_lin<false>(P.cam, R[f], t[f], p, P.obs[f][2 * (size_t)i], P.obs[f][2 * (size_t)i + 1], r, Jc, Jp);
         const double W0 = P.oinfo[f][3 * (size_t)i], W1 = P.oinfo[f][3 * (size_t)i + 1], W2 = P.oinfo[f][3 * (size_t)i + 2];
-        const double wr0 = W0 * r[0] + W1 * r[1], wr1 = W1 * r[0] + W2 * r[1];
-        c = c + (r[0] * wr0 + r[1] * wr1);
+        const double wr0 = fd2(W0, r[0], W1, r[1]), wr1 = fd2(W1, r[0], W2, r[1]);
+        c = fma(r[1], wr1, fma(r[0], wr0, c));
     }
     return c;
 }
@@ -338,7 +346,7 @@ __device__ __forceinline__ bool chol_packed(double (&S)[N * (N + 1) / 2])
         double d = S[lidx(j, j)];
 #pragma unroll
         for (int k = 0; k < j; ++k)
-            d = d - S[lidx(j, k)] * S[lidx(j, k)];
+            d = fma(-S[lidx(j, k)], S[lidx(j, k)], d);
         ok = ok && (d > 0.0) && (d < __builtin_inf());
         const double l = sqrt(d);
         S[lidx(j, j)] = l;
@@ -347,7 +355,7 @@ __device__ __forceinline__ bool chol_packed(double (&S)[N * (N + 1) / 2])
             double v = S[lidx(i, j)];
 #pragma unroll
             for (int k = 0; k < j; ++k)
-                v = v - S[lidx(i, k)] * S[lidx(j, k)];
+                v = fma(-S[lidx(i, k)], S[lidx(j, k)], v);
             S[lidx(i, j)] = v / l;
         }
     }
@@ -362,7 +370,7 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[N * (N + 1) / 2], 
         double v = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k)
-            v = v - Lc[lidx(i, k)] * b[k];
+            v = fma(-Lc[lidx(i, k)], b[k], v);
         b[i] = v / Lc[lidx(i, i)];
     }
 #pragma unroll
@@ -370,7 +378,7 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[N * (N + 1) / 2], 
         double v = b[i];
 #pragma unroll
         for (int k = i + 1; k < N; ++k)
-            v = v - Lc[lidx(k, i)] * b[k];
+            v = fma(-Lc[lidx(k, i)], b[k], v);
         b[i] = v / Lc[lidx(i, i)];
     }
 }
@@ -392,19 +400,15 @@ __device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &c
         const double Hd[6] = {Hpp[0] + lam, Hpp[1], Hpp[2], Hpp[3] + lam, Hpp[4], Hpp[5] + lam};
         double Pi[6];
         sym3_inverse(Hd, Pi);
-        double Y[NC][3];
 #pragma unroll
-        for (int a = 0; a < NC; ++a) {
-            Y[a][0] = (Hcp[a][0] * Pi[0] + Hcp[a][1] * Pi[1]) + Hcp[a][2] * Pi[2];
-            Y[a][1] = (Hcp[a][0] * Pi[1] + Hcp[a][1] * Pi[3]) + Hcp[a][2] * Pi[4];
-            Y[a][2] = (Hcp[a][0] * Pi[2] + Hcp[a][1] * Pi[4]) + Hcp[a][2] * Pi[5];
-        }
-#pragma unroll
-        for (int a = 0; a < NC; ++a) {
+        for (int a = 0; a < NC; ++a) {   // row a of Y = Hcp P lives only for this row of the update
+            const double y0 = fd3(Hcp[a][0], Pi[0], Hcp[a][1], Pi[1], Hcp[a][2], Pi[2]);
+            const double y1 = fd3(Hcp[a][0], Pi[1], Hcp[a][1], Pi[3], Hcp[a][2], Pi[4]);
+            const double y2 = fd3(Hcp[a][0], Pi[2], Hcp[a][1], Pi[4], Hcp[a][2], Pi[5]);
 #pragma unroll
             for (int c = 0; c <= a; ++c)
-                acc[lidx(a, c)] = acc[lidx(a, c)] - ((Y[a][0] * Hcp[c][0] + Y[a][1] * Hcp[c][1]) + Y[a][2] * Hcp[c][2]);
-            acc[NL + a] = acc[NL + a] + ((Y[a][0] * gp[0] + Y[a][1] * gp[1]) + Y[a][2] * gp[2]);
+                acc[lidx(a, c)] = fma(-y2, Hcp[c][2], fma(-y1, Hcp[c][1], fma(-y0, Hcp[c][0], acc[lidx(a, c)])));
+            acc[NL + a] = fma(y2, gp[2], fma(y1, gp[1], fma(y0, gp[0], acc[NL + a])));
         }
     }
     block_reduce<NV>(acc, red);
@@ -528,10 +532,11 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
 #pragma unroll
         for (int k = 0; k < NC; ++k)
             b[k] = acc[NL + k];
-        bool accepted = false;
+        bool accepted = false, solved = false;
         double cand = 0.0;
         double Rn[F][9], tn[F][3];
         if (chol_packed<NC>(S)) {   // uniform: every thread holds the same S
+            solved = true;
             chol_solve<NC>(S, b);
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -558,13 +563,13 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
                 double v0 = gp[0], v1 = gp[1], v2 = gp[2];
 #pragma unroll
                 for (int a = 0; a < NC; ++a) {
-                    v0 = v0 + Hcp[a][0] * b[a];
-                    v1 = v1 + Hcp[a][1] * b[a];
-                    v2 = v2 + Hcp[a][2] * b[a];
+                    v0 = fma(Hcp[a][0], b[a], v0);
+                    v1 = fma(Hcp[a][1], b[a], v1);
+                    v2 = fma(Hcp[a][2], b[a], v2);
                 }
-                const double pn[3] = {p[0] - ((Pi[0] * v0 + Pi[1] * v1) + Pi[2] * v2),
-                                      p[1] - ((Pi[1] * v0 + Pi[3] * v1) + Pi[4] * v2),
-                                      p[2] - ((Pi[2] * v0 + Pi[4] * v1) + Pi[5] * v2)};
+                const double pn[3] = {p[0] - fd3(Pi[0], v0, Pi[1], v1, Pi[2], v2),
+                                      p[1] - fd3(Pi[1], v0, Pi[3], v1, Pi[4], v2),
+                                      p[2] - fd3(Pi[2], v0, Pi[4], v1, Pi[5], v2)};
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     pts_new[3 * (size_t)i + k] = pn[k];
@@ -594,6 +599,10 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
             if (done)
                 break;
         } else {
+            // a trial within the tolerances ABOVE the current error: at the minimum to rounding, stop
+            const double inc = 0.5 * (cand - cur);
+            if (solved && (inc <= cfg.abs_tol || inc <= cfg.rel_tol * (0.5 * cur)))
+                break;
             lam = lam * cfg.lambda_factor;
             if (lam > cfg.lambda_upper)
                 break;
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
                     for (int a = 0; a < NC; ++a)
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
-                            G[a][k] = (Hcp[a][0] * Pf[k] + Hcp[a][1] * Pf[3 + k]) + Hcp[a][2] * Pf[6 + k];
+                            G[a][k] = fd3(Hcp[a][0], Pf[k], Hcp[a][1], Pf[3 + k], Hcp[a][2], Pf[6 + k]);
                     double C[9];
 #pragma unroll
                     for (int k = 0; k < 9; ++k)
@@ -649,14 +658,14 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
                             double s = 0.0;
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
-                                s = s + Sinv[a * NC + c] * G[c][k];
+                                s = fma(Sinv[a * NC + c], G[c][k], s);
                             sg[k] = s;
                         }
 #pragma unroll
                         for (int r = 0; r < 3; ++r)
 #pragma unroll
                             for (int k = 0; k < 3; ++k)
-                                C[3 * r + k] = C[3 * r + k] + G[a][r] * sg[k];
+                                C[3 * r + k] = fma(G[a][r], sg[k], C[3 * r + k]);
                     }
 #pragma unroll
                     for (int k = 0; k < 9; ++k)

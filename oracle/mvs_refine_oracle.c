@@ -38,6 +38,14 @@
 #define NLOW(n) ((n) * ((n) + 1) / 2)
 #define LIDX(r, c) ((r) * ((r) + 1) / 2 + (c)) /* r >= c */
 
+/* fused building blocks: the HIP kernel uses the same ones in the same places (one v_fma_f64 each) */
+static inline double fd2(double a0, double b0, double a1, double b1) { return fma(a1, b1, a0 * b0); }
+static inline double fd3(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    return fma(a2, b2, fma(a1, b1, a0 * b0));
+}
+static inline double fx2(double a, double b, double c, double d) { return fma(a, b, -(c * d)); } /* a b - c d */
+
 typedef struct {
     int F, m;
     double fx, fy, sk, cx, cy;
@@ -124,17 +132,17 @@ static void so3_jrinv(const double w[3], double J[9])
 
 static int sym3_inverse(const double a[6], double o[6])
 { /* a = xx xy xz yy yz zz */
-    double c00 = a[3] * a[5] - a[4] * a[4];
-    double c01 = a[2] * a[4] - a[1] * a[5];
-    double c02 = a[1] * a[4] - a[2] * a[3];
-    double det = (a[0] * c00 + a[1] * c01) + a[2] * c02;
+    double c00 = fx2(a[3], a[5], a[4], a[4]);
+    double c01 = fx2(a[2], a[4], a[1], a[5]);
+    double c02 = fx2(a[1], a[4], a[2], a[3]);
+    double det = fd3(a[0], c00, a[1], c01, a[2], c02);
     double id = 1.0 / det;
     o[0] = c00 * id;
     o[1] = c01 * id;
     o[2] = c02 * id;
-    o[3] = (a[0] * a[5] - a[2] * a[2]) * id;
-    o[4] = (a[1] * a[2] - a[0] * a[4]) * id;
-    o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+    o[3] = fx2(a[0], a[5], a[2], a[2]) * id;
+    o[4] = fx2(a[1], a[2], a[0], a[4]) * id;
+    o[5] = fx2(a[0], a[3], a[1], a[1]) * id;
     return det != 0.0 && isfinite(id);
 }
 
@@ -143,9 +151,9 @@ static int project_lin(const ba_problem *P, const double R[9], const double t[3]
                        double r[2], double Jc[12], double Jp[6], int want_jac)
 {
     double d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
-    double q0 = (R[0] * d0 + R[3] * d1) + R[6] * d2;
-    double q1 = (R[1] * d0 + R[4] * d1) + R[7] * d2;
-    double q2 = (R[2] * d0 + R[5] * d1) + R[8] * d2;
+    double q0 = fd3(R[0], d0, R[3], d1, R[6], d2);
+    double q1 = fd3(R[1], d0, R[4], d1, R[7], d2);
+    double q2 = fd3(R[2], d0, R[5], d1, R[8], d2);
     if (!(q2 > 0.0)) {
         r[0] = 2.0 * P->fx;
         r[1] = 2.0 * P->fx;
@@ -156,7 +164,7 @@ static int project_lin(const ba_problem *P, const double R[9], const double t[3]
         return 0;
     }
     double iz = 1.0 / q2, xn = q0 * iz, yn = q1 * iz;
-    double un = P->fx * xn + P->sk * yn, vn = P->fy * yn;
+    double un = fd2(P->fx, xn, P->sk, yn), vn = P->fy * yn;
     r[0] = (un + P->cx) - uv[0];
     r[1] = (vn + P->cy) - uv[1];
     if (!want_jac)
@@ -164,14 +172,14 @@ static int project_lin(const ba_problem *P, const double R[9], const double t[3]
     double A[6] = {P->fx * iz, P->sk * iz, -(un * iz), 0.0, P->fy * iz, -(vn * iz)};
     for (int a = 0; a < 2; ++a) {
         const double *Aa = A + 3 * a;
-        Jc[6 * a + 0] = Aa[1] * q2 - Aa[2] * q1;
-        Jc[6 * a + 1] = Aa[2] * q0 - Aa[0] * q2;
-        Jc[6 * a + 2] = Aa[0] * q1 - Aa[1] * q0;
+        Jc[6 * a + 0] = fx2(Aa[1], q2, Aa[2], q1);
+        Jc[6 * a + 1] = fx2(Aa[2], q0, Aa[0], q2);
+        Jc[6 * a + 2] = fx2(Aa[0], q1, Aa[1], q0);
         Jc[6 * a + 3] = -Aa[0];
         Jc[6 * a + 4] = -Aa[1];
         Jc[6 * a + 5] = -Aa[2];
         for (int k = 0; k < 3; ++k)
-            Jp[3 * a + k] = (Aa[0] * R[3 * k] + Aa[1] * R[3 * k + 1]) + Aa[2] * R[3 * k + 2];
+            Jp[3 * a + k] = fd3(Aa[0], R[3 * k], Aa[1], R[3 * k + 1], Aa[2], R[3 * k + 2]);
     }
     return 1;
 }
@@ -191,39 +199,39 @@ static void point_linearize(const ba_problem *P, const double R[2][9], const dou
 {
     const double *p = pts + 3 * i, *p0 = P->pts0 + 3 * i, *L = P->pinfo + 6 * i;
     double d[3] = {p[0] - p0[0], p[1] - p0[1], p[2] - p0[2]};
-    double Ld[3] = {(L[0] * d[0] + L[1] * d[1]) + L[2] * d[2], (L[1] * d[0] + L[3] * d[1]) + L[4] * d[2],
-                    (L[2] * d[0] + L[4] * d[1]) + L[5] * d[2]};
+    double Ld[3] = {fd3(L[0], d[0], L[1], d[1], L[2], d[2]), fd3(L[1], d[0], L[3], d[1], L[4], d[2]),
+                    fd3(L[2], d[0], L[4], d[1], L[5], d[2])};
     memcpy(B->Hpp, L, 6 * sizeof(double));
     memcpy(B->gp, Ld, 3 * sizeof(double));
-    B->cost = (d[0] * Ld[0] + d[1] * Ld[1]) + d[2] * Ld[2];
+    B->cost = fd3(d[0], Ld[0], d[1], Ld[1], d[2], Ld[2]);
     for (int f = 0; f < P->F; ++f) {
         double r[2], Jc[12], Jp[6];
         project_lin(P, R[f], t[f], p, P->obs[f] + 2 * i, r, Jc, Jp, 1);
         const double *W = P->oinfo[f] + 3 * i;
-        double wr0 = W[0] * r[0] + W[1] * r[1], wr1 = W[1] * r[0] + W[2] * r[1];
-        B->cost = B->cost + (r[0] * wr0 + r[1] * wr1);
+        double wr0 = fd2(W[0], r[0], W[1], r[1]), wr1 = fd2(W[1], r[0], W[2], r[1]);
+        B->cost = fma(r[1], wr1, fma(r[0], wr0, B->cost));
         double WJc[12], WJp[6];
         for (int k = 0; k < 6; ++k) {
-            WJc[k] = W[0] * Jc[k] + W[1] * Jc[6 + k];
-            WJc[6 + k] = W[1] * Jc[k] + W[2] * Jc[6 + k];
+            WJc[k] = fd2(W[0], Jc[k], W[1], Jc[6 + k]);
+            WJc[6 + k] = fd2(W[1], Jc[k], W[2], Jc[6 + k]);
         }
         for (int k = 0; k < 3; ++k) {
-            WJp[k] = W[0] * Jp[k] + W[1] * Jp[3 + k];
-            WJp[3 + k] = W[1] * Jp[k] + W[2] * Jp[3 + k];
+            WJp[k] = fd2(W[0], Jp[k], W[1], Jp[3 + k]);
+            WJp[3 + k] = fd2(W[1], Jp[k], W[2], Jp[3 + k]);
         }
         for (int a = 0; a < 6; ++a) {
             for (int b = 0; b <= a; ++b)
-                B->Hcc[f][LIDX(a, b)] = Jc[a] * WJc[b] + Jc[6 + a] * WJc[6 + b];
-            B->gc[6 * f + a] = Jc[a] * wr0 + Jc[6 + a] * wr1;
+                B->Hcc[f][LIDX(a, b)] = fd2(Jc[a], WJc[b], Jc[6 + a], WJc[6 + b]);
+            B->gc[6 * f + a] = fd2(Jc[a], wr0, Jc[6 + a], wr1);
             for (int k = 0; k < 3; ++k)
-                B->Hcp[6 * f + a][k] = Jc[a] * WJp[k] + Jc[6 + a] * WJp[3 + k];
+                B->Hcp[6 * f + a][k] = fd2(Jc[a], WJp[k], Jc[6 + a], WJp[3 + k]);
         }
         int s = 0;
         for (int a = 0; a < 3; ++a)
             for (int b = a; b < 3; ++b, ++s)
-                B->Hpp[s] = B->Hpp[s] + (Jp[a] * WJp[b] + Jp[3 + a] * WJp[3 + b]);
+                B->Hpp[s] = fma(Jp[3 + a], WJp[3 + b], fma(Jp[a], WJp[b], B->Hpp[s]));
         for (int k = 0; k < 3; ++k)
-            B->gp[k] = B->gp[k] + (Jp[k] * wr0 + Jp[3 + k] * wr1);
+            B->gp[k] = fma(Jp[3 + k], wr1, fma(Jp[k], wr0, B->gp[k]));
     }
 }
 
@@ -231,15 +239,15 @@ static double point_cost(const ba_problem *P, const double R[2][9], const double
 {
     const double *p0 = P->pts0 + 3 * i, *L = P->pinfo + 6 * i;
     double d[3] = {p[0] - p0[0], p[1] - p0[1], p[2] - p0[2]};
-    double Ld[3] = {(L[0] * d[0] + L[1] * d[1]) + L[2] * d[2], (L[1] * d[0] + L[3] * d[1]) + L[4] * d[2],
-                    (L[2] * d[0] + L[4] * d[1]) + L[5] * d[2]};
-    double c = (d[0] * Ld[0] + d[1] * Ld[1]) + d[2] * Ld[2];
+    double Ld[3] = {fd3(L[0], d[0], L[1], d[1], L[2], d[2]), fd3(L[1], d[0], L[3], d[1], L[4], d[2]),
+                    fd3(L[2], d[0], L[4], d[1], L[5], d[2])};
+    double c = fd3(d[0], Ld[0], d[1], Ld[1], d[2], Ld[2]);
     for (int f = 0; f < P->F; ++f) {
         double r[2];
         project_lin(P, R[f], t[f], p, P->obs[f] + 2 * i, r, NULL, NULL, 0);
         const double *W = P->oinfo[f] + 3 * i;
-        double wr0 = W[0] * r[0] + W[1] * r[1], wr1 = W[1] * r[0] + W[2] * r[1];
-        c = c + (r[0] * wr0 + r[1] * wr1);
+        double wr0 = fd2(W[0], r[0], W[1], r[1]), wr1 = fd2(W[1], r[0], W[2], r[1]);
+        c = fma(r[1], wr1, fma(r[0], wr0, c));
     }
     return c;
 }
@@ -289,7 +297,7 @@ static int chol_packed(double *S, int n)
     for (int j = 0; j < n; ++j) {
         double d = S[LIDX(j, j)];
         for (int k = 0; k < j; ++k)
-            d = d - S[LIDX(j, k)] * S[LIDX(j, k)];
+            d = fma(-S[LIDX(j, k)], S[LIDX(j, k)], d);
         if (!(d > 0.0) || !isfinite(d))
             return 0;
         double l = sqrt(d);
@@ -297,7 +305,7 @@ static int chol_packed(double *S, int n)
         for (int i = j + 1; i < n; ++i) {
             double v = S[LIDX(i, j)];
             for (int k = 0; k < j; ++k)
-                v = v - S[LIDX(i, k)] * S[LIDX(j, k)];
+                v = fma(-S[LIDX(i, k)], S[LIDX(j, k)], v);
             S[LIDX(i, j)] = v / l;
         }
     }
@@ -308,13 +316,13 @@ static void chol_solve(const double *Lc, int n, double *b)
     for (int i = 0; i < n; ++i) {
         double v = b[i];
         for (int k = 0; k < i; ++k)
-            v = v - Lc[LIDX(i, k)] * b[k];
+            v = fma(-Lc[LIDX(i, k)], b[k], v);
         b[i] = v / Lc[LIDX(i, i)];
     }
     for (int i = n - 1; i >= 0; --i) {
         double v = b[i];
         for (int k = i + 1; k < n; ++k)
-            v = v - Lc[LIDX(k, i)] * b[k];
+            v = fma(-Lc[LIDX(k, i)], b[k], v);
         b[i] = v / Lc[LIDX(i, i)];
     }
 }
@@ -336,9 +344,9 @@ static void build_schur(const ba_problem *P, const double R[2][9], const double 
             double Y[MAXC][3];
             for (int a = 0; a < nc; ++a) {
                 const double *h = B.Hcp[a];
-                Y[a][0] = (h[0] * Pi[0] + h[1] * Pi[1]) + h[2] * Pi[2];
-                Y[a][1] = (h[0] * Pi[1] + h[1] * Pi[3]) + h[2] * Pi[4];
-                Y[a][2] = (h[0] * Pi[2] + h[1] * Pi[4]) + h[2] * Pi[5];
+                Y[a][0] = fd3(h[0], Pi[0], h[1], Pi[1], h[2], Pi[2]);
+                Y[a][1] = fd3(h[0], Pi[1], h[1], Pi[3], h[2], Pi[4]);
+                Y[a][2] = fd3(h[0], Pi[2], h[1], Pi[4], h[2], Pi[5]);
             }
             for (int f = 0; f < P->F; ++f) /* the frame's own blocks first, then the Schur correction */
                 for (int a = 0; a < 6; ++a) {
@@ -348,11 +356,15 @@ static void build_schur(const ba_problem *P, const double R[2][9], const double 
                 }
             for (int a = 0; a < nc; ++a) {
                 for (int c = 0; c <= a; ++c) {
-                    double yh = (Y[a][0] * B.Hcp[c][0] + Y[a][1] * B.Hcp[c][1]) + Y[a][2] * B.Hcp[c][2];
-                    acc[LIDX(a, c)][l] = acc[LIDX(a, c)][l] - yh;
+                    double s = acc[LIDX(a, c)][l];
+                    s = fma(-Y[a][0], B.Hcp[c][0], s);
+                    s = fma(-Y[a][1], B.Hcp[c][1], s);
+                    acc[LIDX(a, c)][l] = fma(-Y[a][2], B.Hcp[c][2], s);
                 }
-                double yg = (Y[a][0] * B.gp[0] + Y[a][1] * B.gp[1]) + Y[a][2] * B.gp[2];
-                acc[nl + a][l] = acc[nl + a][l] + yg;
+                double g = acc[nl + a][l];
+                g = fma(Y[a][0], B.gp[0], g);
+                g = fma(Y[a][1], B.gp[1], g);
+                acc[nl + a][l] = fma(Y[a][2], B.gp[2], g);
             }
             acc[nl + nc][l] = acc[nl + nc][l] + B.cost;
         }
@@ -415,11 +427,11 @@ static double step_points(const ba_problem *P, const double R[2][9], const doubl
             double v[3] = {B.gp[0], B.gp[1], B.gp[2]};
             for (int a = 0; a < nc; ++a)
                 for (int k = 0; k < 3; ++k)
-                    v[k] = v[k] + B.Hcp[a][k] * dc[a];
+                    v[k] = fma(B.Hcp[a][k], dc[a], v[k]);
             double *pn = pts_new + 3 * i;
-            pn[0] = pts[3 * i + 0] - ((Pi[0] * v[0] + Pi[1] * v[1]) + Pi[2] * v[2]);
-            pn[1] = pts[3 * i + 1] - ((Pi[1] * v[0] + Pi[3] * v[1]) + Pi[4] * v[2]);
-            pn[2] = pts[3 * i + 2] - ((Pi[2] * v[0] + Pi[4] * v[1]) + Pi[5] * v[2]);
+            pn[0] = pts[3 * i + 0] - fd3(Pi[0], v[0], Pi[1], v[1], Pi[2], v[2]);
+            pn[1] = pts[3 * i + 1] - fd3(Pi[1], v[0], Pi[3], v[1], Pi[4], v[2]);
+            pn[2] = pts[3 * i + 2] - fd3(Pi[2], v[0], Pi[4], v[1], Pi[5], v[2]);
             acc[l] = acc[l] + point_cost(P, Rn, tn, pn, i);
         }
     }
@@ -462,20 +474,20 @@ static int covariances(const ba_problem *P, const double R[2][9], const double t
             double G[MAXC][3]; /* Hcp P */
             for (int a = 0; a < nc; ++a)
                 for (int k = 0; k < 3; ++k)
-                    G[a][k] = (B.Hcp[a][0] * Pf[k] + B.Hcp[a][1] * Pf[3 + k]) + B.Hcp[a][2] * Pf[6 + k];
+                    G[a][k] = fd3(B.Hcp[a][0], Pf[k], B.Hcp[a][1], Pf[3 + k], B.Hcp[a][2], Pf[6 + k]);
             double SG[MAXC][3];
             for (int a = 0; a < nc; ++a)
                 for (int k = 0; k < 3; ++k) {
                     double s = 0.0;
                     for (int c = 0; c < nc; ++c)
-                        s = s + Sinv[a * nc + c] * G[c][k];
+                        s = fma(Sinv[a * nc + c], G[c][k], s);
                     SG[a][k] = s;
                 }
             for (int r = 0; r < 3; ++r)
                 for (int k = 0; k < 3; ++k) {
                     double s = 0.0;
                     for (int a = 0; a < nc; ++a)
-                        s = s + G[a][r] * SG[a][k];
+                        s = fma(G[a][r], SG[a][k], s);
                     point_cov[9 * i + 3 * r + k] = Pf[3 * r + k] + s;
                 }
         }
@@ -509,9 +521,10 @@ static int ba_solve(const ba_problem *P, const orc_refine_params *prm, double R[
     while (ok && it < prm->max_iterations) {
         double S[NLOW(MAXC)], b[MAXC], c2;
         build_schur(P, R, t, pts, lam, S, b, &c2);
-        int accepted = 0;
+        int accepted = 0, solved = 0;
         double cand = 0.0;
         if (chol_packed(S, nc)) {
+            solved = 1;
             chol_solve(S, nc, b);
             double Rn[2][9], tn[2][3];
             for (int f = 0; f < P->F; ++f)
@@ -533,6 +546,11 @@ static int ba_solve(const ba_problem *P, const orc_refine_params *prm, double R[
             if (done)
                 break;
         } else {
+            /* a trial that lands within the tolerances ABOVE the current error: the estimate is at the minimum to
+             * rounding; raising lambda would only replay the same comparison */
+            double inc = 0.5 * (cand - cur);
+            if (solved && (inc <= prm->abs_tol || inc <= prm->rel_tol * (0.5 * cur)))
+                break;
             lam = lam * prm->lambda_factor;
             if (lam > prm->lambda_upper)
                 break;
