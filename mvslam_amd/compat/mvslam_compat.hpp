@@ -263,6 +263,64 @@ struct ImagePoint  // cv::Point_<double>
     ImagePoint() : x(0), y(0) {}
     ImagePoint(ScalarType x_, ScalarType y_) : x(x_), y(y_) {}
 };
+// ---- math/state-estimate.hpp:6-49 and base/data-type.hpp:19-29 -------------------------------------
+struct Vector2Type
+{
+    ScalarType v[2];
+    Vector2Type() : v{0, 0} {}
+    Vector2Type(ScalarType x, ScalarType y) : v{x, y} {}
+    ScalarType &operator[](size_t i) { return v[i]; }
+    const ScalarType &operator[](size_t i) const { return v[i]; }
+};
+template <int N>
+struct SquareMatrix  // row-major N x N stand-in for Eigen::Matrix<ScalarType, N, N>
+{
+    ScalarType m[N * N];
+    SquareMatrix() { std::memset(m, 0, sizeof(m)); }
+    static SquareMatrix Identity()
+    {
+        SquareMatrix I;
+        for (int i = 0; i < N; ++i)
+            I.m[i * N + i] = 1;
+        return I;
+    }
+    ScalarType &operator()(size_t r, size_t c) { return m[r * N + c]; }
+    const ScalarType &operator()(size_t r, size_t c) const { return m[r * N + c]; }
+    const ScalarType *data() const { return m; }
+};
+template <int N>
+inline SquareMatrix<N> operator*(ScalarType s, const SquareMatrix<N> &A)
+{
+    SquareMatrix<N> B;
+    for (int i = 0; i < N * N; ++i)
+        B.m[i] = s * A.m[i];
+    return B;
+}
+using Matrix2Type = SquareMatrix<2>;
+using Matrix6Type = SquareMatrix<6>;
+template <typename MeanType, typename CovarType>
+class StateEstimate
+{
+public:
+    StateEstimate() {}
+    StateEstimate(const MeanType &mean, const CovarType &covar) : _mean(mean), _covar(covar) {}
+    const MeanType &mean() const { return _mean; }
+    MeanType &mean() { return _mean; }
+    const CovarType &covar() const { return _covar; }
+    CovarType &covar() { return _covar; }
+
+private:
+    MeanType _mean;
+    CovarType _covar;
+};
+using TransformationUncertainty = Matrix6Type;
+using TransformationEstimate = StateEstimate<Transformation, TransformationUncertainty>;
+using Point3Uncertainty = Matrix3Type;
+using Point3Estimate = StateEstimate<Point3, Point3Uncertainty>;
+using Point2 = Vector2Type;
+using Point2Uncertainty = Matrix2Type;
+using Point2Estimate = StateEstimate<Point2, Point2Uncertainty>;
+
 struct Point2f { float x, y; };
 struct KeyPoint  // cv::KeyPoint layout
 {
@@ -406,6 +464,17 @@ public:
         r.reserve(m_keypoints.size());
         for (const auto &kp : m_keypoints)
             r.emplace_back(kp.pt.x, kp.pt.y);
+        return r;
+    }
+
+    std::vector<Point2Estimate> get_point_estimates() const  // :193-207: sigma = 2^octave * 0.5 px, isotropic
+    {
+        std::vector<Point2Estimate> r;
+        r.reserve(m_keypoints.size());
+        for (const auto &kp : m_keypoints) {
+            const ScalarType stddev = static_cast<ScalarType>(1 << kp.octave) * 0.5;
+            r.emplace_back(Point2(kp.pt.x, kp.pt.y), sqr(stddev) * Point2Uncertainty::Identity());
+        }
         return r;
     }
 
@@ -586,7 +655,92 @@ inline bool pnp_solve(const std::vector<Point3> &world_points, const std::vector
     return true;
 }
 
-// ---- front-end/image-pair.{hpp,cpp} (ctor + reconstruct; refine() is GTSAM, out of scope) ---------
+// ---- vision/sfm.hpp:56-76 and vision/pnp.hpp:28-46 (row f4: the two callers of ba_frame_pose_and_point) ---------
+namespace hip
+{
+inline mvs_refine_params &refine_config()
+{
+    static thread_local mvs_refine_params cfg = [] {
+        mvs_refine_params p;
+        mvs_refine_params_default(&p);
+        return p;
+    }();
+    return cfg;
+}
+inline TransformationEstimate estimate_from_result_(const mvs_refine_result &r)
+{
+    TransformationUncertainty C;
+    std::memcpy(C.m, r.pose_cov, sizeof(C.m));
+    Matrix3Type Rm;
+    std::memcpy(Rm.m, r.R, sizeof(Rm.m));
+    // the optimiser's rotation is orthonormal to rounding; the reference's Pose3_to_SE3 goes through SO3(Matrix3)
+    return TransformationEstimate(SE3(SO3(Rm), Vector3Type(r.t[0], r.t[1], r.t[2])), C);
+}
+}  // namespace hip
+
+inline bool sfm_refine(const std::vector<Point2Estimate> &p1_estimate, const std::vector<Point2Estimate> &p2_estimate,
+                       const CameraIntrinsics &ci, const Transformation &pose2in1_guess,
+                       const std::vector<Point3> pointsin1_guess, TransformationEstimate &pose2in1_estimate,
+                       std::vector<Point3Estimate> &pointsin1_estimate, ScalarType &error)
+{
+    assert(p1_estimate.size() == p2_estimate.size());      // sfm-refine.cpp:29-30
+    assert(p1_estimate.size() == pointsin1_guess.size());
+    const int m = (int)p1_estimate.size();
+    std::vector<double> p1(2 * (size_t)m), p2(2 * (size_t)m), c1(4 * (size_t)m), c2(4 * (size_t)m), pts(3 * (size_t)m),
+        cov(9 * (size_t)m);
+    for (int i = 0; i < m; ++i) {
+        std::memcpy(&p1[2 * i], p1_estimate[i].mean().v, 2 * sizeof(double));
+        std::memcpy(&p2[2 * i], p2_estimate[i].mean().v, 2 * sizeof(double));
+        std::memcpy(&c1[4 * i], p1_estimate[i].covar().m, 4 * sizeof(double));
+        std::memcpy(&c2[4 * i], p2_estimate[i].covar().m, 4 * sizeof(double));
+    }
+    const Matrix3Type Rg = pose2in1_guess.rotation().get_matrix();
+    const Vector3Type tg = pose2in1_guess.translation();
+    mvs_refine_result res;
+    const mvs_status st = mvs_sfm_refine(hip::context(), p1.data(), c1.data(), p2.data(), c2.data(), m, ci.data(), Rg.m, tg.v,
+                                         pointsin1_guess[0].v, &hip::refine_config(), &res, pts.data(), cov.data());
+    hip::check(st, "sfm_refine");
+    if (st != MVS_OK)
+        return false;
+    pose2in1_estimate = hip::estimate_from_result_(res);
+    pointsin1_estimate.clear();
+    pointsin1_estimate.reserve(m);
+    for (int i = 0; i < m; ++i) {
+        Point3Uncertainty C;
+        std::memcpy(C.m, &cov[9 * (size_t)i], sizeof(C.m));
+        pointsin1_estimate.emplace_back(Point3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), C);
+    }
+    error = res.error;
+    return true;
+}
+
+inline bool pnp_refine(const std::vector<Point3Estimate> &world_point_estimates,
+                       const std::vector<Point2Estimate> &image_point_estimates, const CameraIntrinsics &ci,
+                       const Transformation &pose_guess, TransformationEstimate &pose_estimate, ScalarType &error)
+{
+    assert(world_point_estimates.size() == image_point_estimates.size());  // pnp-refine.cpp:21
+    const int m = (int)world_point_estimates.size();
+    std::vector<double> X(3 * (size_t)m), XC(9 * (size_t)m), uv(2 * (size_t)m), uc(4 * (size_t)m);
+    for (int i = 0; i < m; ++i) {
+        std::memcpy(&X[3 * i], world_point_estimates[i].mean().v, 3 * sizeof(double));
+        std::memcpy(&XC[9 * i], world_point_estimates[i].covar().m, 9 * sizeof(double));
+        std::memcpy(&uv[2 * i], image_point_estimates[i].mean().v, 2 * sizeof(double));
+        std::memcpy(&uc[4 * i], image_point_estimates[i].covar().m, 4 * sizeof(double));
+    }
+    const Matrix3Type Rg = pose_guess.rotation().get_matrix();
+    const Vector3Type tg = pose_guess.translation();
+    mvs_refine_result res;
+    const mvs_status st = mvs_pnp_refine(hip::context(), X.data(), XC.data(), uv.data(), uc.data(), m, ci.data(), Rg.m, tg.v,
+                                         &hip::refine_config(), &res);
+    hip::check(st, "pnp_refine");
+    if (st != MVS_OK)
+        return false;
+    pose_estimate = hip::estimate_from_result_(res);  // the points are not updated (pnp-refine.cpp:103-104)
+    error = res.error;
+    return true;
+}
+
+// ---- front-end/image-pair.{hpp,cpp}: ctor + reconstruct + refine --------------------------------------------------
 struct Frame
 {
     uint32_t id;
@@ -603,12 +757,14 @@ public:
     struct Params
     {
         ScalarType max_match_inlier_distance;   // image-pair.cpp:22-23
-        bool refine_structure_in_constructor;   // image-pair.cpp:25-26 (refinement is GTSAM: not part of this path)
+        bool refine_structure_in_constructor;   // image-pair.cpp:25-26
     };
+    enum class State { INVALID, RECONSTRUCTED, REFINED };  // image-pair.hpp
     static Params get_default_params() { return Params{10, false}; }  // image-pair.cpp:17-28
     ImagePair(const Frame &base_frame_, const Frame &pair_frame_, const CameraIntrinsics &K,
               const Params &params = get_default_params())
-        : valid(false), match_inlier_count(0), match_inlier_ssd(0)
+        : valid(false), match_inlier_count(0), match_inlier_ssd(0), error(0), m_state(State::INVALID),
+          m_base(&base_frame_), m_pair(&pair_frame_), m_K(K)
     {
         assert(base_frame_.id != pair_frame_.id);
         const auto matches = VisualFeature::match_visual_features(base_frame_.visual_feature, pair_frame_.visual_feature,
@@ -629,13 +785,54 @@ public:
                 matched_points.push_back(MatchedPoint{points[k], (size_t)m.trainIdx, (size_t)m.queryIdx});
                 match_inlier_ssd += (uint32_t)sqr(m.distance);
             }
+            m_state = State::RECONSTRUCTED;
         }
+        if (valid && params.refine_structure_in_constructor)  // image-pair.cpp:67-70
+            refine();
     }
+    // image-pair.cpp:176-238: sfm_refine on the matched keypoints' estimates, pose and points replaced on success.
+    // The frames passed to the constructor must still be alive (the reference keeps shared_ptrs).
+    bool refine()
+    {
+        assert(State::RECONSTRUCTED == m_state);
+        assert(valid);
+        const auto be = m_base->visual_feature.get_point_estimates(), pe = m_pair->visual_feature.get_point_estimates();
+        std::vector<Point2Estimate> base_pe, pair_pe;
+        std::vector<Point3> points;
+        for (const auto &mp : matched_points) {
+            base_pe.push_back(be[mp.vf_idx_in_base]);
+            pair_pe.push_back(pe[mp.vf_idx_in_pair]);
+            points.push_back(mp.position);
+        }
+        std::vector<Point3Estimate> point_estimates;
+        TransformationEstimate T_est;
+        valid = sfm_refine(base_pe, pair_pe, m_K, T_pair_to_base, points, T_est, point_estimates, error);
+        if (valid) {
+            T_pair_to_base = T_est.mean();
+            T_pair_to_base_covar = T_est.covar();
+            matched_points_covar.clear();
+            for (size_t i = 0; i < matched_points.size(); ++i) {
+                matched_points[i].position = point_estimates[i].mean();
+                matched_points_covar.push_back(point_estimates[i].covar());
+            }
+            m_state = State::REFINED;
+        }
+        return valid;
+    }
+    State state() const { return m_state; }
     bool valid;
     uint32_t match_inlier_count;
     uint32_t match_inlier_ssd;
+    ScalarType error;
     Transformation T_pair_to_base;
+    TransformationUncertainty T_pair_to_base_covar;
     std::vector<MatchedPoint> matched_points;
+    std::vector<Point3Uncertainty> matched_points_covar;
+
+private:
+    State m_state;
+    const Frame *m_base, *m_pair;
+    CameraIntrinsics m_K;
 };
 
 }  // namespace mvSLAM

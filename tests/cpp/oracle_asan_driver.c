@@ -44,6 +44,27 @@ int main(void)
     int ni = 0, bh = -1;
     int okp = orc_pnp_solve(Xw, uv, 40, K, &pp, R, tt, idx, &ni, NULL, NULL, &bh);
     printf("pnp ok=%d inliers=%d\n", okp, ni);
+    // refinement (row f4): two-view on 300 points (more than one point per partial sum), then motion-only
+    {
+        enum { M = 300 };
+        static double q1[2 * M], q2[2 * M], Xg[3 * M], Xo[3 * M], pc[9 * M], wc[9 * M];
+        const double Rg[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tg[3] = {0.3, 0.0, 0.0};
+        for (int i = 0; i < M; ++i) {
+            double x = rnd() * 2 - 1, y = rnd() * 2 - 1, z = 4 + rnd();
+            q1[2 * i] = 525 * x / z + 320 + (rnd() - 0.5); q1[2 * i + 1] = 525 * y / z + 240 + (rnd() - 0.5);
+            q2[2 * i] = 525 * (x - 0.3) / z + 320 + (rnd() - 0.5); q2[2 * i + 1] = 525 * y / z + 240 + (rnd() - 0.5);
+            Xg[3 * i] = x + 0.01 * (rnd() - 0.5); Xg[3 * i + 1] = y; Xg[3 * i + 2] = z;
+            for (int k = 0; k < 9; ++k) wc[9 * i + k] = (k % 4 == 0) ? 1e-4 : 0.0;
+        }
+        orc_refine_params rp;
+        orc_refine_params_default(&rp);
+        double Ro[9], to[3], cov[36], err = 0;
+        int it = 0;
+        int okr = orc_sfm_refine(q1, NULL, q2, NULL, M, K, Rg, tg, Xg, &rp, Ro, to, cov, Xo, pc, &err, &it);
+        int okq = orc_pnp_refine(Xg, wc, q1, NULL, M, K, Rg, tg, &rp, Ro, to, cov, &err, &it);
+        okq &= orc_sfm_refine(q1, NULL, q2, NULL, 1, K, Rg, tg, Xg, &rp, Ro, to, cov, Xo, pc, &err, &it);
+        printf("refine ok=%d %d\n", okr, okq);
+    }
     free(d1); free(d2); free(k1); free(k2); free(m); free(mask); free(pts); free(idx);
     return 0;
 }

@@ -203,6 +203,125 @@ static void pnp_solve_cube()
     for (int i = 0; i < 6; ++i) ASSERT_EQUAL(se3[i], got[i], tol);
 }
 
+static double get_gaussian(std::mt19937 &g, double mean, double stddev)
+{   // test/unit-test-helper.cpp:6-13 (std::normal_distribution there as well; the seed is ours)
+    return std::normal_distribution<double>(mean, stddev)(g);
+}
+
+static void sfm_refine_L_shape()
+{   // test/test-sfm.cpp:157-286
+    const ScalarType tol = 0.025;
+    std::mt19937 g(2024);
+    Rig r = make_rig(RIG_TYPE::L_SHAPE, SO3(1.5, 0.7, 0.0), 0.5);
+    const ScalarType c_noise = 5e-3, p_noise = 5e-3;
+    std::vector<Point2Estimate> p1e, p2e;
+    for (const auto &p : r.ip1) {
+        Point2Uncertainty C = sqr(c_noise) * Matrix2Type::Identity();
+        p1e.emplace_back(Point2(p.x + get_gaussian(g, 0, c_noise), p.y + get_gaussian(g, 0, c_noise)), C);
+    }
+    for (const auto &p : r.ip2) {
+        Point2Uncertainty C = sqr(c_noise) * Matrix2Type::Identity();
+        p2e.emplace_back(Point2(p.x + get_gaussian(g, 0, c_noise), p.y + get_gaussian(g, 0, c_noise)), C);
+    }
+    Vector6Type delta{get_gaussian(g, 0, 5e-3), get_gaussian(g, 0, 5e-3), get_gaussian(g, 0, 5e-3),
+                      get_gaussian(g, 0, 1e-2), get_gaussian(g, 0, 1e-2), get_gaussian(g, 0, 1e-2)};
+    Transformation guess = SE3::exp(delta) * r.P1 * r.P2.inverse();
+    std::vector<Point3> pg;
+    for (const auto &p : r.X)
+        pg.emplace_back(p[0] + get_gaussian(g, 0, p_noise), p[1] + get_gaussian(g, 0, p_noise), p[2] + get_gaussian(g, 0, p_noise));
+    TransformationEstimate est;
+    std::vector<Point3Estimate> pe;
+    ScalarType error = -1;
+    ASSERT_TRUE(sfm_refine(p1e, p2e, r.K, guess, pg, est, pe, error));
+    const Vector6Type expect{1, 0, 0, 0, 0, 0}, got = est.mean().ln();
+    for (int i = 0; i < 6; ++i) ASSERT_EQUAL(expect[i], got[i], tol);
+    ASSERT_TRUE(pe.size() == r.X.size());
+    for (size_t i = 0; i < pe.size(); ++i)
+        for (int j = 0; j < 3; ++j) ASSERT_EQUAL(r.X[i][j], pe[i].mean()[j], tol);
+    ASSERT_TRUE(error >= 0 && error < 100);
+    for (int i = 0; i < 6; ++i) ASSERT_TRUE(est.covar()(i, i) > 0 && est.covar()(i, i) < 1e-3);   // a proper covariance
+    for (const auto &q : pe) ASSERT_TRUE(q.covar()(0, 0) > 0 && q.covar()(2, 2) > 0);
+}
+
+static void pnp_refine_L_shape()
+{   // test/test-pnp.cpp:62-160
+    const ScalarType tol = 0.025;
+    std::mt19937 g(7);
+    CameraIntrinsics K = Matrix3Type::Identity();
+    Vector6Type se3{1, 0, 0, 0, 0, 0};
+    CameraExtrinsics P(SE3::exp(se3).inverse());
+    PinholeCamera c(K, P);
+    std::vector<Point3> world = get_rig_points(RIG_TYPE::L_SHAPE, SO3(1.5, 0.7, 0.0), Vector3Type(0.6, 0.0, 3.0), 0.5);
+    std::vector<ImagePoint> image = c.project_points(world);
+    std::vector<Point2Estimate> ie;
+    std::vector<Point3Estimate> we;
+    for (const auto &p : image) {
+        Point2Uncertainty C = sqr(5e-3) * Matrix2Type::Identity();
+        ie.emplace_back(Point2(p.x + get_gaussian(g, 0, 5e-3), p.y + get_gaussian(g, 0, 5e-3)), C);
+    }
+    for (const auto &p : world) {
+        Point3Uncertainty C = Matrix3Type::Identity();
+        for (int k = 0; k < 3; ++k) C(k, k) = sqr(5e-3);
+        we.emplace_back(Point3(p[0] + get_gaussian(g, 0, 5e-3), p[1] + get_gaussian(g, 0, 5e-3), p[2] + get_gaussian(g, 0, 5e-3)), C);
+    }
+    Vector6Type delta{get_gaussian(g, 0, 5e-3), get_gaussian(g, 0, 5e-3), get_gaussian(g, 0, 5e-3),
+                      get_gaussian(g, 0, 5e-3), get_gaussian(g, 0, 5e-3), get_gaussian(g, 0, 5e-3)};
+    Transformation guess = SE3::exp(delta) * P.inverse();
+    TransformationEstimate est;
+    ScalarType error = -1;
+    ASSERT_TRUE(pnp_refine(we, ie, K, guess, est, error));
+    const Vector6Type got = est.mean().ln();
+    for (int i = 0; i < 6; ++i) ASSERT_EQUAL(se3[i], got[i], tol);
+    ASSERT_TRUE(error >= 0);
+}
+
+static void image_pair_refine()
+{   // ImagePair with refine_structure_in_constructor (front-end/image-pair.cpp:67-70,176-238) on planted features
+    std::mt19937 g(5);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::normal_distribution<double> Npx(0.0, 0.3);
+    const int n = 300;
+    CameraIntrinsics K = Matrix3Type::Identity();
+    K(0, 0) = K(1, 1) = 525; K(0, 2) = 320; K(1, 2) = 240;
+    SE3 P2 = SE3::exp(Vector6Type{0.3, 0.02, 0.01, 0.01, 0.03, -0.02}).inverse();
+    std::vector<Point3> X;
+    for (int i = 0; i < n; ++i) X.emplace_back(2 * U(g), 1.5 * U(g), 6 + 3 * U(g));
+    auto ip1 = PinholeCamera(K, SE3()).project_points(X), ip2 = PinholeCamera(K, P2).project_points(X);
+    std::vector<KeyPoint> kp1(n), kp2(n);
+    Mat8u d1, d2;
+    d1.cols = d2.cols = 32;
+    for (int i = 0; i < n; ++i) {
+        kp1[i] = KeyPoint{{(float)(ip1[i].x + Npx(g)), (float)(ip1[i].y + Npx(g))}, 31, 0, 0, 0, -1};
+        kp2[i] = KeyPoint{{(float)(ip2[i].x + Npx(g)), (float)(ip2[i].y + Npx(g))}, 31, 0, 0, 0, -1};
+        uint8_t row[32];
+        for (auto &b : row) b = (uint8_t)(g() & 0xff);
+        d1.push_back_row(row);
+        row[i % 32] ^= 1;   // distance 1 to its partner, ~128 to everything else
+        d2.push_back_row(row);
+    }
+    Frame f1{1, VisualFeature(kp1, d1, 640, 480)}, f2{2, VisualFeature(kp2, d2, 640, 480)};
+    hip::ransac_config().num_hypotheses = 512;
+    hip::ransac_config().sampler = MVS_SAMPLER_PHILOX;
+    hip::ransac_config().seed = 3;
+    hip::ransac_config().max_error_sq = 1e-2;
+    ImagePair::Params prm = ImagePair::get_default_params();
+    ImagePair plain(f1, f2, K, prm);
+    prm.refine_structure_in_constructor = true;
+    ImagePair refined(f1, f2, K, prm);
+    hip::ransac_config() = hip::RansacConfig();
+    ASSERT_TRUE(plain.valid && plain.state() == ImagePair::State::RECONSTRUCTED);
+    ASSERT_TRUE(refined.valid && refined.state() == ImagePair::State::REFINED);
+    ASSERT_TRUE(refined.matched_points.size() == plain.matched_points.size() && refined.matched_points.size() > 200);
+    ASSERT_TRUE(refined.matched_points_covar.size() == refined.matched_points.size());
+    // the refined rotation stays at the truth (0.3 px noise), and the pose moved off the linear estimate
+    const Vector6Type want = P2.inverse().ln(), a = plain.T_pair_to_base.ln(), b = refined.T_pair_to_base.ln();
+    double eb = 0, moved = 0;
+    for (int i = 3; i < 6; ++i) eb += sqr(b[i] - want[i]);
+    for (int i = 0; i < 6; ++i) moved += sqr(b[i] - a[i]);
+    ASSERT_TRUE(eb < 1e-5 && moved > 0);
+    ASSERT_TRUE(refined.error > 0 && refined.T_pair_to_base_covar(0, 0) > 0);
+}
+
 int main()
 {
     try {
@@ -213,6 +332,9 @@ int main()
         RUN(match_visual_features_planted);
         RUN(ransac_estimator_and_image_pair);
         RUN(pnp_solve_cube);
+        RUN(sfm_refine_L_shape);
+        RUN(pnp_refine_L_shape);
+        RUN(image_pair_refine);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION: %s\n", e.what());
         return 2;

@@ -21,7 +21,36 @@ import oracle_lib as o  # noqa: E402
 from mvslam_amd import synth  # noqa: E402
 
 
+def refine_vectors():
+    """sfm_refine / pnp_refine (row f4): pixel-unit two-view problem, the reference's L-shape KAT, a PnP problem"""
+    import test_refine as TR
+
+    K = np.array([[525.0, 0, 320], [0, 525, 240], [0, 0, 1]])
+    pb = TR.two_view_problem(11, 40, K=K, sig=0.5, baseline=0.3, depth=(2.0, 10.0))
+    rs = o.sfm_refine(pb["p1"], pb["cov"], pb["p2"], pb["cov"], pb["K"], pb["Rg"], pb["tg"], pb["Xg"])
+    pl = TR.l_shape_refine_problem(0)
+    rl = o.sfm_refine(pl["p1"], pl["cov"], pl["p2"], pl["cov"], pl["K"], pl["Rg"], pl["tg"], pl["Xg"])
+    pp = TR.pnp_problem(12, 30)
+    rp = o.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
+    assert rs["ok"] and rl["ok"] and rp["ok"]
+    d = {}
+    for tag, prob, res in (("s", pb, rs), ("l", pl, rl)):
+        for k in ("p1", "p2", "cov", "K", "Rg", "tg", "Xg"):
+            d[tag + "_" + k] = prob[k]
+        for k in ("R", "t", "pose_cov", "points", "point_cov", "error", "iterations"):
+            d[tag + "_out_" + k] = res[k]
+    for k in ("X", "wcov", "uv", "icov", "K", "Rg", "tg"):
+        d["p_" + k] = pp[k]
+    for k in ("R", "t", "pose_cov", "error", "iterations"):
+        d["p_out_" + k] = rp[k]
+    np.savez_compressed(os.path.join(HERE, "refine_small.npz"), **d)
+
+
 def main():
+    if sys.argv[1:] == ["refine"]:
+        refine_vectors()
+        print("refine vectors written to", HERE)
+        return
     rng = np.random.default_rng(20261003)
     # ---- matcher: random descriptors with planted matches and constructed ties
     train = rng.integers(0, 256, size=(96, 32), dtype=np.uint8)
@@ -84,6 +113,7 @@ def main():
                         cube_inliers=rc["inliers"], K=Ks, X=Xs, uv=uvs, H=256, seed=np.uint64(5), R=rs["R"], t=rs["t"],
                         inliers=rs["inliers"], best_hyp=rs["best_hyp"],
                         samples=np.stack([o.sample4(5, h, 200) for h in range(256)]))
+    refine_vectors()
     print("golden vectors written to", HERE)
 
 

@@ -193,6 +193,24 @@ def test_oracle_cheirality_point_does_not_break_the_solve():
     assert np.abs(res["t"] - pb["t_true"]).max() < 0.05
 
 
+def _golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "refine_small.npz"))
+
+
+def test_oracle_reproduces_golden_refine_vectors():
+    g = _golden()
+    for tag in ("s", "l"):
+        r = o.sfm_refine(g[tag + "_p1"], g[tag + "_cov"], g[tag + "_p2"], g[tag + "_cov"], g[tag + "_K"], g[tag + "_Rg"],
+                         g[tag + "_tg"], g[tag + "_Xg"])
+        assert r["ok"] and r["iterations"] == int(g[tag + "_out_iterations"])
+        for k in ("R", "t", "points"):
+            assert np.abs(r[k] - g[tag + "_out_" + k]).max() < 1e-12
+        assert abs(r["error"] - float(g[tag + "_out_error"])) <= 1e-12 * r["error"]
+        assert np.abs(r["pose_cov"] - g[tag + "_out_pose_cov"]).max() <= 1e-9 * np.abs(r["pose_cov"]).max()
+    r = o.pnp_refine(g["p_X"], g["p_wcov"], g["p_uv"], g["p_icov"], g["p_K"], g["p_Rg"], g["p_tg"])
+    assert r["ok"] and np.abs(r["R"] - g["p_out_R"]).max() < 1e-12 and np.abs(r["t"] - g["p_out_t"]).max() < 1e-12
+
+
 def test_header_and_ctypes_layouts_agree():
     from mvslam_amd import capi
 
@@ -242,6 +260,24 @@ def test_gpu_sfm_refine_matches_oracle(ctx, m, seed, pix):
     assert np.abs(got["points"] - ref["points"]).max() < 1e-9
     _close(got["pose_cov"], ref["pose_cov"], 1e-7, "pose_cov")
     _close(got["point_cov"], ref["point_cov"], 1e-7, "point_cov")
+
+
+@pytest.mark.gpu
+def test_gpu_refine_against_golden(ctx):
+    """Oracle-free: the committed expected outputs (tests/golden/refine_small.npz)."""
+    g = _golden()
+    for tag in ("s", "l"):
+        r = ctx.sfm_refine(g[tag + "_p1"], g[tag + "_cov"], g[tag + "_p2"], g[tag + "_cov"], g[tag + "_K"], g[tag + "_Rg"],
+                           g[tag + "_tg"], g[tag + "_Xg"])
+        assert r["ok"] and r["iterations"] == int(g[tag + "_out_iterations"])
+        assert np.abs(r["R"] - g[tag + "_out_R"]).max() < 1e-10 and np.abs(r["t"] - g[tag + "_out_t"]).max() < 1e-10
+        assert np.abs(r["points"] - g[tag + "_out_points"]).max() < 1e-9
+        assert abs(r["error"] - float(g[tag + "_out_error"])) <= 1e-10 * float(g[tag + "_out_error"])
+        _close(r["pose_cov"], g[tag + "_out_pose_cov"], 1e-7, "pose_cov")
+        _close(r["point_cov"], g[tag + "_out_point_cov"], 1e-7, "point_cov")
+    r = ctx.pnp_refine(g["p_X"], g["p_wcov"], g["p_uv"], g["p_icov"], g["p_K"], g["p_Rg"], g["p_tg"])
+    assert r["ok"] and np.abs(r["R"] - g["p_out_R"]).max() < 1e-10 and np.abs(r["t"] - g["p_out_t"]).max() < 1e-10
+    _close(r["pose_cov"], g["p_out_pose_cov"], 1e-7, "pose_cov")
 
 
 @pytest.mark.gpu
