@@ -297,6 +297,36 @@ mvs_status mvs_batch_refine(mvs_batch *b, const mvs_refine_params *params, doubl
 /* refined[n_pairs]; points_xyz / point_cov: n_pairs x max_kp x 3 / 9 (NULL to skip), rows [0, results[p].n_points) */
 mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, double *points_xyz, double *point_cov);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row f3: keypoint + descriptor extraction.  Replaces VisualFeature::extract
+ * (vision/visual-feature.cpp:40-49, decl visual-feature.hpp:16-20) = cv::ORB::create(500)->detect + compute
+ * (visual-feature.cpp:12-17).  cv::ORB is OpenCV-internal and its learned sampling pattern is not in the reference
+ * tree: this is ORB's published pipeline with the reference's parameters and the library's own fully specified
+ * resize / blur / ranking / pattern -- keypoints and descriptors are NOT bit-identical to
+ * OpenCV's, they are bit-identical to the CPU oracle's. */
+typedef struct mvs_orb_params {
+    int32_t nfeatures;       /* 500 = MAX_FEATURE_COUNT (visual-feature.cpp:9) */
+    int32_t nlevels;         /* 8, scale factor 1.2 (cv::ORB::create defaults) */
+    int32_t edge_threshold;  /* 31 */
+    int32_t fast_threshold;  /* 20 */
+} mvs_orb_params;
+typedef struct mvs_keypoint { /* layout of cv::KeyPoint (base/image.hpp:37-48 DetectorResultType element) */
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} mvs_keypoint;
+void mvs_orb_params_default(mvs_orb_params *p);
+/* images: n_images x height x width grayscale (CV_8UC1, continuous), host.  keypoints: n_images x nfeatures,
+ * descriptors: n_images x nfeatures x 32, n_keypoints: n_images (rows [0, n_keypoints[i]) are valid; ordered by
+ * pyramid level, then response descending).  MVS_ERR_CAPACITY if a level has more corners than the candidate list
+ * holds (16384) or the image is larger than 65535 in a dimension. */
+mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int width, int height,
+                       const mvs_orb_params *params, mvs_keypoint *keypoints, uint8_t *descriptors,
+                       int32_t *n_keypoints);
+/* Extraction straight into a sequence's resident frame arrays (no host round trip of descriptors): frames
+ * [first, first + count) of `s` get up to max_kp keypoints each (params->nfeatures is overridden by max_kp). */
+mvs_status mvs_seq_upload_images(mvs_seq *s, int first, int count, const uint8_t *images, int width, int height,
+                                 const mvs_orb_params *params, const double K[9]);
+
 #ifdef __cplusplus
 }
 #endif

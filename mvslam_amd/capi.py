@@ -80,6 +80,15 @@ REFINE_DTYPE = np.dtype([("ok", "<i4"), ("iterations", "<i4"), ("error", "<f8"),
                          ("t", "<f8", (3,)), ("pose_cov", "<f8", (6, 6))])
 
 
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),
+                ("fast_threshold", C.c_int32)]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])   # cv::KeyPoint
+
+
 class WorkStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers")]
 
@@ -93,6 +102,7 @@ EXPORTS = [
     "mvs_batch_copy_results_device", "mvs_pnp_params_default", "mvs_pnp_solve", "mvs_seq_create", "mvs_seq_destroy",
     "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
     "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
+    "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images",
 ]
 
 
@@ -140,6 +150,14 @@ def default_params(**kw):
 def default_pnp_params(**kw):
     p = PnpParams()
     lib().mvs_pnp_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_orb_params(**kw):
+    p = OrbParams()
+    lib().mvs_orb_params_default(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -286,6 +304,21 @@ class Context:
                                  _ptr(t, C.c_double), _ptr(idx, C.c_int64), C.byref(ni), C.byref(bh))
         self._check(st, "mvs_pnp_solve", allow_no_model=True)
         return dict(ok=st == MVS_OK, R=R, t=t, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
+
+    # VisualFeature::extract(image) for a stack of equally sized grayscale images [B, H, W]
+    def extract(self, images, params=None):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        if images.ndim == 2:
+            images = images[None]
+        B, H, W = images.shape
+        params = params or default_orb_params()
+        kp = np.zeros((B, params.nfeatures), dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((B, params.nfeatures, 32), dtype=np.uint8)
+        n = np.zeros(B, dtype=np.int32)
+        st = lib().mvs_extract(self._h, _ptr(images, C.c_uint8), C.c_int(B), C.c_int(W), C.c_int(H), C.byref(params),
+                               kp.ctypes.data_as(C.c_void_p), _ptr(desc, C.c_uint8), _ptr(n, C.c_int32))
+        self._check(st, "mvs_extract")
+        return dict(kp=kp, desc=desc, n=n)
 
     # sfm_refine(p1_estimates, p2_estimates, K, pose2in1_guess, pointsin1_guess, pose2in1_estimate, pointsin1_estimate, error)
     def sfm_refine(self, p1, cov1, p2, cov2, K, R_guess, t_guess, points_guess, params=None, point_cov=True):
@@ -499,6 +532,16 @@ class Sequence:
         st = lib().mvs_seq_time(self._h, C.byref(params), C.byref(pnp_params), C.c_int(warmup), C.c_int(steps), C.byref(ms))
         self.ctx._check(st, "mvs_seq_time")
         return ms.value
+
+    def upload_images(self, first, images, K, params=None):
+        """extract keypoints + descriptors of frames [first, first + len(images)) on the device, straight into the
+        sequence's resident frame arrays (up to max_kp per frame)"""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, H, W = images.shape
+        params = params or default_orb_params()
+        st = lib().mvs_seq_upload_images(self._h, C.c_int(first), C.c_int(B), _ptr(images, C.c_uint8), C.c_int(W),
+                                         C.c_int(H), C.byref(params), _ptr(_f64(K, (9,)), C.c_double))
+        self.ctx._check(st, "mvs_seq_upload_images")
 
     def download_pairs(self):
         P, N = self.n_frames - 1, self.max_kp

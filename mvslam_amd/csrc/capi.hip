@@ -25,6 +25,9 @@ struct mvs_ctx {
     size_t pnp_bytes = 0;
     void *d_ref = nullptr;      // sfm_refine / pnp_refine workspace
     size_t ref_bytes = 0;
+    void *d_orb = nullptr;      // extraction workspace
+    size_t orb_bytes = 0;
+    bool orb_ready = false;
 };
 
 struct mvs_seq;
@@ -242,6 +245,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->d_orb) (void)hipFree(ctx->d_orb);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1562,6 +1566,197 @@ mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, 
         HIP_TRY(ctx, hipMemcpyAsync(point_cov, d.point_cov, P * N * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return MVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// extraction (row f3)
+void mvs_orb_params_default(mvs_orb_params *p)
+{
+    if (!p)
+        return;
+    p->nfeatures = 500;
+    p->nlevels = 8;
+    p->edge_threshold = 31;
+    p->fast_threshold = 20;
+}
+
+static void philox_host(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4])
+{   // Philox4x32-10 (Random123), counter (c0, c1, 0, 0)
+    uint32_t c[4] = {c0, c1, 0, 0};
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1,
+                       n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    std::memcpy(out, c, sizeof(c));
+}
+
+// the 256 point pairs of the steered-BRIEF tests
+static void orb_pattern_host(int8_t P[1024])
+{
+    for (int i = 0; i < 256; ++i) {
+        uint32_t w[8];
+        philox_host((uint32_t)i, 0, 0x0B5EED00u, 0x31u, w);
+        philox_host((uint32_t)i, 1, 0x0B5EED00u, 0x31u, w + 4);
+        int c[4];
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = w[2 * k], b = w[2 * k + 1];
+            const int u = (int)((a & 0xffffu) + (a >> 16) + (b & 0xffffu) + (b >> 16)) - 131072;
+            c[k] = std::max(-13, std::min(13, (u * 11) / 65536));
+        }
+        if (c[0] == c[2] && c[1] == c[3])
+            c[2] = c[0] + (c[0] < 0 ? 3 : -3);
+        for (int k = 0; k < 4; ++k)
+            P[4 * i + k] = (int8_t)c[k];
+    }
+}
+
+// pyramid layout and per-level quotas (cv::ORB: n_l proportional to 1.2^-l, the last level takes the remainder)
+static bool orb_layout_host(int w, int h, const mvs_orb_params &p, OrbDev &d, size_t &pixels)
+{
+    if (p.nlevels < 1 || p.nlevels > kOrbMaxLevels || p.nfeatures < 1)
+        return false;
+    double s = 1.0;
+    pixels = 0;
+    for (int l = 0; l < p.nlevels; ++l) {
+        OrbLevel &L = d.level[l];
+        L.w = (int)std::lrint((double)w / s);
+        L.h = (int)std::lrint((double)h / s);
+        L.scale = (float)s;
+        L.offset = pixels;
+        pixels += (size_t)std::max(L.w, 0) * std::max(L.h, 0);
+        s = s * 1.2;
+    }
+    const double factor = 1.0 / 1.2;
+    double fn = 1.0;
+    for (int l = 0; l < p.nlevels; ++l)
+        fn = fn * factor;
+    double nd = (double)p.nfeatures * (1.0 - factor) / (1.0 - fn);
+    int sum = 0;
+    for (int l = 0; l < p.nlevels - 1; ++l) {
+        d.level[l].n_keep = (int)std::lrint(nd);
+        sum += d.level[l].n_keep;
+        nd = nd * factor;
+    }
+    d.level[p.nlevels - 1].n_keep = std::max(p.nfeatures - sum, 0);
+    return true;
+}
+
+// runs the extraction of n images (host pointer) through the ctx workspace; outputs go to the given DEVICE arrays
+// (desc / kp_xy / n_kp may belong to a sequence) and, when kp_rec_out is non-null, records are also left in the workspace
+static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int h, const mvs_orb_params &prm,
+                          uint8_t *d_desc_ext, float *d_kp_xy_ext, int32_t *d_n_ext, OrbDev &d)
+{
+    if (w < 1 || h < 1 || w > 65535 || h > 65535)
+        return MVS_ERR_CAPACITY;
+    if (prm.fast_threshold < 1 || prm.fast_threshold > 254 || prm.edge_threshold < 19)
+        return MVS_ERR_INVALID_ARG;
+    d = OrbDev{};
+    size_t T = 0;
+    if (!orb_layout_host(w, h, prm, d, T))
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->orb_ready) {
+        HIP_TRY(ctx, orb_prepare(kOrbCandCap));
+        ctx->orb_ready = true;
+    }
+    const size_t B = (size_t)n, L = (size_t)prm.nlevels, NF = (size_t)prm.nfeatures;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t off = 0;
+    const size_t o_pyr = off; off = up(off + T * B);
+    const size_t o_score = off; off = up(off + T * B);
+    const size_t o_blur = off; off = up(off + T * B);
+    const size_t o_tmp = off; off = up(off + (size_t)w * h * B * 2);
+    const size_t o_keys = off; off = up(off + B * L * kOrbCandCap * 8);
+    const size_t o_cc = off; off = up(off + B * L * 4);
+    const size_t o_sel = off; off = up(off + B * L * NF * sizeof(OrbSel));
+    const size_t o_sc = off; off = up(off + B * L * 4);
+    const size_t o_ovf = off; off = up(off + 4);
+    const size_t o_pat = off; off = up(off + 1024);
+    const size_t o_kp = off; off = up(off + B * NF * sizeof(mvs_keypoint));
+    const size_t o_desc = off; off = up(off + B * NF * 32);
+    const size_t o_n = off; off = up(off + B * 4);
+    if (ctx->orb_bytes < off) {
+        if (ctx->d_orb) (void)hipFree(ctx->d_orb);
+        ctx->d_orb = nullptr;
+        ctx->orb_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_orb, off));
+        ctx->orb_bytes = off;
+    }
+    char *base = static_cast<char *>(ctx->d_orb);
+    d.n_images = n;
+    d.n_levels = prm.nlevels;
+    d.nfeatures = prm.nfeatures;
+    d.edge = prm.edge_threshold;
+    d.fast_threshold = prm.fast_threshold;
+    d.cand_cap = kOrbCandCap;
+    d.pyr = reinterpret_cast<uint8_t *>(base + o_pyr);
+    d.score = reinterpret_cast<uint8_t *>(base + o_score);
+    d.blur = reinterpret_cast<uint8_t *>(base + o_blur);
+    d.tmp16 = reinterpret_cast<uint16_t *>(base + o_tmp);
+    d.cand_keys = reinterpret_cast<uint64_t *>(base + o_keys);
+    d.cand_count = reinterpret_cast<int32_t *>(base + o_cc);
+    d.sel = reinterpret_cast<OrbSel *>(base + o_sel);
+    d.sel_count = reinterpret_cast<int32_t *>(base + o_sc);
+    d.overflow = reinterpret_cast<int32_t *>(base + o_ovf);
+    d.pattern = reinterpret_cast<int8_t *>(base + o_pat);
+    d.kp = reinterpret_cast<mvs_keypoint *>(base + o_kp);
+    d.desc = d_desc_ext ? d_desc_ext : reinterpret_cast<uint8_t *>(base + o_desc);
+    d.n_kp = d_n_ext ? d_n_ext : reinterpret_cast<int32_t *>(base + o_n);
+    d.kp_xy = d_kp_xy_ext;
+    hipStream_t s = ctx->stream;
+    int8_t pat[1024];
+    orb_pattern_host(pat);
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_pat, pat, sizeof(pat), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d.pyr, images, (size_t)w * h * B, hipMemcpyHostToDevice, s));  // level 0 = the input
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // `pat` lives on this frame
+    launch_orb(d, s);
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, d.overflow, sizeof(ovf), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return ovf ? MVS_ERR_CAPACITY : MVS_OK;
+}
+
+mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int width, int height,
+                       const mvs_orb_params *params, mvs_keypoint *keypoints, uint8_t *descriptors, int32_t *n_keypoints)
+{
+    if (!ctx || !images || !params || !keypoints || !descriptors || !n_keypoints || n_images < 1)
+        return MVS_ERR_INVALID_ARG;
+    OrbDev d;
+    const mvs_status st = orb_run(ctx, images, n_images, width, height, *params, nullptr, nullptr, nullptr, d);
+    if (st != MVS_OK)
+        return st;
+    const size_t B = n_images, NF = params->nfeatures;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(keypoints, d.kp, B * NF * sizeof(mvs_keypoint), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(descriptors, d.desc, B * NF * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(n_keypoints, d.n_kp, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MVS_OK;
+}
+
+mvs_status mvs_seq_upload_images(mvs_seq *q, int first, int count, const uint8_t *images, int width, int height,
+                                 const mvs_orb_params *params, const double K[9])
+{
+    if (!q || !images || !params || first < 0 || count < 1 || first + count > q->n_frames)
+        return MVS_ERR_INVALID_ARG;
+    const BatchDev &bd = q->batch->d;
+    if (bd.desc_words != 8)
+        return MVS_ERR_INVALID_ARG;   // the extractor writes 256-bit descriptors
+    mvs_orb_params prm = *params;
+    prm.nfeatures = bd.max_kp;
+    const size_t N = bd.max_kp, off = first;
+    OrbDev d;
+    mvs_status st = orb_run(q->ctx, images, count, width, height, prm,
+                            reinterpret_cast<uint8_t *>(const_cast<uint32_t *>(bd.desc1)) + off * N * 32,
+                            const_cast<float *>(bd.kp1) + off * N * 2, const_cast<int32_t *>(bd.n1) + off, d);
+    if (st != MVS_OK)
+        return st;
+    return K ? mvs_seq_upload(q, first, count, nullptr, nullptr, nullptr, K) : MVS_OK;
 }
 
 }  // extern "C"

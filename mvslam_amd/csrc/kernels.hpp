@@ -187,6 +187,41 @@ void launch_refine_gather(const BatchDev &b, int n_active, double sigma_px, doub
                           double *pose0, double *obs0, double *obs1, double *oinfo0, double *oinfo1, double *pts0,
                           double *pinfo, hipStream_t stream);
 
+// ---- VisualFeature::extract (row f3): ORB-style extraction for a batch of equally sized images ----------------
+constexpr int kOrbMaxLevels = 16;
+constexpr int kOrbCandCap = 16384;   // corners per (image, level) after non-maximum suppression (128 KB of LDS keys)
+
+struct OrbLevel {
+    int w, h;
+    int n_keep;        // n_l: keypoints kept at this level
+    float scale;       // 1.2^l
+    size_t offset;     // pixels of one image's pyramid before this level
+};
+struct OrbSel {        // a selected keypoint of one level
+    int32_t x, y;
+    float harris;
+};
+struct OrbDev {
+    int n_images, n_levels, nfeatures, edge, fast_threshold, cand_cap;
+    OrbLevel level[kOrbMaxLevels];
+    uint8_t *pyr;          // [level][image][h_l][w_l]; level 0 = the input images
+    uint8_t *score;        // same layout: FAST scores
+    uint8_t *blur;         // same layout: blurred levels
+    uint16_t *tmp16;       // [image][h_0][w_0] row-pass buffer
+    uint64_t *cand_keys;   // [image][level][cand_cap]
+    int32_t *cand_count;   // [image][level]
+    OrbSel *sel;           // [image][level][nfeatures]
+    int32_t *sel_count;    // [image][level]
+    int32_t *overflow;     // [1] set when a level had more than cand_cap corners
+    const int8_t *pattern; // [256][4]
+    mvs_keypoint *kp;      // [image][nfeatures]
+    uint8_t *desc;         // [image][nfeatures][32]
+    int32_t *n_kp;         // [image]
+    float *kp_xy;          // optional [image][nfeatures][2] (the layout the matcher reads), may be null
+};
+hipError_t orb_prepare(int cand_cap);
+void launch_orb(const OrbDev &d, hipStream_t stream);
+
 // launch wrappers (all asynchronous on `stream`)
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
 void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);

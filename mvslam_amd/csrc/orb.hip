@@ -1,0 +1,409 @@
+// orb.hip -- VisualFeature::extract (vision/visual-feature.cpp:12-17,40-49 = cv::ORB::create(500) detect + compute;
+// SURVEY section 8 row f3) for a batch of equally sized grayscale images.
+//
+// cv::ORB is OpenCV-internal and its learned sampling pattern is not in the reference tree, so this is ORB's PUBLISHED
+// pipeline with the reference's parameters and the build's own, fully specified choices where OpenCV's are out of
+// reach (the CPU oracle oracle/mvs_orb_oracle.c follows the same specification bit for bit):
+//   resize_kernel    level l from level l-1: pixel-centre bilinear in integer arithmetic (11-bit weights from exact
+//                    rationals, (sum + 2^21) >> 22)                                           thread per pixel
+//   fast_kernel      FAST-9/16 score = the largest threshold at which the pixel is still a corner  thread per pixel
+//   nms_kernel       strict 3x3 maximum inside the edge margin -> rank key (score desc, y, x), appended with one atomic
+//                    per corner; the ORDER of the list does not matter, the select kernel sorts it
+//   select_kernel    one workgroup per (level, image): bitonic sort of the keys in LDS, keep 2 n_l, Harris response
+//                    (7x7, k = 0.04) of those, sort again by (response desc, y, x), keep n_l     (cv::ORB's retainBest)
+//   blur_h / blur_v  7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18}, BORDER_REFLECT_101
+//   describe_kernel  one wavefront per keypoint: intensity-centroid moments over the radius-15 disc (lanes stride the
+//                    disc rows, butterfly sum), cos / sin = moments / hypot (no trigonometry), 256 steered BRIEF tests
+//                    on the blurred level (lane b < 32 builds byte b), cv::KeyPoint record
+// Everything is integer or single IEEE float operations in a stated order, so GPU and oracle agree bit for bit.
+#include "kernels.hpp"
+
+#include "device_math.hpp"
+
+namespace mvs {
+
+namespace {
+
+__constant__ int kFastDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__constant__ int kFastDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+__constant__ int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ int kGauss[7] = {18, 34, 49, 54, 49, 34, 18};
+
+__global__ void resize_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (dx >= dw || dy >= dh)
+        return;
+    src += (size_t)blockIdx.z * sw * sh;
+    dst += (size_t)blockIdx.z * dw * dh;
+    const long long ny = (long long)(2 * dy + 1) * sh - dh, dny = 2LL * dh;
+    long long sy = ny >= 0 ? ny / dny : -1;
+    const long long fy = ny - sy * dny;
+    int wy = (int)((fy * 4096 + dny) / (2 * dny));
+    if (sy < 0) sy = 0, wy = 0;
+    long long sy1 = sy + 1;
+    if (sy >= sh - 1) sy = sh - 1, sy1 = sh - 1;
+    const long long nx = (long long)(2 * dx + 1) * sw - dw, dnx = 2LL * dw;
+    long long sx = nx >= 0 ? nx / dnx : -1;
+    const long long fx = nx - sx * dnx;
+    int wx = (int)((fx * 4096 + dnx) / (2 * dnx));
+    if (sx < 0) sx = 0, wx = 0;
+    long long sx1 = sx + 1;
+    if (sx >= sw - 1) sx = sw - 1, sx1 = sw - 1;
+    const uint32_t p00 = src[sy * sw + sx], p01 = src[sy * sw + sx1], p10 = src[sy1 * sw + sx], p11 = src[sy1 * sw + sx1];
+    const uint32_t v = p00 * (uint32_t)((2048 - wx) * (2048 - wy)) + p01 * (uint32_t)(wx * (2048 - wy)) +
+                       p10 * (uint32_t)((2048 - wx) * wy) + p11 * (uint32_t)(wx * wy);
+    dst[(size_t)dy * dw + dx] = (uint8_t)((v + (1u << 21)) >> 22);
+}
+
+__global__ void fast_kernel(const uint8_t *img, int W, int H, int threshold, uint8_t *score)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H)
+        return;
+    img += (size_t)blockIdx.z * W * H;
+    score += (size_t)blockIdx.z * W * H;
+    int out = 0;
+    if (x >= 3 && y >= 3 && x < W - 3 && y < H - 3) {
+        const int c = img[y * W + x];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            d[k] = (int)img[(y + kFastDy[k]) * W + (x + kFastDx[k])] - c;
+        int best = -256;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int mb = 255, md = 255;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int v = d[(k + j) & 15];
+                mb = min(mb, v);
+                md = min(md, -v);
+            }
+            best = max(best, max(mb, md));
+        }
+        const int s = best - 1;
+        if (s >= threshold)
+            out = s;
+    }
+    score[y * W + x] = (uint8_t)out;
+}
+
+__device__ __forceinline__ uint64_t rank_key(uint32_t value_desc, int y, int x)
+{
+    return ((uint64_t)(0xffffffffu - value_desc) << 32) | ((uint64_t)(uint32_t)y << 16) | (uint32_t)x;
+}
+
+__global__ void nms_kernel(const uint8_t *score, int W, int H, int edge, uint64_t *keys, int32_t *count, int cap,
+                           int level, int n_levels)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x + edge, y = blockIdx.y * blockDim.y + threadIdx.y + edge;
+    if (x >= W - edge || y >= H - edge)
+        return;
+    const int b = blockIdx.z;
+    score += (size_t)b * W * H;
+    const int s = score[y * W + x];
+    if (!s)
+        return;
+    bool is_max = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+            if ((dx || dy) && score[(y + dy) * W + x + dx] >= s)
+                is_max = false;
+    if (!is_max)
+        return;
+    const size_t slot = (size_t)b * n_levels + level;
+    const int idx = atomicAdd(&count[slot], 1);
+    if (idx < cap)
+        keys[slot * cap + idx] = rank_key((uint32_t)s, y, x);
+}
+
+__device__ __forceinline__ float harris_at(const uint8_t *img, int W, int x0, int y0)
+{
+    int a = 0, b = 0, c = 0;
+    for (int dy = -3; dy <= 3; ++dy)
+        for (int dx = -3; dx <= 3; ++dx) {
+            const uint8_t *p = img + (y0 + dy) * W + (x0 + dx);
+            const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-W + 1] - (int)p[-W - 1]) + ((int)p[W + 1] - (int)p[W - 1]);
+            const int Iy = ((int)p[W] - (int)p[-W]) * 2 + ((int)p[W - 1] - (int)p[-W - 1]) + ((int)p[W + 1] - (int)p[-W + 1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            c += Ix * Iy;
+        }
+    const float scale = 1.0f / (4.0f * 7.0f * 255.0f);
+    const float scale4 = ((scale * scale) * scale) * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float t1 = fa * fb, t2 = fc * fc, t3 = fa + fb;
+    return ((t1 - t2) - (0.04f * t3) * t3) * scale4;
+}
+
+__device__ __forceinline__ uint32_t float_ordered(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ascending bitonic sort of n (power of two) keys in LDS by the whole workgroup
+__device__ void bitonic_sort(uint64_t *k, int n)
+{
+    for (int size = 2; size <= n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = k[lo], b = k[hi];
+                if ((a > b) == up) {
+                    k[lo] = b;
+                    k[hi] = a;
+                }
+            }
+        }
+    __syncthreads();
+}
+
+using Sel = OrbSel;
+
+__global__ __launch_bounds__(1024) void select_kernel(OrbDev d, int level)
+{
+    extern __shared__ uint64_t keys[];
+    const int b = blockIdx.x;
+    const OrbLevel &L = d.level[level];
+    const size_t slot = (size_t)b * d.n_levels + level;
+    const int found = d.cand_count[slot];
+    const int c = min(found, d.cand_cap);
+    int n2 = 1;
+    while (n2 < c)
+        n2 <<= 1;
+    const uint64_t *src = d.cand_keys + slot * d.cand_cap;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x)
+        keys[i] = i < c ? src[i] : ~0ull;
+    bitonic_sort(keys, n2);
+    // retainBest(2 n_l) by FAST score, then Harris on the survivors
+    const int keep1 = min(c, 2 * L.n_keep);
+    const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * L.w * L.h;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        uint64_t k = ~0ull;
+        if (i < keep1) {
+            const int x = (int)(keys[i] & 0xffffu), y = (int)((keys[i] >> 16) & 0xffffu);
+            k = rank_key(float_ordered(harris_at(img, L.w, x, y)), y, x);
+        }
+        keys[i] = k;   // slot i is read and written by this thread only
+    }
+    int m2 = 1;
+    while (m2 < keep1)
+        m2 <<= 1;
+    bitonic_sort(keys, max(m2, 1));
+    const int keep2 = min(keep1, L.n_keep);
+    Sel *sel = d.sel + slot * d.nfeatures;
+    for (int i = threadIdx.x; i < keep2; i += blockDim.x) {
+        const uint64_t k = keys[i];
+        const uint32_t ord = 0xffffffffu - (uint32_t)(k >> 32);
+        const uint32_t bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+        sel[i].x = (int)(k & 0xffffu);
+        sel[i].y = (int)((k >> 16) & 0xffffu);
+        sel[i].harris = __uint_as_float(bits);
+    }
+    if (threadIdx.x == 0) {
+        d.sel_count[slot] = keep2;
+        if (found > d.cand_cap)
+            atomicOr(d.overflow, 1);
+    }
+}
+
+__global__ void blur_h_kernel(const uint8_t *img, int W, int H, uint16_t *tmp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H)
+        return;
+    img += (size_t)blockIdx.z * W * H;
+    tmp += (size_t)blockIdx.z * W * H;
+    int s = 0;
+#pragma unroll
+    for (int k = -3; k <= 3; ++k) {
+        int xx = x + k;
+        if (xx < 0) xx = -xx;
+        if (xx >= W) xx = 2 * (W - 1) - xx;
+        s += kGauss[k + 3] * img[y * W + xx];
+    }
+    tmp[y * W + x] = (uint16_t)s;
+}
+
+__global__ void blur_v_kernel(const uint16_t *tmp, int W, int H, uint8_t *out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H)
+        return;
+    tmp += (size_t)blockIdx.z * W * H;
+    out += (size_t)blockIdx.z * W * H;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = -3; k <= 3; ++k) {
+        int yy = y + k;
+        if (yy < 0) yy = -yy;
+        if (yy >= H) yy = 2 * (H - 1) - yy;
+        s += (uint32_t)kGauss[k + 3] * tmp[yy * W + x];
+    }
+    out[y * W + x] = (uint8_t)((s + 32768u) >> 16);
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * 57.29577951308232f, p3 = -0.3258083974640975f * 57.29577951308232f,
+                p5 = 0.1555786518463281f * 57.29577951308232f, p7 = -0.04432655554792128f * 57.29577951308232f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
+// grid (n_levels, n_images), 256 threads = 4 wavefronts, one keypoint per wavefront at a time
+__global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
+{
+    const int level = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const OrbLevel &L = d.level[level];
+    const size_t slot0 = (size_t)b * d.n_levels;
+    int offset = 0;
+    for (int l = 0; l < level; ++l)
+        offset += d.sel_count[slot0 + l];
+    const int n = d.sel_count[slot0 + level];
+    if (level == d.n_levels - 1 && threadIdx.x == 0)
+        d.n_kp[b] = offset + n;
+    const int W = L.w;
+    const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * L.w * L.h;
+    const uint8_t *blr = d.blur + L.offset * d.n_images + (size_t)b * L.w * L.h;
+    const Sel *sel = d.sel + (slot0 + level) * d.nfeatures;
+    const float fs = L.scale;
+    for (int i = wave; i < n; i += 4) {
+        const int x0 = sel[i].x, y0 = sel[i].y;
+        // intensity-centroid moments: lane v < 16 takes disc rows +-v (row 0 once)
+        int m10 = 0, m01 = 0;
+        if (lane < 16) {
+            const uint8_t *c = img + y0 * W + x0;
+            const int v = lane, dmax = kUmax[v];
+            if (v == 0) {
+                for (int u = -15; u <= 15; ++u)
+                    m10 += u * c[u];
+            } else {
+                int vs = 0;
+                for (int u = -dmax; u <= dmax; ++u) {
+                    const int vp = c[u + v * W], vm = c[u - v * W];
+                    vs += vp - vm;
+                    m10 += u * (vp + vm);
+                }
+                m01 = v * vs;
+            }
+        }
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) {   // integer sums: any order gives the same result
+            m10 += __shfl_xor(m10, s, 64);
+            m01 += __shfl_xor(m01, s, 64);
+        }
+        m10 = __shfl(m10, 0, 64);
+        m01 = __shfl(m01, 0, 64);
+        const float f10 = (float)m10, f01 = (float)m01;
+        const float h2 = f10 * f10 + f01 * f01;
+        float ca = 1.0f, sa = 0.0f;
+        if (h2 > 0.0f) {
+            const float hh = sqrtf(h2);
+            ca = f10 / hh;
+            sa = f01 / hh;
+        }
+        const size_t o = (size_t)b * d.nfeatures + offset + i;
+        if (lane < 32) {
+            const uint8_t *ctr = blr + y0 * W + x0;
+            unsigned v = 0;
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const int8_t *q = d.pattern + 4 * (8 * lane + bit);
+                const float x1 = (float)q[0], y1 = (float)q[1], x2 = (float)q[2], y2 = (float)q[3];
+                const int ix1 = (int)rintf(x1 * ca - y1 * sa), iy1 = (int)rintf(x1 * sa + y1 * ca);
+                const int ix2 = (int)rintf(x2 * ca - y2 * sa), iy2 = (int)rintf(x2 * sa + y2 * ca);
+                v |= (unsigned)(ctr[iy1 * W + ix1] < ctr[iy2 * W + ix2]) << bit;
+            }
+            d.desc[o * 32 + lane] = (uint8_t)v;
+        }
+        if (lane == 0) {
+            mvs_keypoint k;
+            k.x = (float)x0 * fs;
+            k.y = (float)y0 * fs;
+            k.size = 31.0f * fs;
+            k.angle = fast_atan2_deg(f01, f10);
+            k.response = sel[i].harris;
+            k.octave = level;
+            k.class_id = -1;
+            d.kp[o] = k;
+            if (d.kp_xy) {
+                d.kp_xy[2 * o] = k.x;
+                d.kp_xy[2 * o + 1] = k.y;
+            }
+        }
+    }
+}
+
+__global__ void orb_clear_kernel(int32_t *count, int n, int32_t *overflow)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        count[i] = 0;
+    if (i == 0)
+        *overflow = 0;
+}
+
+}  // namespace
+
+size_t orb_sel_bytes() { return sizeof(Sel); }
+
+hipError_t orb_prepare(int cand_cap)
+{
+    return hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)cand_cap * sizeof(uint64_t)));
+}
+
+void launch_orb(const OrbDev &d, hipStream_t stream)
+{
+    const int B = d.n_images;
+    if (B <= 0)
+        return;
+    const int slots = B * d.n_levels;
+    hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.cand_count, slots, d.overflow);
+    hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.sel_count, slots, d.overflow);
+    const dim3 blk(32, 8);
+    for (int l = 0; l < d.n_levels; ++l) {
+        const OrbLevel &L = d.level[l];
+        if (L.w < 1 || L.h < 1)
+            break;
+        uint8_t *img = d.pyr + L.offset * B;
+        const dim3 grid((L.w + 31) / 32, (L.h + 7) / 8, B);
+        if (l > 0) {
+            const OrbLevel &Pv = d.level[l - 1];
+            hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, img, L.w, L.h);
+        }
+        if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
+            continue;
+        uint8_t *score = d.score + L.offset * B;
+        hipLaunchKernelGGL(fast_kernel, grid, blk, 0, stream, img, L.w, L.h, d.fast_threshold, score);
+        const dim3 gin((L.w - 2 * d.edge + 31) / 32, (L.h - 2 * d.edge + 7) / 8, B);
+        hipLaunchKernelGGL(nms_kernel, gin, blk, 0, stream, score, L.w, L.h, d.edge, d.cand_keys, d.cand_count, d.cand_cap, l,
+                           d.n_levels);
+        hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), (size_t)d.cand_cap * sizeof(uint64_t), stream, d, l);  // LDS limit raised in orb_prepare()
+        hipLaunchKernelGGL(blur_h_kernel, grid, blk, 0, stream, img, L.w, L.h, d.tmp16);
+        hipLaunchKernelGGL(blur_v_kernel, grid, blk, 0, stream, d.tmp16, L.w, L.h, d.blur + L.offset * B);
+    }
+    hipLaunchKernelGGL(describe_kernel, dim3(d.n_levels, B), dim3(256), 0, stream, d);
+}
+
+}  // namespace mvs

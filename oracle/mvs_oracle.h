@@ -208,6 +208,32 @@ int orc_pnp_refine(const double *world, const double *world_cov, const double *i
                    const double K[9], const double R_guess[9], const double t_guess[3], const orc_refine_params *prm,
                    double R[9], double t[3], double pose_cov[36], double *error, int *iterations);
 
+/* ---- vision/visual-feature.cpp:12-17,40-49: VisualFeature::extract = cv::ORB detect + compute (row f3 of SURVEY
+ * section 8).  Restated in mvs_orb_oracle.c -- PARITY UNPINNED by the reference (OpenCV-internal algorithm and learned
+ * pattern); see that file's header for what is ORB's published pipeline and what is this build's own choice. */
+typedef struct {
+    int32_t nfeatures;       /* 500 = MAX_FEATURE_COUNT, visual-feature.cpp:9 */
+    int32_t nlevels;         /* 8 */
+    int32_t edge_threshold;  /* 31 */
+    int32_t fast_threshold;  /* 20 */
+} orc_orb_params;
+typedef struct { /* layout of cv::KeyPoint */
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+void orc_orb_params_default(orc_orb_params *p);
+void orc_orb_pattern(int8_t P[256 * 4]); /* (x1, y1, x2, y2) per test */
+int orc_orb_layout(int w, int h, const orc_orb_params *p, int *lw, int *lh, int *nl, double *scale);
+void orc_orb_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
+void orc_orb_fast_scores(const uint8_t *img, int w, int h, int threshold, uint8_t *score);
+void orc_orb_blur(const uint8_t *img, int w, int h, uint8_t *out);
+float orc_orb_harris(const uint8_t *img, int w, int x0, int y0);
+void orc_orb_moments(const uint8_t *img, int w, int x0, int y0, int *m10, int *m01);
+float orc_orb_fast_atan2(float y, float x);
+/* image: h x w row-major grayscale.  kp / desc: capacity nfeatures (x 32 bytes).  returns 1 on success */
+int orc_orb_extract(const uint8_t *image, int w, int h, const orc_orb_params *prm, orc_keypoint *kp, uint8_t *desc,
+                    int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

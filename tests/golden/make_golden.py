@@ -46,10 +46,41 @@ def refine_vectors():
     np.savez_compressed(os.path.join(HERE, "refine_small.npz"), **d)
 
 
+def orb_vectors():
+    """extraction (row f3): a small textured image through the oracle; the sampling pattern's hash"""
+    import hashlib
+
+    import test_orb as TO
+
+    img = TO.textured(21, 160, 200)
+    r = o.orb_extract(img, o.make_orb_params(nfeatures=200, nlevels=3))
+    assert r["ok"] and len(r["kp"]) > 100
+    np.savez_compressed(os.path.join(HERE, "orb_small.npz"), image=img, nfeatures=200, nlevels=3, kp=r["kp"], desc=r["desc"],
+                        pattern_sha16=hashlib.sha256(o.orb_pattern().tobytes()).hexdigest()[:16])
+
+
+def tsukuba_frames():
+    """The reference's own test images (data/tsukuba/1..5.jpg, used by test/test-image-pair.cpp and
+    test/test-visual-odometer.cpp), decoded to grayscale once so that the GPU box needs neither the reference tree nor a
+    JPEG decoder.  Data, not source.  Needs /root/reference and PIL; run here only."""
+    from PIL import Image
+
+    ims = np.stack([np.asarray(Image.open("/root/reference/data/tsukuba/%d.jpg" % i).convert("L")) for i in (1, 2, 3, 4, 5)])
+    K = np.array([[350.0, 0, 192], [0, 350, 144], [0, 0, 1]])   # data/tsukuba/camera.config: 350 350 0 192 144
+    np.savez_compressed(os.path.join(HERE, "tsukuba_gray.npz"), images=ims, K=K)
+
+
 def main():
     if sys.argv[1:] == ["refine"]:
         refine_vectors()
         print("refine vectors written to", HERE)
+        return
+    if sys.argv[1:] == ["orb"]:
+        if not os.path.exists(os.path.join(HERE, "orb_small.npz")):   # test_orb reads the pattern hash at import
+            np.savez_compressed(os.path.join(HERE, "orb_small.npz"), pattern_sha16="")
+        orb_vectors()
+        tsukuba_frames()
+        print("orb vectors written to", HERE)
         return
     rng = np.random.default_rng(20261003)
     # ---- matcher: random descriptors with planted matches and constructed ties
@@ -114,6 +145,8 @@ def main():
                         inliers=rs["inliers"], best_hyp=rs["best_hyp"],
                         samples=np.stack([o.sample4(5, h, 200) for h in range(256)]))
     refine_vectors()
+    orb_vectors()
+    tsukuba_frames()
     print("golden vectors written to", HERE)
 
 

@@ -58,7 +58,7 @@ class Counters(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("mvs_oracle.c", "mvs_refine_oracle.c", "mvs_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("mvs_oracle.c", "mvs_refine_oracle.c", "mvs_orb_oracle.c", "mvs_oracle.h")]
     stale = not os.path.exists(_LIB_PATH) or any(
         os.path.exists(f) and os.path.getmtime(_LIB_PATH) < os.path.getmtime(f) for f in srcs)
     if force or stale:
@@ -449,3 +449,90 @@ def pnp_refine(world, world_cov, img, img_cov, K, R_guess, t_guess, params=None)
     ok = lib().orc_pnp_refine(_p(X), _p(wc), _p(uv), icp, C.c_int(m), _p(_f64(K, (3, 3))), _p(_f64(R_guess, (3, 3))),
                               _p(_f64(t_guess, (3,))), C.byref(params), _p(R), _p(t), _p(pc), C.byref(err), C.byref(it))
     return dict(ok=bool(ok), R=R, t=t, pose_cov=pc, error=err.value, iterations=it.value)
+
+
+# ---- ORB-style extraction (row f3) ---------------------------------------------------
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),
+                ("fast_threshold", C.c_int32)]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def make_orb_params(nfeatures=500, nlevels=8, edge_threshold=31, fast_threshold=20):
+    return OrbParams(int(nfeatures), int(nlevels), int(edge_threshold), int(fast_threshold))
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def orb_pattern():
+    P = np.zeros((256, 4), dtype=np.int8)
+    lib().orc_orb_pattern(P.ctypes.data_as(C.c_void_p))
+    return P
+
+
+def orb_layout(w, h, params):
+    L = params.nlevels
+    lw, lh, nl = (np.zeros(L, dtype=np.int32) for _ in range(3))
+    sc = np.zeros(L)
+    lib().orc_orb_layout.restype = C.c_int
+    ok = lib().orc_orb_layout(C.c_int(w), C.c_int(h), C.byref(params), _p(lw, C.c_int), _p(lh, C.c_int), _p(nl, C.c_int),
+                              _p(sc))
+    return bool(ok), lw, lh, nl, sc
+
+
+def orb_resize(src, dw, dh):
+    src = _u8(src)
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    lib().orc_orb_resize(_p(src, C.c_uint8), C.c_int(src.shape[1]), C.c_int(src.shape[0]), _p(dst, C.c_uint8),
+                         C.c_int(dw), C.c_int(dh))
+    return dst
+
+
+def orb_fast_scores(img, threshold):
+    img = _u8(img)
+    out = np.zeros_like(img)
+    lib().orc_orb_fast_scores(_p(img, C.c_uint8), C.c_int(img.shape[1]), C.c_int(img.shape[0]), C.c_int(threshold),
+                              _p(out, C.c_uint8))
+    return out
+
+
+def orb_blur(img):
+    img = _u8(img)
+    out = np.zeros_like(img)
+    lib().orc_orb_blur(_p(img, C.c_uint8), C.c_int(img.shape[1]), C.c_int(img.shape[0]), _p(out, C.c_uint8))
+    return out
+
+
+def orb_harris(img, x, y):
+    img = _u8(img)
+    lib().orc_orb_harris.restype = C.c_float
+    return float(lib().orc_orb_harris(_p(img, C.c_uint8), C.c_int(img.shape[1]), C.c_int(x), C.c_int(y)))
+
+
+def orb_moments(img, x, y):
+    img = _u8(img)
+    a, b = C.c_int(0), C.c_int(0)
+    lib().orc_orb_moments(_p(img, C.c_uint8), C.c_int(img.shape[1]), C.c_int(x), C.c_int(y), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def orb_fast_atan2(y, x):
+    lib().orc_orb_fast_atan2.restype = C.c_float
+    return float(lib().orc_orb_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def orb_extract(img, params=None):
+    img = _u8(img)
+    params = params or make_orb_params()
+    kp = np.zeros(params.nfeatures, dtype=KEYPOINT_DTYPE)
+    desc = np.zeros((params.nfeatures, 32), dtype=np.uint8)
+    n = C.c_int(0)
+    lib().orc_orb_extract.restype = C.c_int
+    ok = lib().orc_orb_extract(_p(img, C.c_uint8), C.c_int(img.shape[1]), C.c_int(img.shape[0]), C.byref(params),
+                               kp.ctypes.data_as(C.c_void_p), _p(desc, C.c_uint8), C.byref(n))
+    return dict(ok=bool(ok), kp=kp[:n.value].copy(), desc=desc[:n.value].copy())
