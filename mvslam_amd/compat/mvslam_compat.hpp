@@ -454,6 +454,27 @@ public:
         }
         return std::make_pair(f1, f2);
     }
+    // VisualFeature::extract (visual-feature.cpp:40-49): _detector->detect + _extractor->compute with
+    // cv::ORB::create(MAX_FEATURE_COUNT = 500) -> mvs_extract (ORB's pipeline, the library's own pattern: DESIGN.md 4.8)
+    static VisualFeature extract(const Mat8u &image)
+    {
+        static_assert(sizeof(KeyPoint) == sizeof(mvs_keypoint), "KeyPoint has cv::KeyPoint's layout");
+        assert(image.rows > 0 && image.cols > 0);
+        mvs_orb_params prm;
+        mvs_orb_params_default(&prm);
+        std::vector<KeyPoint> kp(prm.nfeatures);
+        Mat8u desc;
+        desc.cols = 32;
+        desc.data.resize((size_t)prm.nfeatures * 32);
+        int32_t n = 0;
+        hip::check(mvs_extract(hip::context(), image.data.data(), 1, image.cols, image.rows, &prm,
+                               reinterpret_cast<mvs_keypoint *>(kp.data()), desc.data.data(), &n),
+                   "VisualFeature::extract");
+        kp.resize(n);
+        desc.data.resize((size_t)n * 32);
+        desc.rows = n;
+        return VisualFeature(kp, desc, image.cols, image.rows);
+    }
     size_t size() const { return m_keypoints.size(); }
     bool valid() const { return size() > 0 && m_image_width > 0 && m_image_height > 0; }  // :209-213
     const std::vector<KeyPoint> &get_keypoints() const { return m_keypoints; }

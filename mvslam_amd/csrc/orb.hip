@@ -9,7 +9,7 @@
 //   fast_kernel      FAST-9/16 score = the largest threshold at which the pixel is still a corner  thread per pixel
 //   nms_kernel       strict 3x3 maximum inside the edge margin -> rank key (score desc, y, x), appended with one atomic
 //                    per corner; the ORDER of the list does not matter, the select kernel sorts it
-//   select_kernel    one workgroup per (level, image): bitonic sort of the keys in LDS, keep 2 n_l, Harris response
+//   select_kernel    one launch, one workgroup per (image, level): bitonic sort of the keys in LDS, keep 2 n_l, Harris response
 //                    (7x7, k = 0.04) of those, sort again by (response desc, y, x), keep n_l     (cv::ORB's retainBest)
 //   blur_h / blur_v  7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18}, BORDER_REFLECT_101
 //   describe_kernel  one wavefront per keypoint: intensity-centroid moments over the radius-15 disc (lanes stride the
@@ -98,26 +98,48 @@ __global__ void nms_kernel(const uint8_t *score, int W, int H, int edge, uint64_
                            int level, int n_levels)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x + edge, y = blockIdx.y * blockDim.y + threadIdx.y + edge;
-    if (x >= W - edge || y >= H - edge)
-        return;
     const int b = blockIdx.z;
     score += (size_t)b * W * H;
-    const int s = score[y * W + x];
-    if (!s)
-        return;
-    bool is_max = true;
+    int s = 0;
+    bool is_max = false;
+    if (x < W - edge && y < H - edge) {
+        s = score[y * W + x];
+        is_max = s != 0;
+        if (is_max) {
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx)
-            if ((dx || dy) && score[(y + dy) * W + x + dx] >= s)
-                is_max = false;
-    if (!is_max)
-        return;
+                for (int dx = -1; dx <= 1; ++dx)
+                    if ((dx || dy) && score[(y + dy) * W + x + dx] >= s)
+                        is_max = false;
+        }
+    }
+    // one global atomic per 32x32 tile: all corners of a level append to the same counter, and same-address atomics
+    // serialise (one per wavefront was 46 % of the whole extraction)
+    __shared__ int wave_off[16];
+    __shared__ int tile_base;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long mask = __ballot(is_max);
+    if (lane == 0)
+        wave_off[wave] = __popcll(mask);
+    __syncthreads();
     const size_t slot = (size_t)b * n_levels + level;
-    const int idx = atomicAdd(&count[slot], 1);
-    if (idx < cap)
-        keys[slot * cap + idx] = rank_key((uint32_t)s, y, x);
+    if (tid == 0) {
+        int total = 0;
+        const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+        for (int w = 0; w < nw; ++w) {
+            const int c = wave_off[w];
+            wave_off[w] = total;
+            total += c;
+        }
+        tile_base = total ? atomicAdd(&count[slot], total) : 0;
+    }
+    __syncthreads();
+    if (is_max) {
+        const int idx = tile_base + wave_off[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+        if (idx < cap)
+            keys[slot * cap + idx] = rank_key((uint32_t)s, y, x);
+    }
 }
 
 __device__ __forceinline__ float harris_at(const uint8_t *img, int W, int x0, int y0)
@@ -166,11 +188,14 @@ __device__ void bitonic_sort(uint64_t *k, int n)
 
 using Sel = OrbSel;
 
-__global__ __launch_bounds__(1024) void select_kernel(OrbDev d, int level)
+// grid (n_images, n_levels): all levels of all images in one launch (one launch per level left 3/4 of the CUs idle)
+__global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
 {
     extern __shared__ uint64_t keys[];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, level = blockIdx.y;
     const OrbLevel &L = d.level[level];
+    if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
+        return;   // sel_count stays 0
     const size_t slot = (size_t)b * d.n_levels + level;
     const int found = d.cand_count[slot];
     const int c = min(found, d.cand_cap);
@@ -396,13 +421,14 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
             continue;
         uint8_t *score = d.score + L.offset * B;
         hipLaunchKernelGGL(fast_kernel, grid, blk, 0, stream, img, L.w, L.h, d.fast_threshold, score);
-        const dim3 gin((L.w - 2 * d.edge + 31) / 32, (L.h - 2 * d.edge + 7) / 8, B);
-        hipLaunchKernelGGL(nms_kernel, gin, blk, 0, stream, score, L.w, L.h, d.edge, d.cand_keys, d.cand_count, d.cand_cap, l,
+        const dim3 gin((L.w - 2 * d.edge + 31) / 32, (L.h - 2 * d.edge + 31) / 32, B);
+        hipLaunchKernelGGL(nms_kernel, gin, dim3(32, 32), 0, stream, score, L.w, L.h, d.edge, d.cand_keys, d.cand_count, d.cand_cap, l,
                            d.n_levels);
-        hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), (size_t)d.cand_cap * sizeof(uint64_t), stream, d, l);  // LDS limit raised in orb_prepare()
         hipLaunchKernelGGL(blur_h_kernel, grid, blk, 0, stream, img, L.w, L.h, d.tmp16);
         hipLaunchKernelGGL(blur_v_kernel, grid, blk, 0, stream, d.tmp16, L.w, L.h, d.blur + L.offset * B);
     }
+    hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), (size_t)d.cand_cap * sizeof(uint64_t), stream,
+                       d);   // LDS limit raised in orb_prepare()
     hipLaunchKernelGGL(describe_kernel, dim3(d.n_levels, B), dim3(256), 0, stream, d);
 }
 

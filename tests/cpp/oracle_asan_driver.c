@@ -65,6 +65,21 @@ int main(void)
         okq &= orc_sfm_refine(q1, NULL, q2, NULL, 1, K, Rg, tg, Xg, &rp, Ro, to, cov, Xo, pc, &err, &it);
         printf("refine ok=%d %d\n", okr, okq);
     }
+    // extraction (row f3) on a blocky 200 x 160 image, all levels
+    {
+        enum { W = 200, H = 160, NF = 300 };
+        static uint8_t im[W * H], dd[NF * 32];
+        static orc_keypoint kk[NF];
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                im[y * W + x] = (uint8_t)((((x / 6) * 37 + (y / 6) * 101) * 2654435761u) >> 24);
+        orc_orb_params op;
+        orc_orb_params_default(&op);
+        op.nfeatures = NF;
+        int nk = 0;
+        int oke = orc_orb_extract(im, W, H, &op, kk, dd, &nk);
+        printf("orb ok=%d n=%d\n", oke, nk > 50);
+    }
     free(d1); free(d2); free(k1); free(k2); free(m); free(mask); free(pts); free(idx);
     return 0;
 }

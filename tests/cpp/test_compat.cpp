@@ -322,6 +322,41 @@ static void image_pair_refine()
     ASSERT_TRUE(refined.error > 0 && refined.T_pair_to_base_covar(0, 0) > 0);
 }
 
+static void visual_feature_extract_and_match()
+{   // VisualFeature::extract on a synthetic textured frame and its copy shifted by 7 px: the matches carry the shift
+    std::mt19937 g(3);
+    const int W = 320, H = 240;
+    Mat8u a, b;
+    a.rows = b.rows = H; a.cols = b.cols = W;
+    a.data.resize((size_t)W * H); b.data.resize((size_t)W * H);
+    std::vector<uint8_t> big((size_t)(W + 64) * H);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W + 64; ++x) {
+            uint32_t hsh = (uint32_t)(x / 6) * 2654435761u ^ (uint32_t)(y / 6) * 40503u;
+            hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+            big[(size_t)y * (W + 64) + x] = (uint8_t)(hsh & 0xff);
+        }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            a.data[(size_t)y * W + x] = big[(size_t)y * (W + 64) + x + 7];
+            b.data[(size_t)y * W + x] = big[(size_t)y * (W + 64) + x];
+        }
+    VisualFeature fa = VisualFeature::extract(a), fb = VisualFeature::extract(b);
+    ASSERT_TRUE(fa.valid() && fb.valid() && fa.size() > 300 && fa.size() <= 500);
+    ASSERT_TRUE(fa.get_descriptors().rows == (int)fa.size() && fa.get_descriptors().cols == 32);
+    auto m = VisualFeature::match_visual_features(fa, fb, 30);
+    ASSERT_TRUE(m.size() > 100);
+    size_t good = 0;
+    for (const auto &mm : m) {
+        const auto &pa = fa.get_keypoints()[mm.trainIdx].pt, &pb = fb.get_keypoints()[mm.queryIdx].pt;
+        good += std::fabs((pb.x - pa.x) - 7.0f) < 1.5f && std::fabs(pb.y - pa.y) < 1.5f;
+    }
+    ASSERT_TRUE(good * 10 >= m.size() * 9);
+    auto pe = fa.get_point_estimates();
+    const double sigma = (double)(1 << fa.get_keypoints()[0].octave) * 0.5;   // visual-feature.cpp:202
+    ASSERT_TRUE(pe.size() == fa.size() && pe[0].covar()(0, 0) == sigma * sigma && pe[0].covar()(0, 1) == 0.0);
+}
+
 int main()
 {
     try {
@@ -335,6 +370,7 @@ int main()
         RUN(sfm_refine_L_shape);
         RUN(pnp_refine_L_shape);
         RUN(image_pair_refine);
+        RUN(visual_feature_extract_and_match);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION: %s\n", e.what());
         return 2;

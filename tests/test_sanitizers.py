@@ -10,8 +10,8 @@ def test_oracle_is_clean_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "oracle_asan")
     subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(ROOT, "tests", "cpp", "oracle_asan_driver.c"),
-                           os.path.join(ROOT, "oracle", "mvs_oracle.c"), os.path.join(ROOT, "oracle", "mvs_refine_oracle.c"), "-lm"])
+                           os.path.join(ROOT, "oracle", "mvs_oracle.c"), os.path.join(ROOT, "oracle", "mvs_refine_oracle.c"), os.path.join(ROOT, "oracle", "mvs_orb_oracle.c"), "-lm"])
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0, out
-    assert "image_pair ok=1" in out and "pnp ok=1" in out and "refine ok=1 1" in out and "ERROR" not in out and "runtime error" not in out
+    assert "image_pair ok=1" in out and "pnp ok=1" in out and "refine ok=1 1" in out and "orb ok=1 n=1" in out and "ERROR" not in out and "runtime error" not in out

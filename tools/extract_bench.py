@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Row f3: VisualFeature::extract for a batch of 640x480 frames (2000 features each, the keypoint count BASELINE's
+matching configs assume).  Times upload + extraction + download through the C ABI by wall clock (`mvs_extract` is a
+host-buffer entry point), kernel time comes from rocprofv3.  The CPU oracle extracts a sample of the same frames.
+Prints one JSON line."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mvslam_amd import capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=int, default=64)
+ap.add_argument("--width", type=int, default=640)
+ap.add_argument("--height", type=int, default=480)
+ap.add_argument("--features", type=int, default=2000)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--cpu-images", type=int, default=16)
+args = ap.parse_args()
+
+
+def textured(seed, h, w):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(h // 6 + 2, w // 6 + 2)).astype(np.uint8)
+    img = np.kron(base, np.ones((6, 6), dtype=np.uint8))[:h, :w].astype(np.int32)
+    img += rng.integers(-6, 7, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+imgs = np.stack([textured(100 + i, args.height, args.width) for i in range(args.images)])
+ctx = capi.Context(0)
+prm = capi.default_orb_params(nfeatures=args.features)
+out = ctx.extract(imgs, prm)
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    out = ctx.extract(imgs, prm)
+ms = (time.perf_counter() - t0) * 1e3 / args.steps
+ctx.close()
+# algorithmic bytes per image (u8 pixels, pyramid = 3.16 x level 0): resize read+write, FAST read + score write, NMS read,
+# blur read + u16 write/read + write, descriptors: ~ 9 pyramid passes
+pyr = sum(round(args.width / 1.2 ** l) * round(args.height / 1.2 ** l) for l in range(8))
+alg_bytes = 9.0 * pyr
+cpu = None
+if args.cpu_images > 0:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_lib as o
+    t0 = time.perf_counter()
+    same = True
+    for i in range(args.cpu_images):
+        w = o.orb_extract(imgs[i], o.make_orb_params(nfeatures=args.features))
+        n = int(out["n"][i])
+        same &= n == len(w["kp"]) and np.array_equal(out["desc"][i][:n], w["desc"])
+    dt = time.perf_counter() - t0
+    cpu = {"value": round(args.cpu_images / dt, 2), "unit": "images/s", "cores": 1, "kind": "port",
+           "sample": "%d of the same frames, single thread" % args.cpu_images, "bit_exact_vs_gpu": bool(same)}
+print(json.dumps({
+    "metric": "extracted images/sec (VisualFeature::extract, %dx%d, %d features, host buffers in and out)"
+              % (args.width, args.height, args.features),
+    "value": round(args.images / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 3), "images": args.images,
+    "mean_keypoints": float(out["n"].mean()), "algorithmic_MB_per_image": round(alg_bytes / 1e6, 2),
+    "cpu_baseline": cpu}))
