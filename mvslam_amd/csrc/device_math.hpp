@@ -163,7 +163,7 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
 
 // Sweeps until a sweep without rotation (at most max(M, 30)); W ends as singular values.
 // At: N rows of length M.  Vt: N x N, initialised to identity here.
-template <int M, int N, bool INPLACE = false, bool FAST = false>
+template <int M, int N, bool INPLACE = false, bool FAST = false, bool HAS_V = true>
 MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N], unsigned &rot, unsigned &pairs,
                              bool &bad)
 {
@@ -185,7 +185,7 @@ MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)
         for (int i = 0; i < N - 1; ++i) {
 #pragma unroll
             for (int j = i + 1; j < N; ++j)
-                jacobi_pair<M, N, true, INPLACE, FAST>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot, bad);
+                jacobi_pair<M, N, HAS_V, INPLACE, FAST>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot, bad);
         }
         pairs += N * (N - 1) / 2;
         if (!changed)
@@ -249,12 +249,13 @@ MVS_DEV void select_row(const double (&Mx)[N][N], int row, double (&out)[N])
 }
 
 // Null vector of a symmetric 9x9 matrix B (= A^T A): last row of vt of cv::SVDecomp(B).
-template <bool INPLACE, bool FAST>
+// HAS_V = false: TIMING EXPERIMENT ONLY (V is never rotated, the result is meaningless)
+template <bool INPLACE, bool FAST, bool HAS_V = true>
 MVS_DEV void svd9_last_vt_row(double (&At)[9][9], double (&f)[9], unsigned &rot, unsigned &pairs, bool &bad)
 {
     double Vt[9][9], W[9];
     int tag[9];
-    jacobi_svd_core<9, 9, INPLACE, FAST>(At, Vt, W, rot, pairs, bad);
+    jacobi_svd_core<9, 9, INPLACE, FAST, HAS_V>(At, Vt, W, rot, pairs, bad);
     sort_tags_desc<9>(W, tag);
     select_row<9>(Vt, tag[8], f);
 }
@@ -505,7 +506,7 @@ MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const dou
                 At[j][i] = acc;
             }
         }
-        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0>(At, f, rot9, pairs9, bad);
+        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0, (VAR & 256) == 0>(At, f, rot9, pairs9, bad);
     }
     // rank-2 enforcement (:127-136): F = u diag(w0, w1, 0) vt
     double Fn[3][3];

@@ -889,6 +889,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     const dim3 grid(G, n_active), block(kHypPerBlock);
     switch (g_ransac_variant) {
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
+    case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream); break;   // timing experiment: no V rotations
     default: launch_ransac_var<120>(b, rp, grid, block, stats, stream); break;
     }
 }
