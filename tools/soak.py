@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle soak over every entry point (more cases than the test-suite keeps).  Integer / index outputs
+must agree bit for bit, floating point within the tolerances of the tests.  Prints one JSON summary line; exit code 1
+on any mismatch.  usage: python tools/soak.py [--cases 200]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from mvslam_amd import capi, synth
+import oracle_lib as o
+import test_pnp as TP
+import test_refine as TR
+import test_orb as TO
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=200)
+args = ap.parse_args()
+rng = np.random.default_rng(2026)
+ctx = capi.Context(0)
+bad = []
+cnt = dict(pairs=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0)
+t0 = time.time()
+
+# 1. whole image pairs through the batch API: ragged keypoint counts, varying noise / outliers / hypothesis counts
+n_pairs = args.cases
+sizes = rng.integers(40, 700, size=n_pairs)
+N = int(sizes.max())
+b = capi.Batch(ctx, n_pairs, N)
+data = []
+for i in range(n_pairs):
+    p = synth.make_pair(10_000 + i, n_kp=int(sizes[i]), noise_px=float(rng.choice([0.0, 0.3, 1.0])),
+                        outlier_frac=float(rng.choice([0.0, 0.3, 0.6])))
+    data.append(p)
+pad = lambda a, w: np.concatenate([a, np.zeros((N - len(a),) + a.shape[1:], a.dtype)])
+b.upload(0, np.stack([pad(p["desc1"], 0) for p in data]), np.stack([pad(p["kp1"], 0) for p in data]), sizes.astype(np.int32),
+         np.stack([pad(p["desc2"], 0) for p in data]), np.stack([pad(p["kp2"], 0) for p in data]), sizes.astype(np.int32),
+         np.stack([p["K"].reshape(9) for p in data]), np.arange(n_pairs, dtype=np.int64))
+H = 768
+prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=99, max_error_sq=1e-2)
+b.run(prm)
+b.sync()
+out = b.download()
+b.close()
+for i, p in enumerate(data):
+    n = int(sizes[i])
+    want = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(H, o.SAMPLER_PHILOX, 99 + i, 1e-2), 0.7, 10.0)
+    r = out["results"][i]
+    M = int(r["n_matches"])
+    ok = (bool(r["valid"]) == want["valid"] and M == want["n_matches"] and int(r["best_hyp"]) == want["best_hyp"]
+          and int(r["n_points"]) == want["n_points"] and int(r["best_count"]) == want["best_count"])
+    if ok and M:
+        ok &= np.array_equal(out["matches"][i][:M], want["matches"].astype(capi.MATCH_DTYPE))
+        ok &= np.array_equal(out["mask"][i][:M], want["mask"])
+    if ok and want["valid"]:
+        k = want["n_points"]
+        ok &= np.array_equal(out["point_idx"][i][:k], want["point_idx"])
+        ok &= np.abs(r["R"] - want["R"]).max() <= 1e-12 and np.abs(r["t"] - want["t"]).max() <= 1e-12
+        ok &= np.abs(out["points"][i][:k] - want["points"]).max() <= 1e-9 * max(1.0, np.abs(want["points"]).max())
+    cnt["pairs"] += 1
+    if not ok:
+        bad.append(("pair", i))
+
+# 2. matcher alone: odd sizes, ties, all descriptor widths
+for i in range(args.cases // 4):
+    nb = int(rng.choice([16, 32, 64]))
+    nt, nq = int(rng.integers(2, 900)), int(rng.integers(1, 900))
+    tr = rng.integers(0, 256, size=(nt, nb), dtype=np.uint8)
+    qu = rng.integers(0, 256, size=(nq, nb), dtype=np.uint8)
+    k = min(nt, nq) // 2
+    qu[:k] = tr[rng.integers(0, nt, size=k)]
+    qu[:k, 0] ^= rng.integers(0, 4, size=k).astype(np.uint8)
+    ratio, md = float(rng.choice([0.5, 0.7, 0.95])), float(rng.choice([-1.0, 10.0, 80.0]))
+    got, want = ctx.match_hamming(tr, qu, ratio, md), o.match_visual_features(tr, qu, ratio, md)
+    cnt["match"] += 1
+    if not np.array_equal(got, want.astype(capi.MATCH_DTYPE)):
+        bad.append(("match", i))
+
+# 3. pnp_solve
+for i in range(args.cases // 4):
+    K, X, uv, R, t, _ = TP._scene(500 + i, int(rng.integers(8, 600)), float(rng.choice([0.0, 0.01, 0.5])), int(rng.integers(0, 5)))
+    Hh, seed = int(rng.choice([1, 100, 300])), int(rng.integers(0, 1 << 30))
+    got = ctx.pnp_solve(X, uv, K, capi.default_pnp_params(num_hypotheses=Hh, seed=seed, reproj_error=1.0))
+    want = o.pnp_solve(X, uv, K, o.make_pnp_params(Hh, o.SAMPLER_PHILOX, seed, 1.0))
+    cnt["pnp"] += 1
+    ok = got["ok"] == want["ok"]
+    if ok and want["ok"]:
+        ok = got["best_hyp"] == want["best_hyp"] and np.array_equal(got["inliers"], want["inliers"]) and \
+            np.array_equal(got["R"], want["R"]) and np.array_equal(got["t"], want["t"])
+    if not ok:
+        bad.append(("pnp", i))
+
+# 4. refinement
+for i in range(args.cases // 8):
+    m = int(rng.integers(1, 1500))
+    pb = TR.two_view_problem(900 + i, m, K=synth.K_DEFAULT, sig=0.5, baseline=0.3, depth=(2.0, 10.0))
+    got = ctx.sfm_refine(pb["p1"], pb["cov"], pb["p2"], pb["cov"], pb["K"], pb["Rg"], pb["tg"], pb["Xg"])
+    want = o.sfm_refine(pb["p1"], pb["cov"], pb["p2"], pb["cov"], pb["K"], pb["Rg"], pb["tg"], pb["Xg"])
+    cnt["sfm_refine"] += 1
+    if not (got["ok"] and want["ok"] and got["iterations"] == want["iterations"] and np.abs(got["R"] - want["R"]).max() < 1e-10
+            and np.abs(got["t"] - want["t"]).max() < 1e-10 and np.abs(got["points"] - want["points"]).max() < 1e-9
+            and np.abs(got["pose_cov"] - want["pose_cov"]).max() <= 1e-7 * np.abs(want["pose_cov"]).max()):
+        bad.append(("sfm_refine", i))
+    pp = TR.pnp_problem(1300 + i, int(rng.integers(7, 800)))
+    got = ctx.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
+    want = o.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
+    cnt["pnp_refine"] += 1
+    if not (got["ok"] and want["ok"] and np.abs(got["R"] - want["R"]).max() < 1e-10 and np.abs(got["t"] - want["t"]).max() < 1e-10):
+        bad.append(("pnp_refine", i))
+
+# 5. extraction: random sizes and parameters
+for i in range(args.cases // 8):
+    h, w = int(rng.integers(64, 400)), int(rng.integers(64, 500))
+    img = TO.textured(3000 + i, h, w)
+    kw = dict(nfeatures=int(rng.integers(1, 900)), nlevels=int(rng.integers(1, 9)), fast_threshold=int(rng.choice([5, 20, 60])),
+              edge_threshold=int(rng.choice([19, 31])))
+    got, want = ctx.extract(img, capi.default_orb_params(**kw)), o.orb_extract(img, o.make_orb_params(**kw))
+    n = int(got["n"][0])
+    cnt["extract"] += 1
+    if not (n == len(want["kp"]) and np.array_equal(got["kp"][0][:n], want["kp"].astype(capi.KEYPOINT_DTYPE))
+            and np.array_equal(got["desc"][0][:n], want["desc"])):
+        bad.append(("extract", i, h, w, kw))
+ctx.close()
+print(json.dumps({"cases": cnt, "mismatches": len(bad), "first_mismatches": [list(map(str, x)) for x in bad[:8]],
+                  "seconds": round(time.time() - t0, 1)}))
+sys.exit(1 if bad else 0)
