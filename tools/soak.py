@@ -105,8 +105,12 @@ for i in range(args.cases // 8):
     got = ctx.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
     want = o.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
     cnt["pnp_refine"] += 1
-    if not (got["ok"] and want["ok"] and np.abs(got["R"] - want["R"]).max() < 1e-10 and np.abs(got["t"] - want["t"]).max() < 1e-10):
-        bad.append(("pnp_refine", i))
+    # where the cost is flat (pose weakly constrained next to loose point priors) the two sides stop up to ~1e-9 apart
+    # at the same error to 1e-15: tolerance 1e-8 on the pose, 1e-12 relative on the error
+    if not (got["ok"] and want["ok"] and np.abs(got["R"] - want["R"]).max() < 1e-8 and np.abs(got["t"] - want["t"]).max() < 1e-8
+            and abs(got["error"] - want["error"]) <= 1e-12 * max(1.0, want["error"])):
+        bad.append(("pnp_refine", i, len(pp["X"]), got["ok"], want["ok"], got["iterations"], want["iterations"],
+                    np.abs(got["R"] - want["R"]).max(), np.abs(got["t"] - want["t"]).max(), got["error"], want["error"]))
 
 # 5. extraction: random sizes and parameters
 for i in range(args.cases // 8):
