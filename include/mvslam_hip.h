@@ -296,6 +296,10 @@ mvs_status mvs_pnp_refine(mvs_ctx *ctx, const double *world, const double *world
 mvs_status mvs_batch_refine(mvs_batch *b, const mvs_refine_params *params, double sigma_px);
 /* refined[n_pairs]; points_xyz / point_cov: n_pairs x max_kp x 3 / 9 (NULL to skip), rows [0, results[p].n_points) */
 mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, double *points_xyz, double *point_cov);
+/* the same for the n_frames - 1 consecutive pairs of a sequence that has been run (VisualOdometer::initialize refines its
+ * queued pairs, front-end/visual-odometer.cpp:282-286) */
+mvs_status mvs_seq_refine_pairs(mvs_seq *s, const mvs_refine_params *params, double sigma_px);
+mvs_status mvs_seq_download_refined(mvs_seq *s, mvs_refine_result *refined, double *points_xyz, double *point_cov);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Row f3: keypoint + descriptor extraction.  Replaces VisualFeature::extract

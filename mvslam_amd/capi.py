@@ -102,7 +102,7 @@ EXPORTS = [
     "mvs_batch_copy_results_device", "mvs_pnp_params_default", "mvs_pnp_solve", "mvs_seq_create", "mvs_seq_destroy",
     "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
     "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
-    "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images",
+    "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
 ]
 
 
@@ -542,6 +542,19 @@ class Sequence:
         st = lib().mvs_seq_upload_images(self._h, C.c_int(first), C.c_int(B), _ptr(images, C.c_uint8), C.c_int(W),
                                          C.c_int(H), C.byref(params), _ptr(_f64(K, (9,)), C.c_double))
         self.ctx._check(st, "mvs_seq_upload_images")
+
+    def refine_pairs(self, params=None, sigma_px=0.5):
+        params = params or default_refine_params()
+        self.ctx._check(lib().mvs_seq_refine_pairs(self._h, C.byref(params), C.c_double(sigma_px)), "mvs_seq_refine_pairs")
+
+    def download_refined(self, points=True, point_cov=False):
+        P, N = self.n_frames - 1, self.max_kp
+        res = np.zeros(P, dtype=REFINE_DTYPE)
+        pts = np.zeros((P, N, 3)) if points else None
+        pc = np.zeros((P, N, 3, 3)) if point_cov else None
+        st = lib().mvs_seq_download_refined(self._h, res.ctypes.data_as(C.c_void_p), _ptr(pts, C.c_double), _ptr(pc, C.c_double))
+        self.ctx._check(st, "mvs_seq_download_refined")
+        return dict(refined=res, points=pts, point_cov=pc)
 
     def download_pairs(self):
         P, N = self.n_frames - 1, self.max_kp

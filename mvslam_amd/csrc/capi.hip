@@ -1568,6 +1568,16 @@ mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, 
     return MVS_OK;
 }
 
+mvs_status mvs_seq_refine_pairs(mvs_seq *q, const mvs_refine_params *params, double sigma_px)
+{
+    return q ? mvs_batch_refine(q->batch, params, sigma_px) : MVS_ERR_INVALID_ARG;
+}
+
+mvs_status mvs_seq_download_refined(mvs_seq *q, mvs_refine_result *refined, double *points_xyz, double *point_cov)
+{
+    return q ? mvs_batch_download_refined(q->batch, refined, points_xyz, point_cov) : MVS_ERR_INVALID_ARG;
+}
+
 // ---------------------------------------------------------------------------------------------
 // extraction (row f3)
 void mvs_orb_params_default(mvs_orb_params *p)

@@ -12,8 +12,8 @@
 //   select_kernel    one launch, one workgroup per (image, level): bitonic sort of the keys in LDS, keep 2 n_l, Harris response
 //                    (7x7, k = 0.04) of those, sort again by (response desc, y, x), keep n_l     (cv::ORB's retainBest)
 //   blur_h / blur_v  7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18}, BORDER_REFLECT_101
-//   describe_kernel  one wavefront per keypoint: intensity-centroid moments over the radius-15 disc (lanes stride the
-//                    disc rows, butterfly sum), cos / sin = moments / hypot (no trigonometry), 256 steered BRIEF tests
+//   describe_kernel  half a wavefront per keypoint: intensity-centroid moments over the radius-15 disc (32 lanes split
+//                    the disc rows, butterfly sum), cos / sin = moments / hypot (no trigonometry), 256 steered BRIEF tests
 //                    on the blurred level (lane b < 32 builds byte b), cv::KeyPoint record
 // Everything is integer or single IEEE float operations in a stated order, so GPU and oracle agree bit for bit.
 #include "kernels.hpp"
@@ -312,19 +312,24 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
     const uint8_t *blr = d.blur + L.offset * d.n_images + (size_t)b * L.w * L.h;
     const Sel *sel = d.sel + (slot0 + level) * d.nfeatures;
     const float fs = L.scale;
-    for (int i = wave; i < n; i += 4) {
+    // two keypoints per wavefront: lanes 0-31 take keypoint i0, lanes 32-63 keypoint i0 + 1
+    const int half = lane >> 5, hl = lane & 31;
+    for (int i0 = 2 * wave; i0 < n; i0 += 8) {
+        const bool active = i0 + half < n;
+        const int i = active ? i0 + half : n - 1;
         const int x0 = sel[i].x, y0 = sel[i].y;
-        // intensity-centroid moments: lane v < 16 takes disc rows +-v (row 0 once)
+        // intensity-centroid moments over the radius-15 disc: rows +-v, lanes 0-15 take u < 0, lanes 16-31 take u >= 0
         int m10 = 0, m01 = 0;
-        if (lane < 16) {
+        {
             const uint8_t *c = img + y0 * W + x0;
-            const int v = lane, dmax = kUmax[v];
+            const int v = hl & 15, dmax = kUmax[v];
+            const int u0 = hl < 16 ? -dmax : 0, u1 = hl < 16 ? -1 : dmax;
             if (v == 0) {
-                for (int u = -15; u <= 15; ++u)
+                for (int u = u0; u <= u1; ++u)
                     m10 += u * c[u];
             } else {
                 int vs = 0;
-                for (int u = -dmax; u <= dmax; ++u) {
+                for (int u = u0; u <= u1; ++u) {
                     const int vp = c[u + v * W], vm = c[u - v * W];
                     vs += vp - vm;
                     m10 += u * (vp + vm);
@@ -333,12 +338,10 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
             }
         }
 #pragma unroll
-        for (int s = 1; s < 16; s <<= 1) {   // integer sums: any order gives the same result
+        for (int s = 1; s < 32; s <<= 1) {   // integer sums inside each half: any order gives the same result
             m10 += __shfl_xor(m10, s, 64);
             m01 += __shfl_xor(m01, s, 64);
         }
-        m10 = __shfl(m10, 0, 64);
-        m01 = __shfl(m01, 0, 64);
         const float f10 = (float)m10, f01 = (float)m01;
         const float h2 = f10 * f10 + f01 * f01;
         float ca = 1.0f, sa = 0.0f;
@@ -347,21 +350,23 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
             ca = f10 / hh;
             sa = f01 / hh;
         }
+        if (!active)
+            continue;
         const size_t o = (size_t)b * d.nfeatures + offset + i;
-        if (lane < 32) {
+        {
             const uint8_t *ctr = blr + y0 * W + x0;
             unsigned v = 0;
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
-                const int8_t *q = d.pattern + 4 * (8 * lane + bit);
+                const int8_t *q = d.pattern + 4 * (8 * hl + bit);
                 const float x1 = (float)q[0], y1 = (float)q[1], x2 = (float)q[2], y2 = (float)q[3];
                 const int ix1 = (int)rintf(x1 * ca - y1 * sa), iy1 = (int)rintf(x1 * sa + y1 * ca);
                 const int ix2 = (int)rintf(x2 * ca - y2 * sa), iy2 = (int)rintf(x2 * sa + y2 * ca);
                 v |= (unsigned)(ctr[iy1 * W + ix1] < ctr[iy2 * W + ix2]) << bit;
             }
-            d.desc[o * 32 + lane] = (uint8_t)v;
+            d.desc[o * 32 + hl] = (uint8_t)v;
         }
-        if (lane == 0) {
+        if (hl == 0) {
             mvs_keypoint k;
             k.x = (float)x0 * fs;
             k.y = (float)y0 * fs;

@@ -254,7 +254,13 @@ def test_gpu_images_to_poses_tsukuba_sequence(ctx):
     s.run(prm, pprm)      # run + sync
     pairs = s.download_pairs()
     tracks = s.download_tracks()
+    s.refine_pairs(sigma_px=0.5)      # ImagePair::refine of every pair, as the reference's test-image-pair does
+    refined = s.download_refined()["refined"]
     s.close()
+    assert np.all(refined["ok"] == 1)
+    for p in range(F - 1):            # test-image-pair.cpp:38-45 asserts this AFTER refinement
+        assert np.abs(refined["t"][p] - np.array([1.0, 0, 0])).max() < 1e-2, (p, refined["t"][p])
+        assert np.abs(refined["R"][p] - np.eye(3)).max() < 1e-2
     res = pairs["results"]
     assert np.all(res["valid"] == 1)
     # frames are 1 px apart horizontally in a rectified rig: every consecutive pair is a pure x translation
