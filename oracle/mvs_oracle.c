@@ -280,6 +280,18 @@ static uint32_t cvrng_next(uint64_t *state)
  *   afterwards W[i] = sqrt(chain fma(t, t, sd)); selection sort, descending,
  *   strict '<', swapping rows of At and Vt.
  */
+/* diagnostics for the divergence analysis in DESIGN.md section 4.3: when set, every 9x9 decomposition appends one
+ * 64-bit word per sweep (bit = pair index in (i, j) order, set if the pair was rotated) followed by ~0 */
+static __thread uint64_t *g_trace = NULL;
+static __thread size_t g_trace_cap = 0, g_trace_len = 0;
+void orc_debug_set_jacobi_trace(uint64_t *buf, size_t cap)
+{
+    g_trace = buf;
+    g_trace_cap = cap;
+    g_trace_len = 0;
+}
+size_t orc_debug_jacobi_trace_len(void) { return g_trace_len; }
+
 static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n1, int which)
 {
     const double eps = DBL_EPSILON * 10.0;
@@ -304,11 +316,14 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
 
     for (int iter = 0; iter < max_iter; ++iter) {
         int changed = 0;
+        uint64_t sweep_bits = 0;
+        int pair_idx = -1;
         for (int i = 0; i < n - 1; ++i)
             for (int j = i + 1; j < n; ++j) {
                 double *Ai = At + i * m, *Aj = At + j * m;
                 double a = W[i], b = W[j], p = 0.0;
                 ++pairs;
+                ++pair_idx;
                 for (int k = 0; k < m; ++k)
                     p = fma(Ai[k], Aj[k], p);
                 if (fabs(p) <= eps * sqrt(a * b))
@@ -339,6 +354,7 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
                 W[j] = b;
                 changed = 1;
                 ++rot;
+                sweep_bits |= 1ull << (pair_idx & 63);
                 if (Vt) {
                     double *Vi = Vt + i * n, *Vj = Vt + j * n;
                     for (int k = 0; k < n; ++k) {
@@ -349,9 +365,13 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
                     }
                 }
             }
+        if (which == 9 && g_trace && g_trace_len + 2 <= g_trace_cap)
+            g_trace[g_trace_len++] = sweep_bits;
         if (!changed)
             break;
     }
+    if (which == 9 && g_trace && g_trace_len + 1 <= g_trace_cap)
+        g_trace[g_trace_len++] = ~0ull;
     if (which == 9) { g_cnt.rotations9 += rot; g_cnt.pairs9 += pairs; }
     else if (which == 3) { g_cnt.rotations3 += rot; g_cnt.pairs3 += pairs; }
     else if (which == 4) { g_cnt.rotations4 += rot; g_cnt.pairs4 += pairs; }

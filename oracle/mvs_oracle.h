@@ -180,6 +180,10 @@ int orc_pnp_solve(const double *world_xyz, const double *image_uv, int n, const 
                   const orc_pnp_params *prm, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
                   double Rw2c[9], double tw2c[3], int *best_hyp);
 
+/* diagnostics: trace of the 9x9 Jacobi decompositions (one word per sweep: bit = pair rotated; ~0 terminates one SVD) */
+void orc_debug_set_jacobi_trace(uint64_t *buf, size_t cap);
+size_t orc_debug_jacobi_trace_len(void);
+
 /* ---- vision/sfm-refine.cpp:20-139, vision/pnp-refine.cpp:14-108 -> vision/ba.cpp:26-156 (row f4 of SURVEY section 8)
  * Restated in mvs_refine_oracle.c (see its header: the least-squares problem GTSAM is handed, solved by the build's own
  * Schur-complement Levenberg-Marquardt; parity by tolerance). */

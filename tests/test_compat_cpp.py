@@ -26,8 +26,10 @@ def test_compat_shim_compiles_and_links_with_host_compiler():
 
 @pytest.mark.gpu
 def test_compat_shim_cpp_suite():
-    if not os.path.exists(EXE):
-        _build()
+    deps = [os.path.join(ROOT, "tests", "cpp", "test_compat.cpp"), os.path.join(ROOT, "mvslam_amd", "compat", "mvslam_compat.hpp"),
+            os.path.join(ROOT, "include", "mvslam_hip.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
+        _build()   # a stale binary would test yesterday's shim
     p = subprocess.run([EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0 and "ALL PASSED" in out, out
