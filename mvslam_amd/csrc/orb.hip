@@ -66,25 +66,40 @@ __global__ void fast_kernel(const uint8_t *img, int W, int H, int threshold, uin
     int out = 0;
     if (x >= 3 && y >= 3 && x < W - 3 && y < H - 3) {
         const int c = img[y * W + x];
-        int d[16];
+        // every arc of 9 contiguous circle pixels contains one pixel of each antipodal pair: if both pixels of a pair
+        // are within the threshold of the centre there is no corner (most pixels of a real image leave here)
+        const int d0 = (int)img[(y + 3) * W + x] - c, d8 = (int)img[(y - 3) * W + x] - c;
+        const int d4 = (int)img[y * W + x + 3] - c, d12 = (int)img[y * W + x - 3] - c;
+        const bool maybe = (max(abs(d0), abs(d8)) > threshold) && (max(abs(d4), abs(d12)) > threshold);
+        if (maybe) {
+            int d[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            d[k] = (int)img[(y + kFastDy[k]) * W + (x + kFastDx[k])] - c;
-        int best = -256;
+            for (int k = 0; k < 16; ++k)
+                d[k] = (int)img[(y + kFastDy[k]) * W + (x + kFastDx[k])] - c;
+            // min / max over every window of 9 by doubling: windows of 2, 4, 8, then one more element (min and max
+            // are associative, so this is the same number as the 16 x 9 scan)
+            int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            int mb = 255, md = 255;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int v = d[(k + j) & 15];
-                mb = min(mb, v);
-                md = min(md, -v);
+            for (int k = 0; k < 16; ++k) {
+                lo2[k] = min(d[k], d[(k + 1) & 15]);
+                hi2[k] = max(d[k], d[(k + 1) & 15]);
             }
-            best = max(best, max(mb, md));
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+                hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+            }
+            int best = -256;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // brighter arc: min of (ring - c)
+                const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // darker arc: min of (c - ring) = -max
+                best = max(best, max(lo9, -hi9));
+            }
+            const int s = best - 1;
+            if (s >= threshold)
+                out = s;
         }
-        const int s = best - 1;
-        if (s >= threshold)
-            out = s;
     }
     score[y * W + x] = (uint8_t)out;
 }
