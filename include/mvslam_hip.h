@@ -289,6 +289,28 @@ mvs_status mvs_sfm_refine(mvs_ctx *ctx, const double *p1, const double *cov1, co
 mvs_status mvs_pnp_refine(mvs_ctx *ctx, const double *world, const double *world_cov, const double *image,
                           const double *image_cov, int m, const double K[9], const double R_guess[9],
                           const double t_guess[3], const mvs_refine_params *params, mvs_refine_result *result);
+/* ba_frame_pose_and_point (vision/ba.hpp:25-36, ba.cpp:26-156) for the configurations the reference builds -- one or two
+ * frames: besides sfm_refine / pnp_refine that is VisualOdometer::track_refine (front-end/visual-odometer.cpp:618-800:
+ * last frame anchored at ITS pose, new frame regularised, tracked points with priors, new points without, each frame
+ * observing a subset of the points).  All pointers are host memory. */
+typedef struct mvs_ba_problem {
+    int32_t n_frames;               /* 1 or 2 */
+    int32_t n_points;               /* 1 .. 4096 */
+    const double *K;                /* 9, affine */
+    const double *frame_pose;       /* n_frames x 12: R (9 row-major), t (3): camera in world = guess = prior mean */
+    const double *frame_prior_var;  /* n_frames x 6: DIAGONAL of the prior covariance in tangent order (rotation,
+                                       translation); an entry <= 0 = no prior on that coordinate */
+    const double *points;           /* n_points x 3 guesses (= prior means) */
+    const double *point_prior_cov;  /* n_points x 9, or NULL = no point has a prior; a point whose covariance has a
+                                       first entry <= 0 has no prior (track_refine's new points) */
+    const double *obs[2];           /* per frame: n_points x 2 image points */
+    const double *obs_cov[2];       /* per frame: n_points x 4 covariances, or NULL = identity */
+    const uint8_t *obs_valid[2];    /* per frame: n_points flags (0 = the frame does not observe the point), or NULL = all */
+} mvs_ba_problem;
+/* frames_out[n_frames]: pose estimate and marginal covariance of every frame (error / iterations repeated in each);
+ * points_out n_points x 3, point_cov_out n_points x 9 (may be NULL).  Only the LM fields of params are used. */
+mvs_status mvs_ba_refine(mvs_ctx *ctx, const mvs_ba_problem *problem, const mvs_refine_params *params,
+                         mvs_refine_result *frames_out, double *points_out, double *point_cov_out);
 /* Batched ImagePair::refine (front-end/image-pair.cpp:176-238) on a batch that has been run: every valid pair is refined
  * from its own results on the device (observations = the matched keypoints, covariance (sigma_px)^2 I as
  * VisualFeature::get_point_estimates gives an octave-0 ORB keypoint: sigma_px = 0.5, visual-feature.cpp:193-207).

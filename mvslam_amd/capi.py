@@ -76,6 +76,14 @@ class RefineParams(C.Structure):
                 ("point_sigma", C.c_double)]
 
 
+class BaProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_points", C.c_int32), ("K", C.POINTER(C.c_double)),
+                ("frame_pose", C.POINTER(C.c_double)), ("frame_prior_var", C.POINTER(C.c_double)),
+                ("points", C.POINTER(C.c_double)), ("point_prior_cov", C.POINTER(C.c_double)),
+                ("obs", C.POINTER(C.c_double) * 2), ("obs_cov", C.POINTER(C.c_double) * 2),
+                ("obs_valid", C.POINTER(C.c_uint8) * 2)]
+
+
 REFINE_DTYPE = np.dtype([("ok", "<i4"), ("iterations", "<i4"), ("error", "<f8"), ("R", "<f8", (3, 3)),
                          ("t", "<f8", (3,)), ("pose_cov", "<f8", (6, 6))])
 
@@ -103,6 +111,7 @@ EXPORTS = [
     "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
     "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
+    "mvs_ba_refine",
 ]
 
 
@@ -356,6 +365,36 @@ class Context:
         r = res[0]
         return dict(ok=st == MVS_OK, R=r["R"].copy(), t=r["t"].copy(), pose_cov=r["pose_cov"].copy(),
                     error=float(r["error"]), iterations=int(r["iterations"]))
+
+    # ba_frame_pose_and_point for one or two frames (sfm_refine, pnp_refine, VisualOdometer::track_refine)
+    def ba_refine(self, K, frame_pose, frame_prior_var, points, point_prior_cov, obs, obs_cov, obs_valid, params=None):
+        fp, fv, pg = _f64(frame_pose).reshape(-1, 12), _f64(frame_prior_var).reshape(-1, 6), _f64(points).reshape(-1, 3)
+        F, m = len(fp), len(pg)
+        params = params or default_refine_params()
+        keep = [fp, fv, pg, _f64(K, (9,))]
+        pb = BaProblem()
+        pb.n_frames, pb.n_points = F, m
+        pb.K, pb.frame_pose, pb.frame_prior_var, pb.points = (_ptr(keep[3], C.c_double), _ptr(fp, C.c_double),
+                                                            _ptr(fv, C.c_double), _ptr(pg, C.c_double))
+        if point_prior_cov is not None:
+            keep.append(_f64(point_prior_cov, (m, 9)))
+            pb.point_prior_cov = _ptr(keep[-1], C.c_double)
+        for f in range(F):
+            keep.append(_f64(obs[f], (m, 2)))
+            pb.obs[f] = _ptr(keep[-1], C.c_double)
+            if obs_cov[f] is not None:
+                keep.append(_f64(obs_cov[f], (m, 4)))
+                pb.obs_cov[f] = _ptr(keep[-1], C.c_double)
+            if obs_valid[f] is not None:
+                keep.append(np.ascontiguousarray(obs_valid[f], dtype=np.uint8).reshape(m))
+                pb.obs_valid[f] = _ptr(keep[-1], C.c_uint8)
+        res = np.zeros(F, dtype=REFINE_DTYPE)
+        pts, ptc = np.zeros((m, 3)), np.zeros((m, 3, 3))
+        st = lib().mvs_ba_refine(self._h, C.byref(pb), C.byref(params), res.ctypes.data_as(C.c_void_p), _ptr(pts, C.c_double),
+                                 _ptr(ptc, C.c_double))
+        self._check(st, "mvs_ba_refine", allow_no_model=True)
+        return dict(ok=st == MVS_OK, R=res["R"].copy(), t=res["t"].copy(), pose_cov=res["pose_cov"].copy(), points=pts,
+                    point_cov=ptc, error=float(res["error"][0]), iterations=int(res["iterations"][0]))
 
     def find_fundamental_matrix(self, p1, p2):
         p1, p2 = _f64(p1, (16,)), _f64(p2, (16,))

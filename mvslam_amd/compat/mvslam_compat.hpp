@@ -21,6 +21,8 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -698,6 +700,100 @@ inline TransformationEstimate estimate_from_result_(const mvs_refine_result &r)
     return TransformationEstimate(SE3(SO3(Rm), Vector3Type(r.t[0], r.t[1], r.t[2])), C);
 }
 }  // namespace hip
+
+// ---- vision/ba.hpp:25-36: the one function that talks to GTSAM (ba.cpp:26-156) ------------------------------------
+class Id  // base/data-type.hpp:12-17
+{
+public:
+    using Type = std::size_t;
+    static constexpr Type INVALID = static_cast<Type>(-1);
+};
+using PointIdToPoint2Estimate = std::unordered_map<Id::Type, Point2Estimate>;
+
+// Same signature as the reference.  Supported: the configurations the reference builds -- one or two frames
+// (sfm_refine, pnp_refine, VisualOdometer::track_refine); diagonal frame priors.  With this one function forwarded,
+// sfm-refine.cpp, pnp-refine.cpp and visual-odometer.cpp stay untouched and GTSAM leaves the link line.
+inline void ba_frame_pose_and_point(const CameraIntrinsics &ci, const std::unordered_set<Id::Type> &frame_id,
+                                    const std::unordered_set<Id::Type> &point_id,
+                                    const std::unordered_map<Id::Type, Transformation> &frame_pose_guess,
+                                    const std::unordered_map<Id::Type, TransformationUncertainty> &frame_pose_prior,
+                                    const std::unordered_map<Id::Type, Point3> &point_guess,
+                                    const std::unordered_map<Id::Type, Point3Uncertainty> &point_prior,
+                                    const std::unordered_map<Id::Type, PointIdToPoint2Estimate> &frame_observation,
+                                    std::unordered_map<Id::Type, TransformationEstimate> &frame_pose_estimate,
+                                    std::unordered_map<Id::Type, Point3Estimate> &point_estimate, ScalarType &final_error)
+{
+    assert(frame_id.size() > 0 && frame_id.size() <= 2);   // ba.cpp:39; more than two frames: not built
+    assert(point_id.size() > 0);
+    assert(frame_pose_guess.size() == frame_id.size() && point_guess.size() == point_id.size());
+    assert(frame_pose_prior.size() + point_prior.size() >= 2);   // ba.cpp:43
+    std::vector<Id::Type> fids(frame_id.begin(), frame_id.end()), pids(point_id.begin(), point_id.end());
+    std::sort(fids.begin(), fids.end());
+    std::sort(pids.begin(), pids.end());
+    const int F = (int)fids.size(), m = (int)pids.size();
+    std::unordered_map<Id::Type, int> pidx;
+    for (int i = 0; i < m; ++i)
+        pidx[pids[i]] = i;
+    std::vector<double> pose(12 * (size_t)F), var(6 * (size_t)F, 0.0), pts(3 * (size_t)m), pcov(9 * (size_t)m, 0.0);
+    std::vector<double> obs[2], ocov[2];
+    std::vector<uint8_t> valid[2];
+    for (int f = 0; f < F; ++f) {
+        const Transformation &T = frame_pose_guess.at(fids[f]);
+        std::memcpy(&pose[12 * f], T.rotation().get_matrix().m, 9 * sizeof(double));
+        std::memcpy(&pose[12 * f + 9], T.translation().v, 3 * sizeof(double));
+        auto pr = frame_pose_prior.find(fids[f]);
+        if (pr != frame_pose_prior.end())
+            for (int k = 0; k < 6; ++k)
+                var[6 * f + k] = pr->second(k, k);
+        obs[f].assign(2 * (size_t)m, 0.0);
+        ocov[f].assign(4 * (size_t)m, 0.0);
+        valid[f].assign(m, 0);
+        auto ob = frame_observation.find(fids[f]);
+        if (ob != frame_observation.end())
+            for (const auto &kv : ob->second) {
+                const int i = pidx.at(kv.first);
+                std::memcpy(&obs[f][2 * i], kv.second.mean().v, 2 * sizeof(double));
+                std::memcpy(&ocov[f][4 * i], kv.second.covar().m, 4 * sizeof(double));
+                valid[f][i] = 1;
+            }
+    }
+    for (int i = 0; i < m; ++i) {
+        std::memcpy(&pts[3 * i], point_guess.at(pids[i]).v, 3 * sizeof(double));
+        auto pr = point_prior.find(pids[i]);
+        if (pr != point_prior.end())
+            std::memcpy(&pcov[9 * i], pr->second.m, 9 * sizeof(double));
+    }
+    mvs_ba_problem pb;
+    std::memset(&pb, 0, sizeof(pb));
+    pb.n_frames = F;
+    pb.n_points = m;
+    pb.K = ci.data();
+    pb.frame_pose = pose.data();
+    pb.frame_prior_var = var.data();
+    pb.points = pts.data();
+    pb.point_prior_cov = pcov.data();
+    for (int f = 0; f < F; ++f) {
+        pb.obs[f] = obs[f].data();
+        pb.obs_cov[f] = ocov[f].data();
+        pb.obs_valid[f] = valid[f].data();
+    }
+    std::vector<mvs_refine_result> res(F);
+    std::vector<double> po(3 * (size_t)m), pc(9 * (size_t)m);
+    const mvs_status st = mvs_ba_refine(hip::context(), &pb, &hip::refine_config(), res.data(), po.data(), pc.data());
+    hip::check(st, "ba_frame_pose_and_point");
+    if (st != MVS_OK)
+        throw std::runtime_error("ba_frame_pose_and_point: indeterminate system");   // GTSAM throws here as well
+    frame_pose_estimate.clear();
+    for (int f = 0; f < F; ++f)
+        frame_pose_estimate[fids[f]] = hip::estimate_from_result_(res[f]);
+    point_estimate.clear();
+    for (int i = 0; i < m; ++i) {
+        Point3Uncertainty C;
+        std::memcpy(C.m, &pc[9 * (size_t)i], sizeof(C.m));
+        point_estimate[pids[i]] = Point3Estimate(Point3(po[3 * i], po[3 * i + 1], po[3 * i + 2]), C);
+    }
+    final_error = res[0].error;
+}
 
 inline bool sfm_refine(const std::vector<Point2Estimate> &p1_estimate, const std::vector<Point2Estimate> &p2_estimate,
                        const CameraIntrinsics &ci, const Transformation &pose2in1_guess,

@@ -1378,19 +1378,30 @@ static RefineCfg to_cfg(const mvs_refine_params &p, int n_frames)
     return c;
 }
 
+// extras of the general two-frame problem (mvs_ba_refine); all null for sfm_refine / pnp_refine
+struct RefineExtra {
+    const double *poses_all = nullptr;    // frames x 12: every frame's guess
+    const uint8_t *valid[2] = {nullptr, nullptr};
+    const RefineCfg *cfg = nullptr;       // explicit prior weights
+    mvs_refine_result *results_all = nullptr;  // frames records out
+};
+
 // one problem through the ctx workspace.  frames: 2 = sfm_refine (obs_a = camera 1, obs_b = camera 2), 1 = pnp_refine
 static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, const double *cov_a, const double *obs_b,
                                 const double *cov_b, const double *pts0, const double *cov3, int m, const double K[9],
                                 const double R_guess[9], const double t_guess[3], const mvs_refine_params *params,
-                                mvs_refine_result *result, double *points_out, double *point_cov_out)
+                                mvs_refine_result *result, double *points_out, double *point_cov_out,
+                                const RefineExtra &ex = RefineExtra())
 {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t M = (size_t)m;
     // doubles: obs0 2 obs1 2 oinfo0 3 oinfo1 3 pts0 3 pinfo 6 pts 3 tmp 3 pcov 9 cov2a 4 cov2b 4 cov3 9 = 51 per point
-    const size_t nd = M * 51 + 9 + 12;
+    const size_t nd = M * 51 + 9 + 12 + 24;
     const size_t off_out = (nd * sizeof(double) + 63) & ~size_t(63);
-    const size_t off_m = (off_out + sizeof(mvs_refine_result) + 63) & ~size_t(63);
-    const size_t total = off_m + 64;
+    const size_t off_all = (off_out + sizeof(mvs_refine_result) + 63) & ~size_t(63);
+    const size_t off_m = (off_all + 2 * sizeof(mvs_refine_result) + 63) & ~size_t(63);
+    const size_t off_valid = off_m + 64;
+    const size_t total = off_valid + 2 * ((M + 63) & ~size_t(63));
     if (ctx->ref_bytes < total) {
         if (ctx->d_ref) (void)hipFree(ctx->d_ref);
         ctx->d_ref = nullptr;
@@ -1402,8 +1413,9 @@ static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, c
     double *w = reinterpret_cast<double *>(base);
     double *obs0 = w, *obs1 = obs0 + 2 * M, *oinfo0 = obs1 + 2 * M, *oinfo1 = oinfo0 + 3 * M, *dp0 = oinfo1 + 3 * M;
     double *pinfo = dp0 + 3 * M, *dpts = pinfo + 6 * M, *dtmp = dpts + 3 * M, *dpcov = dtmp + 3 * M;
-    double *c2a = dpcov + 9 * M, *c2b = c2a + 4 * M, *c3 = c2b + 4 * M, *dK = c3 + 9 * M, *dpose = dK + 9;
+    double *c2a = dpcov + 9 * M, *c2b = c2a + 4 * M, *c3 = c2b + 4 * M, *dK = c3 + 9 * M, *dpose = dK + 9, *dpose_all = dpose + 12;
     int32_t *dm = reinterpret_cast<int32_t *>(base + off_m);
+    uint8_t *dv0 = reinterpret_cast<uint8_t *>(base + off_valid), *dv1 = dv0 + ((M + 63) & ~size_t(63));
     hipStream_t s = ctx->stream;
     const int32_t m32 = m;
     double pose[12];
@@ -1418,6 +1430,12 @@ static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, c
         HIP_TRY(ctx, hipMemcpyAsync(c2b, cov_b, M * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if (cov3)
         HIP_TRY(ctx, hipMemcpyAsync(c3, cov3, M * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (ex.poses_all)
+        HIP_TRY(ctx, hipMemcpyAsync(dpose_all, ex.poses_all, (size_t)frames * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (ex.valid[0])
+        HIP_TRY(ctx, hipMemcpyAsync(dv0, ex.valid[0], M, hipMemcpyHostToDevice, s));
+    if (frames == 2 && ex.valid[1])
+        HIP_TRY(ctx, hipMemcpyAsync(dv1, ex.valid[1], M, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dp0, pts0, M * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dpose, pose, sizeof(pose), hipMemcpyHostToDevice, s));
@@ -1427,10 +1445,11 @@ static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, c
     d.n_problems = 1;
     d.stride = m;
     d.n_frames = frames;
-    d.cfg = to_cfg(*params, frames);
+    d.cfg = ex.cfg ? *ex.cfg : to_cfg(*params, frames);
     d.m = dm;
     d.K = dK;
     d.pose0 = dpose;
+    d.pose0_all = ex.poses_all ? dpose_all : nullptr;
     d.obs[0] = obs0;
     d.obs[1] = obs1;
     d.oinfo[0] = oinfo0;
@@ -1441,11 +1460,15 @@ static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, c
     d.pts_tmp = dtmp;
     d.point_cov = point_cov_out ? dpcov : nullptr;
     d.out = reinterpret_cast<mvs_refine_result *>(base + off_out);
+    d.out_all = ex.results_all ? reinterpret_cast<mvs_refine_result *>(base + off_all) : nullptr;
     launch_refine_prep(d, cov_a ? c2a : nullptr, (frames == 2 && cov_b) ? c2b : nullptr, cov3 ? c3 : nullptr,
-                       1.0 / (params->point_sigma * params->point_sigma), oinfo0, oinfo1, pinfo, s);
+                       1.0 / (params->point_sigma * params->point_sigma), oinfo0, oinfo1, pinfo,
+                       ex.valid[0] ? dv0 : nullptr, (frames == 2 && ex.valid[1]) ? dv1 : nullptr, s);
     launch_refine(d, s);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(result, d.out, sizeof(*result), hipMemcpyDeviceToHost, s));
+    if (ex.results_all)
+        HIP_TRY(ctx, hipMemcpyAsync(ex.results_all, d.out_all, (size_t)frames * sizeof(mvs_refine_result), hipMemcpyDeviceToHost, s));
     if (points_out)
         HIP_TRY(ctx, hipMemcpyAsync(points_out, dpts, M * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (point_cov_out)
@@ -1487,6 +1510,44 @@ mvs_status mvs_pnp_refine(mvs_ctx *ctx, const double *world, const double *world
         return MVS_ERR_BAD_INTRINSICS;
     return refine_single(ctx, 1, image, image_cov, nullptr, nullptr, world, world_cov, m, K, R_guess, t_guess, params,
                          result, nullptr, nullptr);
+}
+
+mvs_status mvs_ba_refine(mvs_ctx *ctx, const mvs_ba_problem *pb, const mvs_refine_params *params, mvs_refine_result *frames_out,
+                         double *points_out, double *point_cov_out)
+{
+    if (!ctx || !pb || !frames_out || !refine_params_ok(params) || !pb->K || !pb->frame_pose || !pb->frame_prior_var ||
+        !pb->points || !pb->obs[0] || (pb->n_frames != 1 && pb->n_frames != 2) || (pb->n_frames == 2 && !pb->obs[1]))
+        return MVS_ERR_INVALID_ARG;
+    std::memset(frames_out, 0, (size_t)pb->n_frames * sizeof(mvs_refine_result));
+    if (pb->n_points < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (pb->n_points > kMaxKp)
+        return MVS_ERR_CAPACITY;
+    if (!affine_K(pb->K))
+        return MVS_ERR_BAD_INTRINSICS;
+    RefineCfg cfg = to_cfg(*params, pb->n_frames);
+    for (int f = 0; f < pb->n_frames; ++f)
+        for (int k = 0; k < 6; ++k) {
+            const double v = pb->frame_prior_var[6 * f + k];
+            cfg.w[f][k] = v > 0.0 ? 1.0 / v : 0.0;   // <= 0: no prior on this coordinate
+        }
+    RefineExtra ex;
+    ex.poses_all = pb->frame_pose;
+    ex.valid[0] = pb->obs_valid[0];
+    ex.valid[1] = pb->obs_valid[1];
+    ex.cfg = &cfg;
+    ex.results_all = frames_out;
+    // a NULL point_prior_cov means "no prior on any point": hand the kernel an all-zero covariance table
+    std::vector<double> none;
+    const double *pc = pb->point_prior_cov;
+    if (!pc) {
+        none.assign((size_t)pb->n_points * 9, 0.0);
+        pc = none.data();
+    }
+    mvs_refine_result last;
+    const double *pose_last = pb->frame_pose + 12 * (pb->n_frames - 1);
+    return refine_single(ctx, pb->n_frames, pb->obs[0], pb->obs_cov[0], pb->obs[1], pb->obs_cov[1], pb->points, pc,
+                         pb->n_points, pb->K, pose_last, pose_last + 9, params, &last, points_out, point_cov_out, ex);
 }
 
 mvs_status mvs_batch_refine(mvs_batch *b, const mvs_refine_params *params, double sigma_px)

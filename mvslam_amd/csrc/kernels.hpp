@@ -168,6 +168,7 @@ struct RefineDev {     // G problems; problem g owns slice [g * stride, g * stri
     const int32_t *m;        // [G] points (< 1: not solved)
     const double *K;         // [G][9]
     const double *pose0;     // [G][12] guess of the moving camera: R (9), t (3), camera in world
+    const double *pose0_all; // optional [G][n_frames][12]: every frame's guess (general two-frame problem), else null
     const double *obs[2];    // [G][stride][2] image points seen by frame f
     const double *oinfo[2];  // [G][stride][3] their information matrices (xx xy yy)
     const double *pts0;      // [G][stride][3] point guesses = prior means
@@ -175,12 +176,14 @@ struct RefineDev {     // G problems; problem g owns slice [g * stride, g * stri
     double *pts;             // [G][stride][3] refined points (out)
     double *pts_tmp;         // [G][stride][3] candidate buffer
     double *point_cov;       // [G][stride][9] marginal covariances (out), may be null
-    mvs_refine_result *out;  // [G]
+    mvs_refine_result *out;  // [G] the moving camera (frame n_frames - 1)
+    mvs_refine_result *out_all;  // optional [G][n_frames]: every frame, else null
 };
 // covariance -> information on the device.  cov2_[f]: [G][stride][4] or null (identity); cov3: [G][stride][9] or null
 // (isotropic weight iso3).  Writes d.oinfo / d.pinfo (cast away const by the caller's own buffers).
 void launch_refine_prep(const RefineDev &d, const double *cov2_0, const double *cov2_1, const double *cov3, double iso3,
-                        double *oinfo0, double *oinfo1, double *pinfo, hipStream_t stream);
+                        double *oinfo0, double *oinfo1, double *pinfo, const uint8_t *valid0, const uint8_t *valid1,
+                        hipStream_t stream);
 void launch_refine(const RefineDev &d, hipStream_t stream);
 // batch glue: build the two-view refinement problems of every pair from the batch's own results
 void launch_refine_gather(const BatchDev &b, int n_active, double sigma_px, double point_sigma, int stride, int32_t *m,

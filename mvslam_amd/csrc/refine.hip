@@ -480,7 +480,14 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     double R0[F][9], t0[F][3], R[F][9], t[F][3];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        if (f == F - 1) {
+        if (d.pose0_all) {   // general two-frame problem: every frame has its own guess (= prior mean)
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                R0[f][k] = d.pose0_all[12 * ((size_t)g * F + f) + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                t0[f][k] = d.pose0_all[12 * ((size_t)g * F + f) + 9 + k];
+        } else if (f == F - 1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
                 R0[f][k] = d.pose0[12 * (size_t)g + k];
@@ -697,12 +704,33 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
         for (int r = 0; r < 6; ++r)
             for (int c = 0; c < 6; ++c)
                 out->pose_cov[6 * r + c] = ok ? Sinv[(6 * (F - 1) + r) * NC + (6 * (F - 1) + c)] : 0.0;
+        if (d.out_all) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                mvs_refine_result *o = d.out_all + (size_t)g * F + f;
+                o->ok = ok ? 1 : 0;
+                o->iterations = it;
+                o->error = 0.5 * cur;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    o->R[k] = R[f][k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    o->t[k] = t[f][k];
+                for (int r = 0; r < 6; ++r)
+                    for (int c = 0; c < 6; ++c)
+                        o->pose_cov[6 * r + c] = ok ? Sinv[(6 * f + r) * NC + (6 * f + c)] : 0.0;
+            }
+        }
     }
 }
 
 // covariance -> information, one thread per point slot
+// valid0 / valid1: optional per-observation flags (0 = frame f does not see the point: zero information);
+// a 3x3 covariance whose first entry is <= 0 means "no prior on this point" (zero information)
 __global__ void refine_prep_kernel(RefineDev d, const double *cov2_0, const double *cov2_1, const double *cov3, double iso3,
-                                   double *oinfo0, double *oinfo1, double *pinfo)
+                                   double *oinfo0, double *oinfo1, double *pinfo, const uint8_t *valid0,
+                                   const uint8_t *valid1)
 {
     const int g = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -711,8 +739,11 @@ __global__ void refine_prep_kernel(RefineDev d, const double *cov2_0, const doub
     const size_t s = (size_t)g * d.stride + i;
     for (int f = 0; f < d.n_frames; ++f) {
         const double *cv = f ? cov2_1 : cov2_0;
+        const uint8_t *vd = f ? valid1 : valid0;
         double *o = (f ? oinfo1 : oinfo0) + 3 * s;
-        if (!cv) {
+        if (vd && !vd[s]) {
+            o[0] = 0.0, o[1] = 0.0, o[2] = 0.0;
+        } else if (!cv) {
             o[0] = 1.0, o[1] = 0.0, o[2] = 1.0;
         } else {
             const double a = cv[4 * s], b = 0.5 * (cv[4 * s + 1] + cv[4 * s + 2]), dd = cv[4 * s + 3];
@@ -727,8 +758,9 @@ __global__ void refine_prep_kernel(RefineDev d, const double *cov2_0, const doub
     } else {
         const double *C = cov3 + 9 * s;
         const double a[6] = {C[0], 0.5 * (C[1] + C[3]), 0.5 * (C[2] + C[6]), C[4], 0.5 * (C[5] + C[7]), C[8]};
-        double o[6];
-        sym3_inverse(a, o);
+        double o[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (C[0] > 0.0)
+            sym3_inverse(a, o);
 #pragma unroll
         for (int k = 0; k < 6; ++k)
             L[k] = o[k];
@@ -768,12 +800,14 @@ __global__ void refine_gather_kernel(BatchDev b, double w_obs, double w_pt, int 
 }  // namespace
 
 void launch_refine_prep(const RefineDev &d, const double *cov2_0, const double *cov2_1, const double *cov3, double iso3,
-                        double *oinfo0, double *oinfo1, double *pinfo, hipStream_t stream)
+                        double *oinfo0, double *oinfo1, double *pinfo, const uint8_t *valid0, const uint8_t *valid1,
+                        hipStream_t stream)
 {
     if (d.n_problems <= 0)
         return;
     dim3 grid((d.stride + 255) / 256, d.n_problems);
-    hipLaunchKernelGGL(refine_prep_kernel, grid, dim3(256), 0, stream, d, cov2_0, cov2_1, cov3, iso3, oinfo0, oinfo1, pinfo);
+    hipLaunchKernelGGL(refine_prep_kernel, grid, dim3(256), 0, stream, d, cov2_0, cov2_1, cov3, iso3, oinfo0, oinfo1, pinfo,
+                       valid0, valid1);
 }
 
 void launch_refine(const RefineDev &d, hipStream_t stream)

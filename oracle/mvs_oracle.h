@@ -212,6 +212,15 @@ int orc_pnp_refine(const double *world, const double *world_cov, const double *i
                    const double K[9], const double R_guess[9], const double t_guess[3], const orc_refine_params *prm,
                    double R[9], double t[3], double pose_cov[36], double *error, int *iterations);
 
+/* the general one / two frame problem (VisualOdometer::track_refine, front-end/visual-odometer.cpp:618-800).  frame_pose:
+ * n_frames x 12 (R, t); frame_prior_var: n_frames x 6 (<= 0: none); point_prior_cov: m x 9 or NULL (first entry <= 0: no
+ * prior); obs / obs_cov / obs_valid per frame.  outputs per frame: R (9), t (3), pose_cov (36). */
+int orc_ba_refine(int n_frames, int m, const double K[9], const double *frame_pose, const double *frame_prior_var,
+                  const double *points_guess, const double *point_prior_cov, const double *const obs[2],
+                  const double *const obs_cov[2], const uint8_t *const obs_valid[2], const orc_refine_params *prm,
+                  double *R_out, double *t_out, double *pose_cov_out, double *points, double *point_cov, double *error,
+                  int *iterations);
+
 /* ---- vision/visual-feature.cpp:12-17,40-49: VisualFeature::extract = cv::ORB detect + compute (row f3 of SURVEY
  * section 8).  Restated in mvs_orb_oracle.c -- PARITY UNPINNED by the reference (OpenCV-internal algorithm and learned
  * pattern); see that file's header for what is ORB's published pipeline and what is this build's own choice. */

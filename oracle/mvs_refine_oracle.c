@@ -670,3 +670,68 @@ int orc_pnp_refine(const double *world, const double *world_cov, const double *i
     free(pinfo), free(o1), free(pts);
     return ok;
 }
+
+/* ba_frame_pose_and_point for one or two frames in its general form (VisualOdometer::track_refine,
+ * front-end/visual-odometer.cpp:618-800): every frame has its own guess and diagonal prior (variance <= 0: none), a
+ * point covariance with a first entry <= 0 means "no prior", obs_valid marks which frame sees which point. */
+int orc_ba_refine(int n_frames, int m, const double K[9], const double *frame_pose, const double *frame_prior_var,
+                  const double *points_guess, const double *point_prior_cov, const double *const obs[2],
+                  const double *const obs_cov[2], const uint8_t *const obs_valid[2], const orc_refine_params *prm,
+                  double *R_out, double *t_out, double *pose_cov_out, double *points, double *point_cov, double *error,
+                  int *iterations)
+{
+    if (m < 1 || (n_frames != 1 && n_frames != 2))
+        return 0;
+    ba_problem P;
+    memset(&P, 0, sizeof(P));
+    P.F = n_frames, P.m = m;
+    set_K(&P, K);
+    double *pinfo = (double *)calloc(6 * (size_t)m, sizeof(double));
+    double *oi[2] = {NULL, NULL};
+    for (int f = 0; f < n_frames; ++f) {
+        memcpy(P.R0[f], frame_pose + 12 * f, 9 * sizeof(double));
+        memcpy(P.t0[f], frame_pose + 12 * f + 9, 3 * sizeof(double));
+        for (int k = 0; k < 6; ++k) {
+            const double v = frame_prior_var[6 * f + k];
+            P.w[f][k] = v > 0.0 ? 1.0 / v : 0.0;
+        }
+        oi[f] = (double *)malloc(sizeof(double) * 3 * (size_t)m);
+        cov2_to_info(obs_cov[f], m, oi[f]);
+        if (obs_valid[f])
+            for (int i = 0; i < m; ++i)
+                if (!obs_valid[f][i])
+                    oi[f][3 * i] = oi[f][3 * i + 1] = oi[f][3 * i + 2] = 0.0;
+        P.obs[f] = obs[f];
+        P.oinfo[f] = oi[f];
+    }
+    if (point_prior_cov)
+        for (int i = 0; i < m; ++i) {
+            const double *C = point_prior_cov + 9 * i;
+            if (C[0] > 0.0) {
+                double a[6] = {C[0], 0.5 * (C[1] + C[3]), 0.5 * (C[2] + C[6]), C[4], 0.5 * (C[5] + C[7]), C[8]};
+                sym3_inverse(a, pinfo + 6 * i);
+            }
+        }
+    P.pts0 = points_guess, P.pinfo = pinfo;
+    double R[2][9], t[2][3];
+    memcpy(R, P.R0, sizeof(R));
+    memcpy(t, P.t0, sizeof(t));
+    memcpy(points, points_guess, sizeof(double) * 3 * (size_t)m);
+    int ok = ba_solve(&P, prm, R, t, points, error, iterations);
+    if (ok) {
+        double Sinv[144];
+        const int nc = 6 * n_frames;
+        ok = covariances(&P, R, t, points, Sinv, point_cov);
+        if (ok && pose_cov_out)
+            for (int f = 0; f < n_frames; ++f)
+                for (int r = 0; r < 6; ++r)
+                    for (int c = 0; c < 6; ++c)
+                        pose_cov_out[36 * f + 6 * r + c] = Sinv[(6 * f + r) * nc + (6 * f + c)];
+    }
+    for (int f = 0; f < n_frames; ++f) {
+        memcpy(R_out + 9 * f, R[f], 9 * sizeof(double));
+        memcpy(t_out + 3 * f, t[f], 3 * sizeof(double));
+    }
+    free(pinfo), free(oi[0]), free(oi[1]);
+    return ok;
+}

@@ -322,6 +322,56 @@ static void image_pair_refine()
     ASSERT_TRUE(refined.error > 0 && refined.T_pair_to_base_covar(0, 0) > 0);
 }
 
+static void ba_frame_pose_and_point_two_frames()
+{   // the reference's own BA entry point (vision/ba.hpp:25-36) shaped like VisualOdometer::track_refine: frame 7 anchored
+    // at its own pose, frame 9 regularised, even point ids with priors, odd ones without, one observation missing
+    std::mt19937 g(17);
+    CameraIntrinsics K = Matrix3Type::Identity();
+    K(0, 0) = K(1, 1) = 525; K(0, 2) = 320; K(1, 2) = 240;
+    const SE3 Ta = SE3::exp(Vector6Type{0.4, -0.1, 0.2, 0.02, -0.1, 0.03});
+    const SE3 Tb = SE3::exp(Vector6Type{0.7, -0.08, 0.25, 0.03, -0.12, 0.02});
+    std::unordered_set<Id::Type> fid{7, 9}, pid;
+    std::unordered_map<Id::Type, Transformation> guess{{7, Ta}, {9, SE3::exp(Vector6Type{0.003, -0.002, 0.004, 0.002, 0.001, -0.003}) * Tb}};
+    std::unordered_map<Id::Type, TransformationUncertainty> fprior;
+    fprior[7] = 1e-5 * Matrix6Type::Identity();
+    fprior[9] = 1e-2 * Matrix6Type::Identity();
+    std::unordered_map<Id::Type, Point3> pguess;
+    std::unordered_map<Id::Type, Point3Uncertainty> pprior;
+    std::unordered_map<Id::Type, PointIdToPoint2Estimate> fobs;
+    std::unordered_map<Id::Type, Point3> truth;
+    PinholeCamera ca(K, Ta.inverse()), cb(K, Tb.inverse());
+    for (Id::Type i = 100; i < 140; ++i) {
+        pid.insert(i);
+        Point3 X(get_gaussian(g, 0, 1.0), get_gaussian(g, 0, 0.8), 6 + get_gaussian(g, 0, 1.0));
+        truth[i] = X;
+        pguess[i] = Point3(X[0] + get_gaussian(g, 0, 5e-3), X[1] + get_gaussian(g, 0, 5e-3), X[2] + get_gaussian(g, 0, 5e-3));
+        if (i % 2 == 0) {
+            Point3Uncertainty C = Matrix3Type::Identity();
+            for (int k = 0; k < 3; ++k) C(k, k) = 1e-4;
+            pprior[i] = C;
+        }
+        const auto ua = ca.project_points({X})[0], ub = cb.project_points({X})[0];
+        const Point2Uncertainty C2 = 0.25 * Matrix2Type::Identity();
+        fobs[7][i] = Point2Estimate(Point2(ua.x + get_gaussian(g, 0, 0.5), ua.y + get_gaussian(g, 0, 0.5)), C2);
+        if (i != 104)
+            fobs[9][i] = Point2Estimate(Point2(ub.x + get_gaussian(g, 0, 0.5), ub.y + get_gaussian(g, 0, 0.5)), C2);
+    }
+    std::unordered_map<Id::Type, TransformationEstimate> fest;
+    std::unordered_map<Id::Type, Point3Estimate> pest;
+    ScalarType err = -1;
+    ba_frame_pose_and_point(K, fid, pid, guess, fprior, pguess, pprior, fobs, fest, pest, err);
+    ASSERT_TRUE(fest.size() == 2 && pest.size() == 40 && err > 0);
+    const Vector6Type a = fest[7].mean().ln(), a0 = Ta.ln(), b = fest[9].mean().ln(), b0 = Tb.ln();
+    for (int i = 0; i < 6; ++i) ASSERT_EQUAL(a[i], a0[i], 1e-3);     // anchored
+    for (int i = 0; i < 6; ++i) ASSERT_EQUAL(b[i], b0[i], 2e-2);     // regularised, pulled to the data
+    for (const auto &kv : pest) {
+        const bool has_prior = kv.first % 2 == 0;   // without a prior the depth of a point is known to ~0.16 (0.5 px, b 0.3)
+        for (int j = 0; j < 3; ++j) ASSERT_EQUAL(kv.second.mean()[j], truth[kv.first][j], has_prior ? 0.05 : (j == 2 ? 1.0 : 0.2));
+        ASSERT_TRUE(kv.second.covar()(2, 2) > 0 && (has_prior ? kv.second.covar()(2, 2) < 2e-4 : kv.second.covar()(2, 2) > 1e-3));
+    }
+    ASSERT_TRUE(fest[9].covar()(0, 0) > fest[7].covar()(0, 0));   // the anchored frame is the better known one
+}
+
 static void visual_feature_extract_and_match()
 {   // VisualFeature::extract on a synthetic textured frame and its copy shifted by 7 px: the matches carry the shift
     std::mt19937 g(3);
@@ -370,6 +420,7 @@ int main()
         RUN(sfm_refine_L_shape);
         RUN(pnp_refine_L_shape);
         RUN(image_pair_refine);
+        RUN(ba_frame_pose_and_point_two_frames);
         RUN(visual_feature_extract_and_match);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION: %s\n", e.what());

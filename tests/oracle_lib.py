@@ -451,6 +451,36 @@ def pnp_refine(world, world_cov, img, img_cov, K, R_guess, t_guess, params=None)
     return dict(ok=bool(ok), R=R, t=t, pose_cov=pc, error=err.value, iterations=it.value)
 
 
+def ba_refine(K, frame_pose, frame_prior_var, points, point_prior_cov, obs, obs_cov, obs_valid, params=None):
+    """frame_pose [F, 12], frame_prior_var [F, 6], obs / obs_cov / obs_valid: lists of length F (entries may be None)"""
+    fp, fv, pg = _f64(frame_pose).reshape(-1, 12), _f64(frame_prior_var).reshape(-1, 6), _f64(points).reshape(-1, 3)
+    F, m = len(fp), len(pg)
+    params = params or make_refine_params()
+    keep = []
+
+    def arr(a, shape, t=C.c_double, dt=np.float64):
+        if a is None:
+            return None
+        x = np.ascontiguousarray(a, dtype=dt).reshape(shape)
+        keep.append(x)
+        return x.ctypes.data_as(C.POINTER(t))
+    P2 = C.POINTER(C.c_double) * 2
+    PV = C.POINTER(C.c_uint8) * 2
+    o_, c_, v_ = P2(), P2(), PV()
+    for f in range(F):
+        o_[f] = arr(obs[f], (m, 2))
+        c_[f] = arr(obs_cov[f], (m, 4)) if obs_cov[f] is not None else None
+        v_[f] = arr(obs_valid[f], (m,), C.c_uint8, np.uint8) if obs_valid[f] is not None else None
+    R, t, pc = np.zeros((F, 3, 3)), np.zeros((F, 3)), np.zeros((F, 6, 6))
+    pts, ptc = np.zeros((m, 3)), np.zeros((m, 3, 3))
+    err, it = C.c_double(0), C.c_int(0)
+    lib().orc_ba_refine.restype = C.c_int
+    ok = lib().orc_ba_refine(C.c_int(F), C.c_int(m), _p(_f64(K, (3, 3))), _p(fp), _p(fv), _p(pg),
+                             arr(point_prior_cov, (m, 9)), o_, c_, v_, C.byref(params), _p(R), _p(t), _p(pc), _p(pts),
+                             _p(ptc), C.byref(err), C.byref(it))
+    return dict(ok=bool(ok), R=R, t=t, pose_cov=pc, points=pts, point_cov=ptc, error=err.value, iterations=it.value)
+
+
 # ---- ORB-style extraction (row f3) ---------------------------------------------------
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),

@@ -193,6 +193,76 @@ def test_oracle_cheirality_point_does_not_break_the_solve():
     assert np.abs(res["t"] - pb["t_true"]).max() < 0.05
 
 
+def track_refine_problem(seed, m, n_new):
+    """the shape of VisualOdometer::track_refine (front-end/visual-odometer.cpp:618-800): the last frame anchored at its
+    own pose, the new frame regularised, tracked points with isotropic priors, n_new new points without any, and each
+    frame missing some observations (every point keeps at least one; prior-less points keep both)"""
+    rng = np.random.default_rng(seed)
+    K = np.array([[525.0, 0, 320], [0, 525, 240], [0, 0, 1]])
+    X = np.stack([rng.uniform(-2, 2, m), rng.uniform(-1.5, 1.5, m), rng.uniform(4, 9, m)], 1)
+    Ra = Rot.from_rotvec([0.02, -0.1, 0.03]).as_matrix()
+    ta = np.array([0.4, -0.1, 0.2])
+    Rb = Ra @ Rot.from_rotvec(rng.normal(0, 0.02, 3)).as_matrix()
+    tb = ta + np.array([0.3, 0.02, 0.05])
+    sig = 0.5
+    obs = [proj(K, Ra, ta, X) + rng.normal(0, sig, (m, 2)), proj(K, Rb, tb, X) + rng.normal(0, sig, (m, 2))]
+    cov = np.tile((np.eye(2) * sig ** 2).reshape(4), (m, 1))
+    has_prior = np.ones(m, bool)
+    has_prior[rng.choice(m, n_new, replace=False)] = False
+    valid = [np.ones(m, np.uint8), np.ones(m, np.uint8)]
+    for i in rng.choice(np.nonzero(has_prior)[0], m // 5, replace=False):
+        valid[int(rng.integers(0, 2))][i] = 0
+    pcov = np.zeros((m, 9))
+    pcov[has_prior] = (np.eye(3) * 1e-2 ** 2).reshape(9)
+    Xg = X + rng.normal(0, 5e-3, X.shape)
+    Rbg = Rb @ Rot.from_rotvec(rng.normal(0, 5e-3, 3)).as_matrix()
+    tbg = tb + rng.normal(0, 5e-3, 3)
+    poses = np.stack([np.concatenate([Ra.reshape(9), ta]), np.concatenate([Rbg.reshape(9), tbg])])
+    var = np.stack([np.full(6, 1e-5), np.full(6, 1e-2)])     # the reference passes the stddev as the variance (:687-699)
+    return dict(K=K, X=X, poses=poses, var=var, Xg=Xg, pcov=pcov, obs=obs, cov=[cov, cov], valid=valid, has_prior=has_prior,
+                sig=sig, Rb=Rb, tb=tb)
+
+
+def test_oracle_ba_refine_general_two_frame_problem_is_the_minimiser():
+    pb = track_refine_problem(3, 24, 5)
+    m = 24
+    res = o.ba_refine(pb["K"], pb["poses"], pb["var"], pb["Xg"], pb["pcov"], pb["obs"], pb["cov"], pb["valid"])
+    assert res["ok"]
+    Rg = [pb["poses"][f][:9].reshape(3, 3) for f in range(2)]
+    tg = [pb["poses"][f][9:] for f in range(2)]
+
+    def resid(x):
+        r = []
+        P = x[12:].reshape(m, 3)
+        for f in range(2):
+            R = Rg[f] @ Rot.from_rotvec(x[6 * f:6 * f + 3]).as_matrix()
+            t = x[6 * f + 3:6 * f + 6]
+            sd = np.sqrt(pb["var"][f])
+            r += [Rot.from_matrix(Rg[f].T @ R).as_rotvec() / sd[:3], Rg[f].T @ (t - tg[f]) / sd[3:]]
+            e = (proj(pb["K"], R, t, P) - pb["obs"][f]) / pb["sig"]
+            r.append((e * pb["valid"][f][:, None]).ravel())
+        r.append((((P - pb["Xg"]) / 1e-2) * pb["has_prior"][:, None]).ravel())
+        return np.concatenate(r)
+
+    x0 = np.concatenate([np.zeros(3), tg[0], np.zeros(3), tg[1], pb["Xg"].ravel()])
+    sol = least_squares(resid, x0, xtol=1e-15, ftol=1e-15, gtol=1e-15, method="trf", jac="3-point", x_scale="jac")
+    assert abs(0.5 * np.sum(sol.fun ** 2) - res["error"]) <= 1e-9 * res["error"]
+    for f in range(2):
+        R = Rg[f] @ Rot.from_rotvec(sol.x[6 * f:6 * f + 3]).as_matrix()
+        assert np.abs(R - res["R"][f]).max() < 1e-8 and np.abs(sol.x[6 * f + 3:6 * f + 6] - res["t"][f]).max() < 1e-8
+    assert np.abs(sol.x[12:].reshape(m, 3) - res["points"]).max() < 1e-7
+    # the anchored frame barely moves, the new frame gets close to the truth
+    assert np.abs(res["t"][0] - tg[0]).max() < 1e-3 and np.abs(res["t"][1] - pb["tb"]).max() < 0.02
+    # sfm_refine is the special case: camera 1 at the identity, sigma 1e-5 / 1e-2, all points with sigma 1e-2
+    tv = two_view_problem(1, 12)
+    a = o.sfm_refine(tv["p1"], tv["cov"], tv["p2"], tv["cov"], tv["K"], tv["Rg"], tv["tg"], tv["Xg"])
+    poses = np.stack([np.concatenate([np.eye(3).reshape(9), np.zeros(3)]), np.concatenate([tv["Rg"].reshape(9), tv["tg"]])])
+    b = o.ba_refine(tv["K"], poses, np.stack([np.full(6, 1e-10), np.full(6, 1e-4)]), tv["Xg"],
+                    np.tile((np.eye(3) * 1e-4).reshape(9), (12, 1)), [tv["p1"], tv["p2"]], [tv["cov"], tv["cov"]], [None, None])
+    assert np.abs(a["R"] - b["R"][1]).max() < 1e-12 and np.abs(a["t"] - b["t"][1]).max() < 1e-12
+    assert np.abs(a["pose_cov"] - b["pose_cov"][1]).max() <= 1e-9 * np.abs(a["pose_cov"]).max()
+
+
 def _golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "refine_small.npz"))
 
@@ -305,6 +375,25 @@ def test_gpu_pnp_refine_matches_oracle(ctx, m, seed):
     _close(got["pose_cov"], ref["pose_cov"], 1e-7, "pose_cov")
     # the refined pose is closer to the truth than a 5e-3 guess on average; at least it must not be far
     assert np.abs(got["t"] - pb["t_true"]).max() < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n_new,seed", [(24, 5, 3), (400, 60, 4), (1500, 0, 5)])
+def test_gpu_ba_refine_matches_oracle(ctx, m, n_new, seed):
+    """mvs_ba_refine on track_refine-shaped problems: own anchor pose, prior-less points, missing observations"""
+    pb = track_refine_problem(seed, m, n_new)
+    want = o.ba_refine(pb["K"], pb["poses"], pb["var"], pb["Xg"], pb["pcov"], pb["obs"], pb["cov"], pb["valid"])
+    got = ctx.ba_refine(pb["K"], pb["poses"], pb["var"], pb["Xg"], pb["pcov"], pb["obs"], pb["cov"], pb["valid"])
+    assert got["ok"] and want["ok"] and got["iterations"] == want["iterations"]
+    assert abs(got["error"] - want["error"]) <= 1e-10 * want["error"]
+    assert np.abs(got["R"] - want["R"]).max() < 1e-9 and np.abs(got["t"] - want["t"]).max() < 1e-9
+    assert np.abs(got["points"] - want["points"]).max() < 1e-8
+    for f in range(2):
+        _close(got["pose_cov"][f], want["pose_cov"][f], 1e-6, "pose_cov[%d]" % f)
+    _close(got["point_cov"], want["point_cov"], 1e-6, "point_cov")
+    # one frame, no point priors at all -> every point is unconstrained along its ray: no model, never a crash
+    one = ctx.ba_refine(pb["K"], pb["poses"][1:], pb["var"][1:], pb["Xg"], None, pb["obs"][1:], pb["cov"][1:], [None])
+    assert not one["ok"]
 
 
 @pytest.mark.gpu
