@@ -579,7 +579,7 @@ class Sequence:
         B, H, W = images.shape
         params = params or default_orb_params()
         st = lib().mvs_seq_upload_images(self._h, C.c_int(first), C.c_int(B), _ptr(images, C.c_uint8), C.c_int(W),
-                                         C.c_int(H), C.byref(params), _ptr(_f64(K, (9,)), C.c_double))
+                                         C.c_int(H), C.byref(params), None if K is None else _ptr(_f64(K, (9,)), C.c_double))
         self.ctx._check(st, "mvs_seq_upload_images")
 
     def refine_pairs(self, params=None, sigma_px=0.5):

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,6 +29,10 @@ struct mvs_ctx {
     void *d_orb = nullptr;      // extraction workspace
     size_t orb_bytes = 0;
     bool orb_ready = false;
+    // the ~50 launches of one extraction, captured once per (batch shape, parameters, buffers) and replayed
+    hipGraphExec_t orb_graph = nullptr;
+    OrbDev orb_graph_key{};
+    bool orb_graph_valid = false;
 };
 
 struct mvs_seq;
@@ -245,6 +250,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->orb_graph) (void)hipGraphExecDestroy(ctx->orb_graph);
     if (ctx->d_orb) (void)hipFree(ctx->d_orb);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
@@ -1784,7 +1790,26 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     HIP_TRY(ctx, hipMemcpyAsync(base + o_pat, pat, sizeof(pat), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d.pyr, images, (size_t)w * h * B, hipMemcpyHostToDevice, s));  // level 0 = the input
     HIP_TRY(ctx, hipStreamSynchronize(s));   // `pat` lives on this frame
-    launch_orb(d, s);
+    static const bool no_graph = std::getenv("MVS_NO_GRAPH") != nullptr;   // A/B switch for tools/extract_bench.py
+    if (no_graph) {
+        launch_orb(d, s);
+    } else {
+        if (!ctx->orb_graph_valid || std::memcmp(&ctx->orb_graph_key, &d, sizeof(d)) != 0) {
+            if (ctx->orb_graph) (void)hipGraphExecDestroy(ctx->orb_graph);
+            ctx->orb_graph = nullptr;
+            ctx->orb_graph_valid = false;
+            hipGraph_t graph = nullptr;
+            HIP_TRY(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            launch_orb(d, s);
+            HIP_TRY(ctx, hipStreamEndCapture(s, &graph));
+            const hipError_t ie = hipGraphInstantiate(&ctx->orb_graph, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIP_TRY(ctx, ie);
+            std::memcpy(&ctx->orb_graph_key, &d, sizeof(d));
+            ctx->orb_graph_valid = true;
+        }
+        HIP_TRY(ctx, hipGraphLaunch(ctx->orb_graph, s));
+    }
     HIP_TRY(ctx, hipGetLastError());
     int32_t ovf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&ovf, d.overflow, sizeof(ovf), hipMemcpyDeviceToHost, s));

@@ -15,6 +15,7 @@ ap.add_argument("--height", type=int, default=480)
 ap.add_argument("--features", type=int, default=2000)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--cpu-images", type=int, default=16)
+ap.add_argument("--resident", action="store_true", help="also time extraction straight into a resident sequence (no D2H)")
 args = ap.parse_args()
 
 
@@ -34,6 +35,16 @@ t0 = time.perf_counter()
 for _ in range(args.steps):
     out = ctx.extract(imgs, prm)
 ms = (time.perf_counter() - t0) * 1e3 / args.steps
+resident_ms = None
+if args.resident:
+    seq = capi.Sequence(ctx, args.images, args.features, 32)
+    K = np.array([[525.0, 0, 320], [0, 525, 240], [0, 0, 1]])
+    seq.upload_images(0, imgs, K, prm)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seq.upload_images(0, imgs, None, prm)
+    resident_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    seq.close()
 ctx.close()
 # algorithmic bytes per image (u8 pixels, pyramid = 3.16 x level 0): resize read+write, FAST read + score write, NMS read,
 # blur read + u16 write/read + write, descriptors: ~ 9 pyramid passes
@@ -57,4 +68,5 @@ print(json.dumps({
               % (args.width, args.height, args.features),
     "value": round(args.images / (ms * 1e-3), 1), "unit": "images/s", "ms_per_batch": round(ms, 3), "images": args.images,
     "mean_keypoints": float(out["n"].mean()), "algorithmic_MB_per_image": round(alg_bytes / 1e6, 2),
-    "cpu_baseline": cpu}))
+    "resident_ms_per_batch": None if resident_ms is None else round(resident_ms, 3),
+    "graph": os.environ.get("MVS_NO_GRAPH") is None, "cpu_baseline": cpu}))
