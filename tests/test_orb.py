@@ -236,6 +236,14 @@ def test_gpu_extract_against_golden_and_argument_errors(ctx):
     with pytest.raises(capi.MvsError) as e:
         ctx.extract(g["image"], capi.default_orb_params(nlevels=40))
     assert e.value.status == capi.MVS_ERR_INVALID_ARG
+    # more corners at one level than the candidate list holds (16384): reported, never silently truncated
+    noise = np.random.default_rng(0).integers(0, 256, size=(1, 1100, 1400), dtype=np.uint8)
+    with pytest.raises(capi.MvsError) as e:
+        ctx.extract(noise, capi.default_orb_params(nfeatures=100, nlevels=1, fast_threshold=5))
+    assert e.value.status == capi.MVS_ERR_CAPACITY
+    # ... and the context is still usable afterwards
+    again = ctx.extract(g["image"], capi.default_orb_params(nfeatures=int(g["nfeatures"]), nlevels=int(g["nlevels"])))
+    assert int(again["n"][0]) == n
 
 
 @pytest.mark.gpu
