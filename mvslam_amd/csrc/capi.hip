@@ -1744,9 +1744,27 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     size_t off = 0;
     const size_t o_pyr = off; off = up(off + T * B);
-    const size_t o_score = off; off = up(off + T * B);
     const size_t o_blur = off; off = up(off + T * B);
-    const size_t o_tmp = off; off = up(off + (size_t)w * h * B * 2);
+    // resize tables: for every level >= 1, {source index, 11-bit weight} per destination column, then per row
+    std::vector<int2> tab;
+    for (int l = 1; l < prm.nlevels; ++l) {
+        OrbLevel &Lv = d.level[l];
+        const OrbLevel &Pv = d.level[l - 1];
+        Lv.tab_offset = tab.size();
+        for (int pass = 0; pass < 2; ++pass) {
+            const long long sn = pass ? Pv.h : Pv.w, dn = pass ? Lv.h : Lv.w;
+            for (long long dd = 0; dd < dn; ++dd) {
+                const long long num = (2 * dd + 1) * sn - dn, den = 2 * dn;   // source coordinate = num / den (>= 0 here)
+                long long si = num >= 0 ? num / den : -1;
+                const long long fr = num - si * den;
+                int wgt = (int)((fr * 4096 + den) / (2 * den));               // round(frac * 2048)
+                if (si < 0) si = 0, wgt = 0;
+                if (si >= sn - 1) si = sn - 1;
+                tab.push_back(make_int2((int)si, wgt));
+            }
+        }
+    }
+    const size_t o_tab = off; off = up(off + std::max<size_t>(tab.size(), 1) * sizeof(int2));
     const size_t o_keys = off; off = up(off + B * L * kOrbCandCap * 8);
     const size_t o_cc = off; off = up(off + B * L * 4);
     const size_t o_sel = off; off = up(off + B * L * NF * sizeof(OrbSel));
@@ -1771,9 +1789,8 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     d.fast_threshold = prm.fast_threshold;
     d.cand_cap = kOrbCandCap;
     d.pyr = reinterpret_cast<uint8_t *>(base + o_pyr);
-    d.score = reinterpret_cast<uint8_t *>(base + o_score);
     d.blur = reinterpret_cast<uint8_t *>(base + o_blur);
-    d.tmp16 = reinterpret_cast<uint16_t *>(base + o_tmp);
+    d.resize_tab = reinterpret_cast<const int2 *>(base + o_tab);
     d.cand_keys = reinterpret_cast<uint64_t *>(base + o_keys);
     d.cand_count = reinterpret_cast<int32_t *>(base + o_cc);
     d.sel = reinterpret_cast<OrbSel *>(base + o_sel);
@@ -1788,8 +1805,10 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     int8_t pat[1024];
     orb_pattern_host(pat);
     HIP_TRY(ctx, hipMemcpyAsync(base + o_pat, pat, sizeof(pat), hipMemcpyHostToDevice, s));
+    if (!tab.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d.pyr, images, (size_t)w * h * B, hipMemcpyHostToDevice, s));  // level 0 = the input
-    HIP_TRY(ctx, hipStreamSynchronize(s));   // `pat` lives on this frame
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // `pat` and `tab` live on this frame
     static const bool no_graph = std::getenv("MVS_NO_GRAPH") != nullptr;   // A/B switch for tools/extract_bench.py
     if (no_graph) {
         launch_orb(d, s);

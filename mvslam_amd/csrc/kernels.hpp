@@ -199,6 +199,7 @@ struct OrbLevel {
     int n_keep;        // n_l: keypoints kept at this level
     float scale;       // 1.2^l
     size_t offset;     // pixels of one image's pyramid before this level
+    size_t tab_offset; // first entry of this level's resize table (w column entries, then h row entries)
 };
 struct OrbSel {        // a selected keypoint of one level
     int32_t x, y;
@@ -208,9 +209,8 @@ struct OrbDev {
     int n_images, n_levels, nfeatures, edge, fast_threshold, cand_cap;
     OrbLevel level[kOrbMaxLevels];
     uint8_t *pyr;          // [level][image][h_l][w_l]; level 0 = the input images
-    uint8_t *score;        // same layout: FAST scores
     uint8_t *blur;         // same layout: blurred levels
-    uint16_t *tmp16;       // [image][h_0][w_0] row-pass buffer
+    const int2 *resize_tab;  // per level >= 1: {source index, 11-bit weight} per destination column and row
     uint64_t *cand_keys;   // [image][level][cand_cap]
     int32_t *cand_count;   // [image][level]
     OrbSel *sel;           // [image][level][nfeatures]

@@ -6,12 +6,13 @@
 // reach (the CPU oracle oracle/mvs_orb_oracle.c follows the same specification bit for bit):
 //   resize_kernel    level l from level l-1: pixel-centre bilinear in integer arithmetic (11-bit weights from exact
 //                    rationals, (sum + 2^21) >> 22)                                           thread per pixel
-//   fast_kernel      FAST-9/16 score = the largest threshold at which the pixel is still a corner  thread per pixel
-//   nms_kernel       strict 3x3 maximum inside the edge margin -> rank key (score desc, y, x), appended with one atomic
-//                    per corner; the ORDER of the list does not matter, the select kernel sorts it
+//   fast_nms_kernel  FAST-9/16 score (the largest threshold at which the pixel is still a corner) and the strict 3x3
+//                    maximum of one 64x16 tile through LDS -> rank key (score desc, y, x), one atomic per tile; the
+//                    ORDER of the list does not matter, the select kernel sorts it
 //   select_kernel    one launch, one workgroup per (image, level): bitonic sort of the keys in LDS, keep 2 n_l, Harris response
 //                    (7x7, k = 0.04) of those, sort again by (response desc, y, x), keep n_l     (cv::ORB's retainBest)
-//   blur_h / blur_v  7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18}, BORDER_REFLECT_101
+//   blur_kernel      7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18}, BORDER_REFLECT_101, rows then columns
+//                    of one tile through LDS
 //   describe_kernel  half a wavefront per keypoint: intensity-centroid moments over the radius-15 disc (32 lanes split
 //                    the disc rows, butterfly sum), cos / sin = moments / hypot (no trigonometry), 256 steered BRIEF tests
 //                    on the blurred level (lane b < 32 builds byte b), cv::KeyPoint record
@@ -29,79 +30,23 @@ __constant__ int kFastDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1,
 __constant__ int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 __constant__ int kGauss[7] = {18, 34, 49, 54, 49, 34, 18};
 
-__global__ void resize_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+// tab: per destination column / row {source index, 11-bit weight of the next sample}, computed once per level on the
+// host from the exact rationals ((2 d + 1) s_src - s_dst) / (2 s_dst) -- 64-bit divisions per pixel were 3/4 of this kernel
+__global__ void resize_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, const int2 *xtab,
+                              const int2 *ytab)
 {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
     if (dx >= dw || dy >= dh)
         return;
     src += (size_t)blockIdx.z * sw * sh;
     dst += (size_t)blockIdx.z * dw * dh;
-    const long long ny = (long long)(2 * dy + 1) * sh - dh, dny = 2LL * dh;
-    long long sy = ny >= 0 ? ny / dny : -1;
-    const long long fy = ny - sy * dny;
-    int wy = (int)((fy * 4096 + dny) / (2 * dny));
-    if (sy < 0) sy = 0, wy = 0;
-    long long sy1 = sy + 1;
-    if (sy >= sh - 1) sy = sh - 1, sy1 = sh - 1;
-    const long long nx = (long long)(2 * dx + 1) * sw - dw, dnx = 2LL * dw;
-    long long sx = nx >= 0 ? nx / dnx : -1;
-    const long long fx = nx - sx * dnx;
-    int wx = (int)((fx * 4096 + dnx) / (2 * dnx));
-    if (sx < 0) sx = 0, wx = 0;
-    long long sx1 = sx + 1;
-    if (sx >= sw - 1) sx = sw - 1, sx1 = sw - 1;
+    const int2 tx = xtab[dx], ty = ytab[dy];
+    const int sx = tx.x, wx = tx.y, sy = ty.x, wy = ty.y;
+    const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
     const uint32_t p00 = src[sy * sw + sx], p01 = src[sy * sw + sx1], p10 = src[sy1 * sw + sx], p11 = src[sy1 * sw + sx1];
     const uint32_t v = p00 * (uint32_t)((2048 - wx) * (2048 - wy)) + p01 * (uint32_t)(wx * (2048 - wy)) +
                        p10 * (uint32_t)((2048 - wx) * wy) + p11 * (uint32_t)(wx * wy);
     dst[(size_t)dy * dw + dx] = (uint8_t)((v + (1u << 21)) >> 22);
-}
-
-__global__ void fast_kernel(const uint8_t *img, int W, int H, int threshold, uint8_t *score)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H)
-        return;
-    img += (size_t)blockIdx.z * W * H;
-    score += (size_t)blockIdx.z * W * H;
-    int out = 0;
-    if (x >= 3 && y >= 3 && x < W - 3 && y < H - 3) {
-        const int c = img[y * W + x];
-        // every arc of 9 contiguous circle pixels contains one pixel of each antipodal pair: if both pixels of a pair
-        // are within the threshold of the centre there is no corner (most pixels of a real image leave here)
-        const int d0 = (int)img[(y + 3) * W + x] - c, d8 = (int)img[(y - 3) * W + x] - c;
-        const int d4 = (int)img[y * W + x + 3] - c, d12 = (int)img[y * W + x - 3] - c;
-        const bool maybe = (max(abs(d0), abs(d8)) > threshold) && (max(abs(d4), abs(d12)) > threshold);
-        if (maybe) {
-            int d[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                d[k] = (int)img[(y + kFastDy[k]) * W + (x + kFastDx[k])] - c;
-            // min / max over every window of 9 by doubling: windows of 2, 4, 8, then one more element (min and max
-            // are associative, so this is the same number as the 16 x 9 scan)
-            int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                lo2[k] = min(d[k], d[(k + 1) & 15]);
-                hi2[k] = max(d[k], d[(k + 1) & 15]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-                hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
-            }
-            int best = -256;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // brighter arc: min of (ring - c)
-                const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // darker arc: min of (c - ring) = -max
-                best = max(best, max(lo9, -hi9));
-            }
-            const int s = best - 1;
-            if (s >= threshold)
-                out = s;
-        }
-    }
-    score[y * W + x] = (uint8_t)out;
 }
 
 __device__ __forceinline__ uint64_t rank_key(uint32_t value_desc, int y, int x)
@@ -109,40 +54,108 @@ __device__ __forceinline__ uint64_t rank_key(uint32_t value_desc, int y, int x)
     return ((uint64_t)(0xffffffffu - value_desc) << 32) | ((uint64_t)(uint32_t)y << 16) | (uint32_t)x;
 }
 
-__global__ void nms_kernel(const uint8_t *score, int W, int H, int edge, uint64_t *keys, int32_t *count, int cap,
-                           int level, int n_levels)
+// FAST-9/16 score of the pixel at LDS position c (row pitch P): the largest threshold at which it is still a corner,
+// 0 if below `threshold`
+__device__ __forceinline__ int fast_score_lds(const uint8_t *c, int P, int threshold)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x + edge, y = blockIdx.y * blockDim.y + threadIdx.y + edge;
-    const int b = blockIdx.z;
-    score += (size_t)b * W * H;
-    int s = 0;
-    bool is_max = false;
-    if (x < W - edge && y < H - edge) {
-        s = score[y * W + x];
-        is_max = s != 0;
+    const int ctr = c[0];
+    // every arc of 9 contiguous circle pixels contains one pixel of each antipodal pair: if both pixels of a pair are
+    // within the threshold of the centre there is no corner (most pixels of a real image leave here)
+    const int d0 = (int)c[3 * P] - ctr, d8 = (int)c[-3 * P] - ctr, d4 = (int)c[3] - ctr, d12 = (int)c[-3] - ctr;
+    if (!((max(abs(d0), abs(d8)) > threshold) && (max(abs(d4), abs(d12)) > threshold)))
+        return 0;
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        d[k] = (int)c[kFastDy[k] * P + kFastDx[k]] - ctr;
+    // min / max over every window of 9 by doubling: windows of 2, 4, 8, then one more element
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo2[k] = min(d[k], d[(k + 1) & 15]);
+        hi2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+    }
+    int best = -256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // brighter arc: min of (ring - centre)
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // darker arc: min of (centre - ring) = -max
+        best = max(best, max(lo9, -hi9));
+    }
+    const int sc = best - 1;
+    return sc >= threshold ? sc : 0;
+}
+
+// FAST + non-maximum suppression of one 64 x 16 tile through LDS: the image patch (tile + 4) is read from HBM once, the
+// scores of (tile + 1) never leave the CU, and the surviving corners are appended with ONE atomic per tile (all corners of
+// a level append to the same counter and same-address atomics serialise: one per wavefront was 46 % of the extraction).
+// Keys carry (score desc, y, x): the order of the list does not matter, select_kernel sorts it.
+constexpr int kTileW = 64, kTileH = 16;
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *img, int W, int H, int threshold, int edge, uint64_t *keys,
+                                                       int32_t *count, int cap, int level, int n_levels)
+{
+    constexpr int PW = kTileW + 8, PH = kTileH + 8;      // image patch: +-4 (NMS 1 + circle 3)
+    constexpr int SW = kTileW + 2, SH = kTileH + 2;      // score patch: +-1
+    __shared__ uint8_t s_img[PH * PW];
+    __shared__ uint8_t s_sc[SH * SW];
+    __shared__ int wave_off[4];
+    __shared__ int tile_base;
+    const int b = blockIdx.z, tid = threadIdx.x;
+    img += (size_t)b * W * H;
+    const int x0 = edge + blockIdx.x * kTileW, y0 = edge + blockIdx.y * kTileH;   // first output pixel of the tile
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int py = i / PW, px = i - py * PW;
+        const int gx = min(max(x0 - 4 + px, 0), W - 1), gy = min(max(y0 - 4 + py, 0), H - 1);   // clamped reads are never used
+        s_img[i] = img[gy * W + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < SH * SW; i += 256) {
+        const int qy = i / SW, qx = i - qy * SW;
+        const int gx = x0 - 1 + qx, gy = y0 - 1 + qy;
+        int sc = 0;
+        if (gx >= 3 && gy >= 3 && gx < W - 3 && gy < H - 3)
+            sc = fast_score_lds(s_img + (qy + 3) * PW + (qx + 3), PW, threshold);
+        s_sc[i] = (uint8_t)sc;
+    }
+    __syncthreads();
+    // 4 output pixels per thread: rows ty, ty + 4, ty + 8, ty + 12 of column tx
+    const int tx = tid & 63, ty = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long masks[4];
+    int scs[4];
+    int total_wave = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = ty + 4 * r;
+        const int gx = x0 + tx, gy = y0 + oy;
+        const uint8_t *c = s_sc + (oy + 1) * SW + (tx + 1);
+        const int sc = c[0];
+        bool is_max = sc != 0 && gx < W - edge && gy < H - edge;
         if (is_max) {
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx)
-                    if ((dx || dy) && score[(y + dy) * W + x + dx] >= s)
+                    if ((dx || dy) && c[dy * SW + dx] >= sc)
                         is_max = false;
         }
+        scs[r] = is_max ? sc : 0;
+        masks[r] = __ballot(is_max);
+        total_wave += __popcll(masks[r]);
     }
-    // one global atomic per 32x32 tile: all corners of a level append to the same counter, and same-address atomics
-    // serialise (one per wavefront was 46 % of the whole extraction)
-    __shared__ int wave_off[16];
-    __shared__ int tile_base;
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long mask = __ballot(is_max);
     if (lane == 0)
-        wave_off[wave] = __popcll(mask);
+        wave_off[wave] = total_wave;
     __syncthreads();
     const size_t slot = (size_t)b * n_levels + level;
     if (tid == 0) {
         int total = 0;
-        const int nw = (blockDim.x * blockDim.y + 63) >> 6;
-        for (int w = 0; w < nw; ++w) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
             const int c = wave_off[w];
             wave_off[w] = total;
             total += c;
@@ -150,10 +163,15 @@ __global__ void nms_kernel(const uint8_t *score, int W, int H, int edge, uint64_
         tile_base = total ? atomicAdd(&count[slot], total) : 0;
     }
     __syncthreads();
-    if (is_max) {
-        const int idx = tile_base + wave_off[wave] + __popcll(mask & ((1ull << lane) - 1ull));
-        if (idx < cap)
-            keys[slot * cap + idx] = rank_key((uint32_t)s, y, x);
+    int base = tile_base + wave_off[wave];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (scs[r]) {
+            const int idx = base + __popcll(masks[r] & ((1ull << lane) - 1ull));
+            if (idx < cap)
+                keys[slot * cap + idx] = rank_key((uint32_t)scs[r], y0 + ty + 4 * r, x0 + tx);
+        }
+        base += __popcll(masks[r]);
     }
 }
 
@@ -253,40 +271,76 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
     }
 }
 
-__global__ void blur_h_kernel(const uint8_t *img, int W, int H, uint16_t *tmp)
+// 7x7 sigma-2 blur of one 64 x 16 tile: rows then columns through LDS (Q8 kernel, BORDER_REFLECT_101, u16 row sums).
+// Every work item produces 4 adjacent pixels from dword LDS reads (3 per row item, 14 per column item); byte-wide LDS
+// reads made the first LDS version slower than two global passes.
+__global__ __launch_bounds__(256) void blur_kernel(const uint8_t *img, int W, int H, uint8_t *out)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H)
-        return;
+    constexpr int PW = kTileW + 8, PH = kTileH + 6;   // 72-byte pitch: output column 4k starts at a dword of the patch
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[PH * PW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_row[PH * kTileW];
+    const int tid = threadIdx.x;
     img += (size_t)blockIdx.z * W * H;
-    tmp += (size_t)blockIdx.z * W * H;
-    int s = 0;
-#pragma unroll
-    for (int k = -3; k <= 3; ++k) {
-        int xx = x + k;
-        if (xx < 0) xx = -xx;
-        if (xx >= W) xx = 2 * (W - 1) - xx;
-        s += kGauss[k + 3] * img[y * W + xx];
-    }
-    tmp[y * W + x] = (uint16_t)s;
-}
-
-__global__ void blur_v_kernel(const uint16_t *tmp, int W, int H, uint8_t *out)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H)
-        return;
-    tmp += (size_t)blockIdx.z * W * H;
     out += (size_t)blockIdx.z * W * H;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = -3; k <= 3; ++k) {
-        int yy = y + k;
-        if (yy < 0) yy = -yy;
-        if (yy >= H) yy = 2 * (H - 1) - yy;
-        s += (uint32_t)kGauss[k + 3] * tmp[yy * W + x];
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int py = i / PW, px = i - py * PW;
+        int gx = x0 - 3 + px, gy = y0 - 3 + py;
+        if (gx < 0) gx = -gx;
+        if (gx >= W) gx = 2 * (W - 1) - gx;
+        if (gy < 0) gy = -gy;
+        if (gy >= H) gy = 2 * (H - 1) - gy;
+        gx = min(max(gx, 0), W - 1);   // only for tile pixels beyond the image (never written)
+        gy = min(max(gy, 0), H - 1);
+        s_img[i] = img[gy * W + gx];
     }
-    out[y * W + x] = (uint8_t)((s + 32768u) >> 16);
+    __syncthreads();
+    for (int i = tid; i < PH * (kTileW / 4); i += 256) {   // row pass: 4 outputs from 10 patch bytes
+        const int py = i / (kTileW / 4), q = i - py * (kTileW / 4);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(s_img + py * PW + 4 * q);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        int p[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p[k] = (w0 >> (8 * k)) & 0xff;
+            p[4 + k] = (w1 >> (8 * k)) & 0xff;
+            p[8 + k] = (w2 >> (8 * k)) & 0xff;
+        }
+        uint32_t r[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                sum += kGauss[k] * p[o + k];
+            r[o] = (uint32_t)sum;
+        }
+        uint2 pack;
+        pack.x = r[0] | (r[1] << 16);
+        pack.y = r[2] | (r[3] << 16);
+        *reinterpret_cast<uint2 *>(s_row + py * kTileW + 4 * q) = pack;
+    }
+    __syncthreads();
+    {   // column pass: thread = (row ty, column group q), 4 outputs
+        const int q = tid & 15, oy = tid >> 4;
+        uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(s_row + (oy + k) * kTileW + 4 * q);
+            const uint32_t g = (uint32_t)kGauss[k];
+            acc[0] += g * (v.x & 0xffffu);
+            acc[1] += g * (v.x >> 16);
+            acc[2] += g * (v.y & 0xffffu);
+            acc[3] += g * (v.y >> 16);
+        }
+        const int gx = x0 + 4 * q, gy = y0 + oy;
+        if (gy < H) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (gx + o < W)
+                    out[gy * W + gx + o] = (uint8_t)((acc[o] + 32768u) >> 16);
+        }
+    }
 }
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -432,20 +486,19 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
         if (L.w < 1 || L.h < 1)
             break;
         uint8_t *img = d.pyr + L.offset * B;
-        const dim3 grid((L.w + 31) / 32, (L.h + 7) / 8, B);
         if (l > 0) {
             const OrbLevel &Pv = d.level[l - 1];
-            hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, img, L.w, L.h);
+            const dim3 grid((L.w + 31) / 32, (L.h + 7) / 8, B);
+            hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, img, L.w, L.h,
+                               d.resize_tab + L.tab_offset, d.resize_tab + L.tab_offset + L.w);
         }
         if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
             continue;
-        uint8_t *score = d.score + L.offset * B;
-        hipLaunchKernelGGL(fast_kernel, grid, blk, 0, stream, img, L.w, L.h, d.fast_threshold, score);
-        const dim3 gin((L.w - 2 * d.edge + 31) / 32, (L.h - 2 * d.edge + 31) / 32, B);
-        hipLaunchKernelGGL(nms_kernel, gin, dim3(32, 32), 0, stream, score, L.w, L.h, d.edge, d.cand_keys, d.cand_count, d.cand_cap, l,
-                           d.n_levels);
-        hipLaunchKernelGGL(blur_h_kernel, grid, blk, 0, stream, img, L.w, L.h, d.tmp16);
-        hipLaunchKernelGGL(blur_v_kernel, grid, blk, 0, stream, d.tmp16, L.w, L.h, d.blur + L.offset * B);
+        const dim3 gin((L.w - 2 * d.edge + kTileW - 1) / kTileW, (L.h - 2 * d.edge + kTileH - 1) / kTileH, B);
+        hipLaunchKernelGGL(fast_nms_kernel, gin, dim3(256), 0, stream, img, L.w, L.h, d.fast_threshold, d.edge, d.cand_keys,
+                           d.cand_count, d.cand_cap, l, d.n_levels);
+        const dim3 gb((L.w + kTileW - 1) / kTileW, (L.h + kTileH - 1) / kTileH, B);
+        hipLaunchKernelGGL(blur_kernel, gb, dim3(256), 0, stream, img, L.w, L.h, d.blur + L.offset * B);
     }
     hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), (size_t)d.cand_cap * sizeof(uint64_t), stream,
                        d);   // LDS limit raised in orb_prepare()
