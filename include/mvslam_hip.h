@@ -353,6 +353,14 @@ mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int wi
 mvs_status mvs_seq_upload_images(mvs_seq *s, int first, int count, const uint8_t *images, int width, int height,
                                  const mvs_orb_params *params, const double K[9]);
 
+/* Scale propagation and trajectory of a sequence that has been run (the last stage of mvs_seq_run; row f2,
+ * front-end/visual-odometer.cpp:422-445,577-588).  Pair k has a unit baseline; track q is in pair q's scale;
+ *   track_scale[q] = |(pair_q^-1 o track_q).t| = baseline(pair q+1) / baseline(pair q)      (n_frames - 2 entries)
+ *   pair_scale[k]  = prod_{j<k} track_scale[j] = pair k's baseline in units of pair 0's      (n_frames - 1 entries)
+ *   R / t          = pose of frame k in frame 0: G_0 = I, G_1 = pair 0, G_{q+2} = G_q o (R_track_q, pair_scale[q] t_track_q)
+ * (a failed track keeps the scale and falls back to the two-view pose of pair q+1).  Any pointer may be NULL. */
+mvs_status mvs_seq_download_trajectory(mvs_seq *s, double *R, double *t, double *pair_scale, double *track_scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,7 +111,7 @@ EXPORTS = [
     "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
     "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
-    "mvs_ba_refine",
+    "mvs_ba_refine", "mvs_seq_download_trajectory",
 ]
 
 
@@ -581,6 +581,15 @@ class Sequence:
         st = lib().mvs_seq_upload_images(self._h, C.c_int(first), C.c_int(B), _ptr(images, C.c_uint8), C.c_int(W),
                                          C.c_int(H), C.byref(params), None if K is None else _ptr(_f64(K, (9,)), C.c_double))
         self.ctx._check(st, "mvs_seq_upload_images")
+
+    def download_trajectory(self):
+        """pose of every frame in frame 0 (pair 0's baseline = 1), pair and track scales (scale propagation, row f2)"""
+        F = self.n_frames
+        R, t, ps, ts = np.zeros((F, 3, 3)), np.zeros((F, 3)), np.zeros(F - 1), np.zeros(F - 2)
+        st = lib().mvs_seq_download_trajectory(self._h, _ptr(R, C.c_double), _ptr(t, C.c_double), _ptr(ps, C.c_double),
+                                               _ptr(ts, C.c_double))
+        self.ctx._check(st, "mvs_seq_download_trajectory")
+        return dict(R=R, t=t, pair_scale=ps, track_scale=ts)
 
     def refine_pairs(self, params=None, sigma_px=0.5):
         params = params or default_refine_params()

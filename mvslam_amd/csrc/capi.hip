@@ -55,6 +55,7 @@ struct mvs_seq {
     int n_frames = 0, n_tracks = 0, stride = 0, rec_groups = 0;
     SeqJoinDev join{};
     PnpDev pnp{};
+    SeqChainDev chain{};
     std::vector<void *> allocs;
 };
 
@@ -992,6 +993,11 @@ mvs_status mvs_seq_create(mvs_ctx *ctx, int n_frames, int max_kp, int desc_bytes
     SALLOC(inl, T * S);
     SALLOC(gidx, T);
     SALLOC(po, T);
+    double *traj_R = nullptr, *traj_t = nullptr, *traj_s = nullptr, *trk_s = nullptr;   // scale-propagation fold outputs
+    SALLOC(traj_R, (size_t)n_frames * 9);
+    SALLOC(traj_t, (size_t)n_frames * 3);
+    SALLOC(traj_s, (size_t)n_frames);
+    SALLOC(trk_s, (size_t)n_frames);
 #undef SALLOC
     if (st != MVS_OK) {
         mvs_seq_destroy(q);
@@ -1028,6 +1034,13 @@ mvs_status mvs_seq_create(mvs_ctx *ctx, int n_frames, int max_kp, int desc_bytes
     q->pnp.fb = fb;
     q->pnp.inliers = inl;
     q->pnp.out = po;
+    q->chain.n_frames = n_frames;
+    q->chain.results = d.results;
+    q->chain.tracks = po;
+    q->chain.traj_R = traj_R;
+    q->chain.traj_t = traj_t;
+    q->chain.traj_sigma = traj_s;
+    q->chain.track_scale = trk_s;
     q->pnp.rec = nullptr;
     q->pnp.max_groups = 0;
     *out = q;
@@ -1135,6 +1148,8 @@ static mvs_status seq_enqueue(mvs_seq *q, const RunParams &rp)
         return st;
     launch_seq_join(q->join, q->ctx->stream);
     launch_pnp(q->pnp, q->ctx->stream);
+    q->chain.n_corr = q->pnp.n;
+    launch_seq_chain(q->chain, q->ctx->stream);
     HIP_TRY(q->ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -1631,6 +1646,26 @@ mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, 
         HIP_TRY(ctx, hipMemcpyAsync(points_xyz, d.pts, P * N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (point_cov)
         HIP_TRY(ctx, hipMemcpyAsync(point_cov, d.point_cov, P * N * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MVS_OK;
+}
+
+mvs_status mvs_seq_download_trajectory(mvs_seq *q, double *R, double *t, double *pair_scale, double *track_scale)
+{
+    if (!q)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = q->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t F = q->n_frames;
+    if (R)
+        HIP_TRY(ctx, hipMemcpyAsync(R, q->chain.traj_R, F * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (t)
+        HIP_TRY(ctx, hipMemcpyAsync(t, q->chain.traj_t, F * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (pair_scale)
+        HIP_TRY(ctx, hipMemcpyAsync(pair_scale, q->chain.traj_sigma, (F - 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (track_scale)
+        HIP_TRY(ctx, hipMemcpyAsync(track_scale, q->chain.track_scale, (F - 2) * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return MVS_OK;
 }

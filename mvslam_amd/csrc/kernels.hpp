@@ -153,6 +153,19 @@ struct SeqJoinDev {
 };
 void launch_seq_join(const SeqJoinDev &j, hipStream_t stream);
 
+// scale propagation + trajectory of a sequence (sequential fold over the frames, pnp.hip)
+struct SeqChainDev {
+    int n_frames;
+    const mvs_pair_result *results;  // [n_frames - 1]
+    const PnpOut *tracks;            // [n_frames - 2]
+    const int32_t *n_corr;           // [n_frames - 2]
+    double *traj_R;                  // [n_frames][9] pose of frame k in frame 0 (pair 0's baseline = 1)
+    double *traj_t;                  // [n_frames][3]
+    double *traj_sigma;              // [n_frames - 1] sigma_k = pair k's unit baseline in units of pair 0's
+    double *track_scale;             // [n_frames - 2]
+};
+void launch_seq_chain(const SeqChainDev &c, hipStream_t stream);
+
 // ---- sfm_refine / pnp_refine (row f4): batched Schur-complement Levenberg-Marquardt ---------------------------
 struct RefineCfg {
     int max_iterations;

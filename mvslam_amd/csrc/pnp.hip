@@ -517,4 +517,78 @@ void launch_pnp(const PnpDev &p, hipStream_t stream)
     hipLaunchKernelGGL(pnp_finalize_kernel, dim3(Q), dim3(256), 0, stream, p);
 }
 
+// ---- scale propagation and trajectory of a sequence (row f2; front-end/visual-odometer.cpp:422-445,577-588) ------------
+// Pair k gives the pose of frame k+1 in frame k with a UNIT baseline; track q gives the pose of frame q+2 in frame q in pair
+// q's scale.  rel_q = pair_q^-1 o track_q is the pose of frame q+2 in frame q+1 in pair q's scale, so
+//   scale_q = |rel_q.t| = baseline(pair q+1) / baseline(pair q)      (visual-odometer.cpp:583-587)
+//   sigma_0 = 1, sigma_{q+1} = sigma_q * scale_q                    (everything in pair 0's baseline)
+//   G_0 = I, G_1 = pair_0, G_{q+2} = G_q o (R_track_q, sigma_q t_track_q)           (the PnP pose is the frame pose)
+// A failed track keeps the scale (scale_q = 1) and falls back to the two-view pose: G_{q+2} = G_{q+1} o (R, sigma t) of
+// pair q+1; an invalid pair contributes the identity.  A sequential fold (the order of operations is part of the
+// specification, the CPU oracle repeats it): one lane, ~45 flops per frame.
+__global__ void seq_chain_kernel(SeqChainDev c)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    const int F = c.n_frames;
+    double Ga[12], Gb[12];   // G_q and G_{q+1}: R (9) t (3)
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        Ga[k] = (k < 9 && k % 4 == 0) ? 1.0 : 0.0;
+    auto store = [&](int f, const double *G) {
+        for (int k = 0; k < 9; ++k)
+            c.traj_R[9 * (size_t)f + k] = G[k];
+        for (int k = 0; k < 3; ++k)
+            c.traj_t[3 * (size_t)f + k] = G[9 + k];
+    };
+    auto compose = [](const double *A, const double *R, const double *t, double sig, double *out) {
+        // out = A o (R, sig * t):  R_out = A.R R,  t_out = A.R (sig t) + A.t
+        const double s0 = sig * t[0], s1 = sig * t[1], s2 = sig * t[2];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j)
+                out[3 * i + j] = (A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j]) + A[3 * i + 2] * R[6 + j];
+            out[9 + i] = ((A[3 * i] * s0 + A[3 * i + 1] * s1) + A[3 * i + 2] * s2) + A[9 + i];
+        }
+    };
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
+    double sigma = 1.0;
+    store(0, Ga);
+    c.traj_sigma[0] = 1.0;
+    {
+        const mvs_pair_result &p0 = c.results[0];
+        compose(Ga, p0.valid ? p0.R : I3, p0.valid ? p0.t : Z3, 1.0, Gb);
+    }
+    store(1, Gb);
+    for (int q = 0; q + 2 < F; ++q) {
+        const mvs_pair_result &pq = c.results[q], &pn = c.results[q + 1];
+        const PnpOut &tr = c.tracks[q];
+        const bool ok = c.n_corr[q] >= 7 && tr.ok && pq.valid;
+        double scale = 1.0, Gn[12];
+        if (ok) {
+            // rel.t = R_pair^T (t_track - t_pair)
+            const double d0 = tr.t[0] - pq.t[0], d1 = tr.t[1] - pq.t[1], d2 = tr.t[2] - pq.t[2];
+            const double r0 = (pq.R[0] * d0 + pq.R[3] * d1) + pq.R[6] * d2;
+            const double r1 = (pq.R[1] * d0 + pq.R[4] * d1) + pq.R[7] * d2;
+            const double r2 = (pq.R[2] * d0 + pq.R[5] * d1) + pq.R[8] * d2;
+            scale = sqrt((r0 * r0 + r1 * r1) + r2 * r2);
+            compose(Ga, tr.R, tr.t, sigma, Gn);
+        } else {
+            compose(Gb, pn.valid ? pn.R : I3, pn.valid ? pn.t : Z3, sigma, Gn);
+        }
+        c.track_scale[q] = scale;
+        sigma = sigma * scale;
+        c.traj_sigma[q + 1] = sigma;
+        store(q + 2, Gn);
+        for (int k = 0; k < 12; ++k) {
+            Ga[k] = Gb[k];
+            Gb[k] = Gn[k];
+        }
+    }
+}
+
+void launch_seq_chain(const SeqChainDev &c, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_chain_kernel, dim3(1), dim3(64), 0, stream, c);
+}
+
 }  // namespace mvs

@@ -1294,3 +1294,56 @@ int orc_pnp_solve(const double *world_xyz, const double *image_uv, int n, const 
     free(fb);
     return ok;
 }
+
+
+/* ---- scale propagation and trajectory of a sequence (row f2; front-end/visual-odometer.cpp:422-445,577-588) ----
+ * pair k: pose of frame k+1 in frame k, unit baseline; track q: pose of frame q+2 in frame q in pair q's scale.
+ *   track_scale[q] = |(pair_q^-1 o track_q).t|, sigma_0 = 1, sigma_{q+1} = sigma_q track_scale[q]
+ *   G_0 = I, G_1 = pair_0, G_{q+2} = G_q o (R_track_q, sigma_q t_track_q)
+ * a failed track keeps the scale and uses pair q+1: G_{q+2} = G_{q+1} o (R, sigma t); an invalid pair is the identity. */
+static void chain_compose(const double *A, const double *R, const double *t, double sig, double *out)
+{
+    const double s0 = sig * t[0], s1 = sig * t[1], s2 = sig * t[2];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            out[3 * i + j] = (A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j]) + A[3 * i + 2] * R[6 + j];
+        out[9 + i] = ((A[3 * i] * s0 + A[3 * i + 1] * s1) + A[3 * i + 2] * s2) + A[9 + i];
+    }
+}
+
+void orc_seq_chain(int n_frames, const double *pair_R, const double *pair_t, const int32_t *pair_valid,
+                   const double *track_R, const double *track_t, const int32_t *track_ok, double *traj_R, double *traj_t,
+                   double *pair_scale, double *track_scale)
+{
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
+    double Ga[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, Gb[12], Gn[12];
+    double sigma = 1.0;
+    memcpy(traj_R, Ga, 9 * sizeof(double));
+    memcpy(traj_t, Ga + 9, 3 * sizeof(double));
+    pair_scale[0] = 1.0;
+    chain_compose(Ga, pair_valid[0] ? pair_R : I3, pair_valid[0] ? pair_t : Z3, 1.0, Gb);
+    memcpy(traj_R + 9, Gb, 9 * sizeof(double));
+    memcpy(traj_t + 3, Gb + 9, 3 * sizeof(double));
+    for (int q = 0; q + 2 < n_frames; ++q) {
+        const double *Rp = pair_R + 9 * q, *tp = pair_t + 3 * q, *Rt = track_R + 9 * q, *tt = track_t + 3 * q;
+        double scale = 1.0;
+        if (track_ok[q] && pair_valid[q]) {
+            const double d0 = tt[0] - tp[0], d1 = tt[1] - tp[1], d2 = tt[2] - tp[2];
+            const double r0 = (Rp[0] * d0 + Rp[3] * d1) + Rp[6] * d2;
+            const double r1 = (Rp[1] * d0 + Rp[4] * d1) + Rp[7] * d2;
+            const double r2 = (Rp[2] * d0 + Rp[5] * d1) + Rp[8] * d2;
+            scale = sqrt((r0 * r0 + r1 * r1) + r2 * r2);
+            chain_compose(Ga, Rt, tt, sigma, Gn);
+        } else {
+            const int v = pair_valid[q + 1];
+            chain_compose(Gb, v ? pair_R + 9 * (q + 1) : I3, v ? pair_t + 3 * (q + 1) : Z3, sigma, Gn);
+        }
+        track_scale[q] = scale;
+        sigma = sigma * scale;
+        pair_scale[q + 1] = sigma;
+        memcpy(traj_R + 9 * (q + 2), Gn, 9 * sizeof(double));
+        memcpy(traj_t + 3 * (q + 2), Gn + 9, 3 * sizeof(double));
+        memcpy(Ga, Gb, sizeof(Ga));
+        memcpy(Gb, Gn, sizeof(Gb));
+    }
+}

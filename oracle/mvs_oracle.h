@@ -180,6 +180,13 @@ int orc_pnp_solve(const double *world_xyz, const double *image_uv, int n, const 
                   const orc_pnp_params *prm, double R[9], double t[3], int64_t *inlier_idx, int *n_inliers,
                   double Rw2c[9], double tw2c[3], int *best_hyp);
 
+/* scale propagation + trajectory of a sequence (row f2; front-end/visual-odometer.cpp:422-445,577-588): see the .c file.
+ * pair_*: n_frames - 1 entries, track_*: n_frames - 2; outputs traj_R / traj_t: n_frames, pair_scale: n_frames - 1,
+ * track_scale: n_frames - 2 */
+void orc_seq_chain(int n_frames, const double *pair_R, const double *pair_t, const int32_t *pair_valid,
+                   const double *track_R, const double *track_t, const int32_t *track_ok, double *traj_R, double *traj_t,
+                   double *pair_scale, double *track_scale);
+
 /* diagnostics: trace of the 9x9 Jacobi decompositions (one word per sweep: bit = pair rotated; ~0 terminates one SVD) */
 void orc_debug_set_jacobi_trace(uint64_t *buf, size_t cap);
 size_t orc_debug_jacobi_trace_len(void);

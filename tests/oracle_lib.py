@@ -398,6 +398,18 @@ def pnp_solve(world_xyz, image_uv, K, params):
     return dict(ok=bool(ok), R=R, t=t, Rw2c=Rw, tw2c=tw, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
 
 
+def seq_chain(pair_R, pair_t, pair_valid, track_R, track_t, track_ok):
+    pR, pt = _f64(pair_R).reshape(-1, 9), _f64(pair_t).reshape(-1, 3)
+    tR, tt = _f64(track_R).reshape(-1, 9), _f64(track_t).reshape(-1, 3)
+    F = len(pR) + 1
+    pv = np.ascontiguousarray(pair_valid, dtype=np.int32)
+    ok = np.ascontiguousarray(track_ok, dtype=np.int32)
+    R, t, ps, ts = np.zeros((F, 3, 3)), np.zeros((F, 3)), np.zeros(F - 1), np.zeros(max(F - 2, 1))
+    lib().orc_seq_chain(C.c_int(F), _p(pR), _p(pt), _p(pv, C.c_int32), _p(tR), _p(tt), _p(ok, C.c_int32), _p(R), _p(t), _p(ps),
+                        _p(ts))
+    return dict(R=R, t=t, pair_scale=ps, track_scale=ts[:F - 2])
+
+
 # ---- sfm-refine / pnp-refine (row f4) ----------------------------------------------
 class RefineParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("reserved", C.c_int32), ("lambda_initial", C.c_double),

@@ -113,3 +113,58 @@ def test_gpu_sequence_recovers_motion(ctx):
         crel = R0 @ (-R2.T @ t2) + t0
         assert np.abs(t["R"] - Rrel).max() < 0.02
         assert np.abs(t["t"] * scale - crel).max() < 0.05 * max(1.0, np.linalg.norm(crel))
+
+
+def test_oracle_seq_chain_on_exact_poses():
+    """scale propagation (visual-odometer.cpp:577-588) on noise-free inputs: pairs with unit baselines and tracks in their
+    pair's scale reproduce the true trajectory up to the first baseline; a failed track falls back to the two-view pose"""
+    seq = synth.make_sequence(8, n_kp=50, n_map=500, step=0.07, yaw_step=0.02)
+    P = seq["poses"]                                     # world -> camera
+    cam = [(R.T, -R.T @ t) for R, t in P]                # camera in world
+    rel = lambda a, b: (cam[a][0].T @ cam[b][0], cam[a][0].T @ (cam[b][1] - cam[a][1]))   # pose of frame b in frame a
+    base = [np.linalg.norm(rel(k, k + 1)[1]) * (1.0 + 0.3 * k) ** 0 for k in range(7)]
+    pR = [rel(k, k + 1)[0] for k in range(7)]
+    pt = [rel(k, k + 1)[1] / base[k] for k in range(7)]
+    tR = [rel(q, q + 2)[0] for q in range(6)]
+    tt = [rel(q, q + 2)[1] / base[q] for q in range(6)]
+    ok = np.ones(6, np.int32)
+    ok[3] = 0
+    r = o.seq_chain(pR, pt, np.ones(7, np.int32), tR, tt, ok)
+    for q in range(6):
+        want = base[q + 1] / base[q] if ok[q] else 1.0
+        assert abs(r["track_scale"][q] - want) < 1e-12
+    # with the failed track the scale of pair 4 is assumed equal to pair 3's: in this constant-speed sequence that is true
+    for k in range(8):
+        R, t = rel(0, k)
+        assert np.abs(r["R"][k] - R).max() < 1e-12 and np.abs(r["t"][k] * base[0] - t).max() < 1e-12
+    assert abs(r["pair_scale"][5] - base[5] / base[0]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_sequence_trajectory_matches_oracle_and_truth(ctx):
+    from mvslam_amd import capi
+
+    F, N = 12, 800
+    seq = synth.make_sequence(F, n_kp=N, n_map=9000, noise_px=0.1, step=0.12)
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    s.run(capi.default_params(num_hypotheses=4096, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=2e-3),
+          capi.default_pnp_params(num_hypotheses=512, seed=2, reproj_error=1.0))
+    gp, gt, tr = s.download_pairs(), s.download_tracks(), s.download_trajectory()
+    s.close()
+    res, trk = gp["results"], gt["tracks"]
+    want = o.seq_chain(res["R"], res["t"], res["valid"], trk["R"], trk["t"], trk["ok"])
+    for k in ("R", "t", "pair_scale", "track_scale"):
+        assert tr[k].tobytes() == want[k].tobytes(), k               # same fold, same order of operations: bit-exact
+    assert np.all(trk["ok"] == 1)
+    # ground truth: camera centres in frame 0, in units of the first baseline
+    cam = [(R.T, -R.T @ t) for R, t in seq["poses"]]
+    b0 = np.linalg.norm(cam[1][1] - cam[0][1])
+    for k in range(F):
+        c_true = cam[0][0].T @ (cam[k][1] - cam[0][1]) / b0
+        R_true = cam[0][0].T @ cam[k][0]
+        assert np.abs(tr["R"][k] - R_true).max() < 0.02
+        assert np.linalg.norm(tr["t"][k] - c_true) < 0.05 * max(1.0, np.linalg.norm(c_true)), (k, tr["t"][k], c_true)
+    # constant speed: every pair has the same baseline; each step's ratio is good to a few per cent, and the product
+    # drifts like a random walk (monocular scale drift -- the reference has it too, visual-odometer.cpp:577-588)
+    assert np.all(np.abs(tr["track_scale"] - 1.0) < 0.1) and np.all(np.abs(tr["pair_scale"] - 1.0) < 0.25)
