@@ -526,69 +526,122 @@ void launch_pnp(const PnpDev &p, hipStream_t stream)
 // A failed track keeps the scale (scale_q = 1) and falls back to the two-view pose: G_{q+2} = G_{q+1} o (R, sigma t) of
 // pair q+1; an invalid pair contributes the identity.  A sequential fold (the order of operations is part of the
 // specification, the CPU oracle repeats it): one lane, ~45 flops per frame.
-__global__ void seq_chain_kernel(SeqChainDev c)
+__global__ __launch_bounds__(256) void seq_chain_kernel(SeqChainDev c)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0)
-        return;
-    const int F = c.n_frames;
-    double Ga[12], Gb[12];   // G_q and G_{q+1}: R (9) t (3)
-#pragma unroll
-    for (int k = 0; k < 12; ++k)
-        Ga[k] = (k < 9 && k % 4 == 0) ? 1.0 : 0.0;
-    auto store = [&](int f, const double *G) {
-        for (int k = 0; k < 9; ++k)
-            c.traj_R[9 * (size_t)f + k] = G[k];
-        for (int k = 0; k < 3; ++k)
-            c.traj_t[3 * (size_t)f + k] = G[9 + k];
-    };
+    // Only the fold itself is sequential.  Per chunk of kChunk steps the workgroup first prepares, in parallel, everything
+    // that does not depend on the running state -- which operand a step composes with (track pose on G_q, or the next
+    // pair's pose on G_{q+1}) and its scale ratio (the sqrt) -- into LDS; one lane then folds the chunk out of LDS with the
+    // next step's operands prefetched, and the workgroup writes the chunk's results back.  (Reading HBM inside the
+    // dependent loop cost 2 us per frame.)
+    constexpr int kChunk = 128;
+    __shared__ double s_op[kChunk * 12];    // R (9), t (3) of the step's operand, unscaled
+    __shared__ double s_scale[kChunk];
+    __shared__ int s_sel[kChunk];           // 0: compose on G_q, 1: on G_{q+1}
+    __shared__ double s_out[kChunk * 14];   // G_{q+2} (12), track_scale, sigma_{q+1}
+    const int F = c.n_frames, tid = threadIdx.x;
+    double Ga[12], Gb[12];   // G_q and G_{q+1}: R (9) t (3)   (meaningful on thread 0 only)
+    double sigma = 1.0;
     auto compose = [](const double *A, const double *R, const double *t, double sig, double *out) {
         // out = A o (R, sig * t):  R_out = A.R R,  t_out = A.R (sig t) + A.t
         const double s0 = sig * t[0], s1 = sig * t[1], s2 = sig * t[2];
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
+#pragma unroll
             for (int j = 0; j < 3; ++j)
                 out[3 * i + j] = (A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j]) + A[3 * i + 2] * R[6 + j];
             out[9 + i] = ((A[3 * i] * s0 + A[3 * i + 1] * s1) + A[3 * i + 2] * s2) + A[9 + i];
         }
     };
-    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
-    double sigma = 1.0;
-    store(0, Ga);
-    c.traj_sigma[0] = 1.0;
-    {
+    if (tid == 0) {
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            Ga[k] = (k < 9 && k % 4 == 0) ? 1.0 : 0.0;
         const mvs_pair_result &p0 = c.results[0];
         compose(Ga, p0.valid ? p0.R : I3, p0.valid ? p0.t : Z3, 1.0, Gb);
-    }
-    store(1, Gb);
-    for (int q = 0; q + 2 < F; ++q) {
-        const mvs_pair_result &pq = c.results[q], &pn = c.results[q + 1];
-        const PnpOut &tr = c.tracks[q];
-        const bool ok = c.n_corr[q] >= 7 && tr.ok && pq.valid;
-        double scale = 1.0, Gn[12];
-        if (ok) {
-            // rel.t = R_pair^T (t_track - t_pair)
-            const double d0 = tr.t[0] - pq.t[0], d1 = tr.t[1] - pq.t[1], d2 = tr.t[2] - pq.t[2];
-            const double r0 = (pq.R[0] * d0 + pq.R[3] * d1) + pq.R[6] * d2;
-            const double r1 = (pq.R[1] * d0 + pq.R[4] * d1) + pq.R[7] * d2;
-            const double r2 = (pq.R[2] * d0 + pq.R[5] * d1) + pq.R[8] * d2;
-            scale = sqrt((r0 * r0 + r1 * r1) + r2 * r2);
-            compose(Ga, tr.R, tr.t, sigma, Gn);
-        } else {
-            compose(Gb, pn.valid ? pn.R : I3, pn.valid ? pn.t : Z3, sigma, Gn);
+        for (int k = 0; k < 9; ++k) {
+            c.traj_R[k] = Ga[k];
+            c.traj_R[9 + k] = Gb[k];
         }
-        c.track_scale[q] = scale;
-        sigma = sigma * scale;
-        c.traj_sigma[q + 1] = sigma;
-        store(q + 2, Gn);
-        for (int k = 0; k < 12; ++k) {
-            Ga[k] = Gb[k];
-            Gb[k] = Gn[k];
+        for (int k = 0; k < 3; ++k) {
+            c.traj_t[k] = Ga[9 + k];
+            c.traj_t[3 + k] = Gb[9 + k];
+        }
+        c.traj_sigma[0] = 1.0;
+    }
+    const int T = F - 2;
+    for (int q0 = 0; q0 < T; q0 += kChunk) {
+        const int n = min(kChunk, T - q0);
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) {   // state-independent part of step q = q0 + j
+            const int q = q0 + j;
+            const mvs_pair_result &pq = c.results[q], &pn = c.results[q + 1];
+            const PnpOut &tr = c.tracks[q];
+            const bool ok = c.n_corr[q] >= 7 && tr.ok && pq.valid;
+            double scale = 1.0;
+            double *op = s_op + 12 * j;
+            if (ok) {
+                // rel.t = R_pair^T (t_track - t_pair)
+                const double d0 = tr.t[0] - pq.t[0], d1 = tr.t[1] - pq.t[1], d2 = tr.t[2] - pq.t[2];
+                const double r0 = (pq.R[0] * d0 + pq.R[3] * d1) + pq.R[6] * d2;
+                const double r1 = (pq.R[1] * d0 + pq.R[4] * d1) + pq.R[7] * d2;
+                const double r2 = (pq.R[2] * d0 + pq.R[5] * d1) + pq.R[8] * d2;
+                scale = sqrt((r0 * r0 + r1 * r1) + r2 * r2);
+                for (int k = 0; k < 9; ++k) op[k] = tr.R[k];
+                for (int k = 0; k < 3; ++k) op[9 + k] = tr.t[k];
+            } else if (pn.valid) {
+                for (int k = 0; k < 9; ++k) op[k] = pn.R[k];
+                for (int k = 0; k < 3; ++k) op[9 + k] = pn.t[k];
+            } else {
+                for (int k = 0; k < 12; ++k) op[k] = (k < 9 && k % 4 == 0) ? 1.0 : 0.0;
+            }
+            s_scale[j] = scale;
+            s_sel[j] = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double cur[12], nxt[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                cur[k] = s_op[k];
+            for (int j = 0; j < n; ++j) {
+                const int jn = min(j + 1, n - 1);
+#pragma unroll
+                for (int k = 0; k < 12; ++k)   // prefetch the next operand while this step's products are in flight
+                    nxt[k] = s_op[12 * jn + k];
+                const double scale = s_scale[j];
+                double Gn[12];
+                if (s_sel[j] == 0)
+                    compose(Ga, cur, cur + 9, sigma, Gn);
+                else
+                    compose(Gb, cur, cur + 9, sigma, Gn);
+                sigma = sigma * scale;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    s_out[14 * j + k] = Gn[k];
+                    Ga[k] = Gb[k];
+                    Gb[k] = Gn[k];
+                    cur[k] = nxt[k];
+                }
+                s_out[14 * j + 12] = scale;
+                s_out[14 * j + 13] = sigma;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n * 14; i += 256) {
+            const int j = i / 14, k = i - j * 14, q = q0 + j;
+            const double v = s_out[i];
+            if (k < 9) c.traj_R[9 * (size_t)(q + 2) + k] = v;
+            else if (k < 12) c.traj_t[3 * (size_t)(q + 2) + (k - 9)] = v;
+            else if (k == 12) c.track_scale[q] = v;
+            else c.traj_sigma[q + 1] = v;
         }
     }
 }
 
 void launch_seq_chain(const SeqChainDev &c, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seq_chain_kernel, dim3(1), dim3(64), 0, stream, c);
+    hipLaunchKernelGGL(seq_chain_kernel, dim3(1), dim3(256), 0, stream, c);
 }
 
 }  // namespace mvs
