@@ -213,7 +213,12 @@ def main():
                 "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per launch from profiles/r01_pmc_summary_opt1.json (algorithmic: %d)"
                                 % int((m_avg * 32 + 88 * ((args.hyp + 255) // 256)) * n_local),
-                "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3)},
+                "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3),
+                # north_star: occupancy / LDS of the RANSAC kernel (hipcc -Rpass-analysis=kernel-resource-usage)
+                "occupancy_waves_per_simd": 1, "vgprs": 256, "agprs": 124, "scratch_bytes": 0,
+                "lds_bytes_per_workgroup": 131072,
+                "fp64_issue_note": "one fp64 instruction per 6.0 cycles = 86 % of the 5.14-cycle rate this part sustains "
+                                   "(profiles/r01_fp64_issue_microbench.txt)"},
             "hbm_roofline": {
                 "achieved": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9 / HBM_PEAK_GBS, 6),
