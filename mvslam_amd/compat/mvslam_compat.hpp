@@ -13,11 +13,13 @@
 // types without touching the call sites.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -392,6 +394,24 @@ class PinholeCamera
 {
 public:
     PinholeCamera(const CameraIntrinsics &K_, const CameraExtrinsics &P_) : K(K_), P(P_) {}
+    explicit PinholeCamera(const std::string &filename)  // camera.cpp:8-12,105-124: "fx fy shear px py" then an se3 line
+    {
+        const bool ok = load_from_file(filename);
+        assert(ok);
+        (void)ok;
+    }
+    bool load_from_file(const std::string &filename)
+    {
+        std::ifstream in(filename);
+        K = Matrix3Type();
+        in >> K(0, 0) >> K(1, 1) >> K(0, 1) >> K(0, 2) >> K(1, 2);
+        K(2, 2) = 1;
+        Vector6Type se3{};
+        for (int i = 0; i < 6; ++i)
+            in >> se3[i];
+        P = SE3::exp(se3);
+        return bool(in);
+    }
     ImagePoint project_point(const Point3 &p_world) const  // camera.cpp:24-37
     {
         const Vector3Type pc = P * p_world;
