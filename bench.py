@@ -207,16 +207,16 @@ def main():
                 "pairs_per_gpu": n_local, "keypoints": args.kp, "hypotheses": args.hyp, "noise_px": args.noise_px,
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world},
             "roofline": {
-                "bound": "mfma", "kernel": "ransac_kernel",
+                "bound": "mfma", "kernel": "ransac_solve_kernel + ransac_score_kernel (the RANSAC stage; launch_ms is their sum)",
                 "bound_detail": "fp64 VALU (vector FMA); MI355X fp64 vector peak = fp64 MFMA dense peak = 78.6 TFLOP/s",
                 "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r01_pmc_summary_opt1.json (algorithmic: %d)"
+                "traffic_note": "HBM bytes per launch from profiles/r01_ransac_hbm_traffic.json; algorithmic: %d for points + arg-best, + 2 x 72 B per hypothesis for the F hand-over between the solve and the scoring launch"
                                 % int((m_avg * 32 + 88 * ((args.hyp + 255) // 256)) * n_local),
                 "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3),
                 # north_star: occupancy / LDS of the RANSAC kernel (hipcc -Rpass-analysis=kernel-resource-usage)
-                "occupancy_waves_per_simd": 1, "vgprs": 256, "agprs": 124, "scratch_bytes": 0,
-                "lds_bytes_per_workgroup": 131072,
+                "occupancy_waves_per_simd": {"solve": 1, "score": 4}, "vgprs": {"solve": 256, "score": 124},
+                "agprs": {"solve": 123, "score": 0}, "scratch_bytes": 0, "lds_bytes_per_workgroup": {"solve": 0, "score": 32768},
                 "fp64_issue_note": "one fp64 instruction per 6.0 cycles = 86 % of the 5.14-cycle rate this part sustains "
                                    "(profiles/r01_fp64_issue_microbench.txt)"},
             "hbm_roofline": {

@@ -129,6 +129,15 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if (st != MVS_OK)
         return st;
     b->d.wgbest = p;  // the smaller old block stays owned by allocs until destroy
+    // per-hypothesis F for the split solve / score variant of the RANSAC stage: 72 B x hypotheses x pairs
+    double *hf = nullptr;
+    uint8_t *ho = nullptr;
+    if ((st = dev_alloc(b, &hf, (size_t)b->d.n_pairs * 9 * G * kHypPerBlock)) != MVS_OK)
+        return st;
+    if ((st = dev_alloc(b, &ho, (size_t)b->d.n_pairs * G * kHypPerBlock)) != MVS_OK)
+        return st;
+    b->d.hyp_F = hf;
+    b->d.hyp_okf = ho;
     b->d.max_groups = G;
     return MVS_OK;
 }

@@ -411,6 +411,131 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
     }
 }
 
+// ---- split variant (VAR & 512): the solve and the scoring as two launches -----------------------------------------
+// The fused kernel runs at 1 wave/SIMD (380 registers for the solve), where every non-fp64 instruction of the scoring
+// loop costs a full fp64 issue slot (profiles/r01_fp64_issue_microbench.txt).  Scoring needs 18 registers of state: as
+// its own kernel it runs at 4 waves/SIMD and the compare / count / mask instructions overlap with other waves' FMAs.
+// Price: F of every hypothesis goes through HBM once (72 B x 50 000 x 512 pairs = 1.8 GB written + read per batch).
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp)
+{
+    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int M = b.M[pair];
+    if (M < 8)
+        return;
+    const int H = rp.num_hypotheses;
+    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
+    const uint32_t hh = h < (uint32_t)H ? h : (uint32_t)(H - 1);
+    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+    double F[9];
+    unsigned rot = 0, pairs = 0;
+    bool bad = false;
+    bool ok = solve_hypothesis<VAR>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+    if ((VAR & 32) && __builtin_expect(__any(bad), 0)) {
+        rot = 0;
+        pairs = 0;
+        ok = solve_hypothesis<(VAR & ~32)>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+    }
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    double *Fo = b.hyp_F + (size_t)pair * 9 * Hp + h;   // [9][Hp]: lane h of every row -> coalesced
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        Fo[k * Hp] = F[k];
+    b.hyp_okf[(size_t)pair * Hp + h] = ok ? 1 : 0;
+}
+
+constexpr int kScoreChunk = 1024;   // points staged per pass: 32 KB of LDS -> 4 workgroups per CU
+__global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams rp)
+{
+    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int M = b.M[pair];
+    WgBest *out = b.wgbest + (size_t)pair * b.max_groups + g;
+    if (M < 8) {  // estimator-RANSAC.cpp:25-29
+        if (tid == 0) {
+            out->count = -1;
+            out->hyp = 0xffffffffu;
+            out->residual = 0.0;
+        }
+        return;
+    }
+    const int H = rp.num_hypotheses;
+    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
+    const bool live = h < (uint32_t)H;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const double *Fi = b.hyp_F + (size_t)pair * 9 * Hp + h;
+    double F[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        F[k] = Fi[k * Hp];
+    const bool ok = b.hyp_okf[(size_t)pair * Hp + h] != 0;
+    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+    __shared__ __attribute__((aligned(16))) double s_pts[kScoreChunk * 4];
+    const double thr = pair_max_error_sq(b, rp, pair);
+    int cnt = 0;
+    double res = 0.0;
+    for (int c0 = 0; c0 < M; c0 += kScoreChunk) {
+        const int n = min(kScoreChunk, M - c0);
+        __syncthreads();
+        const double2 *src = reinterpret_cast<const double2 *>(P + (size_t)c0 * 4);
+        double2 *dst = reinterpret_cast<double2 *>(s_pts);
+        for (int i = tid; i < 2 * n; i += kHypPerBlock)
+            dst[i] = src[i];
+        __syncthreads();
+        const double4 *L4 = reinterpret_cast<const double4 *>(s_pts);
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) {   // same order and the same operations as the fused kernel: same bits
+            const double4 p = L4[i];
+            const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+            const bool in = r < thr;
+            cnt += in ? 1 : 0;
+            const double m = __hiloint2double(in ? 0x3ff00000 : 0, 0);
+            res = dfma(r, m, res);
+        }
+    }
+    if (!ok || !live) {
+        cnt = -1;
+        res = 0.0;
+    }
+    if (b.hyp_count && live) {
+        b.hyp_count[(size_t)pair * H + h] = cnt;
+        b.hyp_residual[(size_t)pair * H + h] = res;
+    }
+    // workgroup arg-best
+    Cand me{cnt, h, res};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand other;
+        other.cnt = __shfl_xor(me.cnt, o);
+        other.hyp = __shfl_xor(me.hyp, o);
+        other.res = __shfl_xor(me.res, o);
+        if (cand_better(other, me))
+            me = other;
+    }
+    __shared__ Cand s_c[4];
+    __shared__ uint32_t s_win;
+    if ((tid & 63) == 0)
+        s_c[tid >> 6] = me;
+    __syncthreads();
+    if (tid == 0) {
+        Cand best = s_c[0];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2)
+            if (cand_better(s_c[w2], best))
+                best = s_c[w2];
+        s_win = best.hyp;
+        out->count = best.cnt;
+        out->hyp = best.hyp;
+        out->residual = best.res;
+    }
+    __syncthreads();
+    if (h == s_win) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            out->F[k] = F[k];
+    }
+}
+
 // diagnostics: compare the unscaled sqrt / div sequences with the compiler's IEEE ones on caller-supplied operands.
 // out[0] = sqrt mismatches among operands that pass sqrt_fast_ok, out[1] = div mismatches among operand pairs
 // inside the guarded range, out[2] / out[3] = number of operands / pairs that were inside the guards.
@@ -870,7 +995,7 @@ void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2,
     hipLaunchKernelGGL(prep_points_kernel, dim3((b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b, uv1, uv2);
 }
 
-static int g_ransac_variant = 120;
+static int g_ransac_variant = 632;  // 120 fused; 632 = solve + score as two launches
 void set_ransac_variant(int v) { g_ransac_variant = v; }
 int get_ransac_variant() { return g_ransac_variant; }
 
@@ -890,6 +1015,15 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     switch (g_ransac_variant) {
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
     case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream); break;   // timing experiment: no V rotations
+    case 632:   // 120 | 512: solve and scoring as two launches (stats replay stays on the fused kernel; so does a
+                // launch of one or two pairs, where the second launch costs more latency than the scoring gains)
+        if (stats || !b.hyp_F || n_active < 3) {
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+        } else {
+            hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
+            hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
+        }
+        break;
     default: launch_ransac_var<120>(b, rp, grid, block, stats, stream); break;
     }
 }

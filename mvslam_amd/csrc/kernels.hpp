@@ -56,6 +56,8 @@ struct BatchDev {
     mvs_match *matches;  // [P][N]
     double *pts;         // [P][N][4]  (x1, y1, x2, y2) ideal-camera coordinates of match m
     WgBest *wgbest;      // [P][max_groups]
+    double *hyp_F;       // [P][9][max_groups * 256] F of every hypothesis (split solve / score variant), may be null
+    uint8_t *hyp_okf;    // [P][max_groups * 256] solve succeeded
     double *cand_pts;    // [P][4][N][3] triangulation scratch
     FinModel *fin;       // [P]
     uint16_t *inl;       // [P][N] ordered inlier list

@@ -11,7 +11,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvslam_amd import capi, synth  # noqa: E402
 
-NAMES = {0: "round-1 first version", 120: "LDS point stream + in-place rotation + mask-fma + unscaled sqrt/div (default)"}
+NAMES = {0: "round-1 first version", 120: "fused: LDS point stream + in-place rotation + mask-fma + unscaled sqrt/div",
+         632: "120 split into a solve and a scoring launch (default)", 376: "timing only: 120 without V rotations"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=128)
