@@ -168,3 +168,29 @@ def test_gpu_sequence_trajectory_matches_oracle_and_truth(ctx):
     # constant speed: every pair has the same baseline; each step's ratio is good to a few per cent, and the product
     # drifts like a random walk (monocular scale drift -- the reference has it too, visual-odometer.cpp:577-588)
     assert np.all(np.abs(tr["track_scale"] - 1.0) < 0.1) and np.all(np.abs(tr["pair_scale"] - 1.0) < 0.25)
+
+
+@pytest.mark.gpu
+def test_gpu_sequence_trajectory_with_failed_tracks(ctx):
+    """a frame with almost no keypoints invalidates its two pairs and the tracks through it: the fold falls back to the
+    two-view poses / the identity exactly as the oracle's fold does"""
+    from mvslam_amd import capi
+
+    F, N = 9, 500
+    seq = synth.make_sequence(F, n_kp=N, n_map=6000, noise_px=0.2, step=0.1)
+    n_kp = seq["n_kp"].copy()
+    n_kp[4] = 5                                                  # frame 4 is (almost) blind
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload(0, seq["desc"], seq["kp"], n_kp, seq["K"])
+    s.run(capi.default_params(num_hypotheses=1024, sampler=capi.SAMPLER_PHILOX, seed=3, max_error_sq=2e-3),
+          capi.default_pnp_params(num_hypotheses=256, seed=4, reproj_error=1.0))
+    gp, gt, tr = s.download_pairs(), s.download_tracks(), s.download_trajectory()
+    s.close()
+    res, trk = gp["results"], gt["tracks"]
+    assert not res["valid"][3] and not res["valid"][4] and res["valid"][0]
+    assert not trk["ok"][2] and not trk["ok"][3] and not trk["ok"][4] and trk["ok"][0]
+    want = o.seq_chain(res["R"], res["t"], res["valid"], trk["R"], trk["t"], trk["ok"])
+    for k in ("R", "t", "pair_scale", "track_scale"):
+        assert tr[k].tobytes() == want[k].tobytes(), k
+    assert np.all(tr["track_scale"][2:5] == 1.0)
+    assert np.array_equal(tr["R"][5], tr["R"][4]) and np.array_equal(tr["t"][5], tr["t"][4])   # pair 4 invalid: identity step
