@@ -1,72 +1,71 @@
-// The reference's two-image driver (utility/reconstruct-scene.cpp:22-66) on top of the drop-in shim, call for call:
-// load two grayscale images -> VisualFeature::extract x2 -> match_and_filter_visual_features -> PinholeCamera(file) ->
-// sfm_solve -> print.  Differences: no visualiser window, and the images come as raw 8-bit files (width height on the
-// command line) because the build image has no JPEG decoder for C++ (the reference uses cv::imread).
-// usage: reconstruct_scene <image_1.raw> <image_2.raw> <width> <height> <intrinsics> <max_dist>
+// Drives the drop-in shim through the call sequence of the reference's two-image utility (utility/reconstruct-scene.cpp:
+// extract both images, match_and_filter_visual_features, camera from a config file, sfm_solve) and prints what
+// tests/test_compat_cpp.py checks.  Written for the test-suite: raw 8-bit frames instead of image files (the build image
+// has no decoder for C++), no viewer, machine-readable output.
+//   argv: frame_a.raw frame_b.raw width height camera.config max_descriptor_distance
 #include <cstdio>
-#include <iostream>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../mvslam_amd/compat/mvslam_compat.hpp"
 
-static mvSLAM::Mat8u load_image_grayscale(const std::string &filename, int width, int height)
-{   // base/image.cpp:10-15
-    mvSLAM::Mat8u image;
-    image.rows = height;
-    image.cols = width;
-    image.data.resize((size_t)width * height);
-    std::FILE *f = std::fopen(filename.c_str(), "rb");
-    const bool ok = f && std::fread(image.data.data(), 1, image.data.size(), f) == image.data.size();
-    if (f) std::fclose(f);
-    if (!ok) image.rows = image.cols = 0;
-    return image;
+namespace
+{
+bool read_raw_frame(const char *path, int w, int h, mvSLAM::Mat8u &frame)
+{
+    frame.rows = h;
+    frame.cols = w;
+    frame.data.assign((size_t)w * h, 0);
+    std::FILE *fp = std::fopen(path, "rb");
+    if (!fp)
+        return false;
+    const size_t got = std::fread(frame.data.data(), 1, frame.data.size(), fp);
+    std::fclose(fp);
+    return got == frame.data.size();
 }
+}  // namespace
 
 int main(int argc, char **argv)
 {
+    using namespace mvSLAM;
     if (argc != 7) {
-        std::printf("Usage: %s <image_1.raw> <image_2.raw> <width> <height> <intrinsics> <max_dist>\n", argv[0]);
-        return 1;
+        std::fprintf(stderr, "expected: frame_a.raw frame_b.raw width height camera.config max_distance\n");
+        return 64;
     }
-    const int width = std::stoi(argv[3]), height = std::stoi(argv[4]);
-    mvSLAM::ScalarType max_dist = std::stoi(std::string(argv[6]));
-
-    // input
-    mvSLAM::Mat8u image1 = load_image_grayscale(argv[1], width, height);
-    mvSLAM::Mat8u image2 = load_image_grayscale(argv[2], width, height);
-    if (image1.rows <= 0 || image2.rows <= 0) {
-        std::printf("cannot read the images.\n");
-        return 1;
+    const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
+    Mat8u frames[2];
+    if (w <= 0 || h <= 0 || !read_raw_frame(argv[1], w, h, frames[0]) || !read_raw_frame(argv[2], w, h, frames[1])) {
+        std::fprintf(stderr, "unreadable frames\n");
+        return 65;
     }
-    auto image1_vf = mvSLAM::VisualFeature::extract(image1);
-    auto image2_vf = mvSLAM::VisualFeature::extract(image2);
-    auto matched_vf_pair = mvSLAM::VisualFeature::match_and_filter_visual_features(image1_vf, image2_vf, max_dist);
-    mvSLAM::PinholeCamera camera{std::string(argv[5])};
+    // a real RANSAC instead of the single hypothesis the reference ships with (sfm-solve.cpp:67): backend setting only
+    hip::RansacConfig &rc = hip::ransac_config();
+    rc.num_hypotheses = 2000;
+    rc.sampler = MVS_SAMPLER_PHILOX;
+    rc.seed = 1;
+    rc.max_error_sq = 1e-3;
 
-    // the reference as shipped scores ONE hypothesis on the first 8 matches (sfm-solve.cpp:67); a real RANSAC is a
-    // setting of the backend, not of the call surface
-    mvSLAM::hip::ransac_config().num_hypotheses = 2000;
-    mvSLAM::hip::ransac_config().sampler = MVS_SAMPLER_PHILOX;
-    mvSLAM::hip::ransac_config().seed = 1;
-    mvSLAM::hip::ransac_config().max_error_sq = 1e-3;
+    const VisualFeature feat_a = VisualFeature::extract(frames[0]), feat_b = VisualFeature::extract(frames[1]);
+    const auto filtered = VisualFeature::match_and_filter_visual_features(feat_a, feat_b, (ScalarType)std::atoi(argv[6]));
+    const PinholeCamera cam{std::string(argv[5])};
+    const CameraIntrinsics &K = cam.get_intrinsics();
 
-    // output
-    mvSLAM::Transformation pose2in1_scaled;
-    std::vector<mvSLAM::Point3> pointsin1_scaled;
-    std::vector<size_t> point_indexes;
-    if (!sfm_solve(matched_vf_pair.first.get_image_points(), matched_vf_pair.second.get_image_points(),
-                   camera.get_intrinsics(), pose2in1_scaled, pointsin1_scaled, point_indexes)) {
-        std::printf("Reconstruction failed.\n");
+    Transformation T_b_in_a;
+    std::vector<Point3> cloud;
+    std::vector<size_t> cloud_match_index;
+    const bool solved = sfm_solve(filtered.first.get_image_points(), filtered.second.get_image_points(), K, T_b_in_a, cloud,
+                                  cloud_match_index);
+    std::printf("features: %zu %zu, matches: %zu\n", feat_a.size(), feat_b.size(), filtered.first.size());
+    std::printf("camera intrinsics: fx %g fy %g shear %g px %g py %g\n", K(0, 0), K(1, 1), K(0, 1), K(0, 2), K(1, 2));
+    if (!solved) {
+        std::printf("no reconstruction\n");
         return 2;
     }
-    const auto &K = camera.get_intrinsics();
-    std::printf("features: %zu %zu, matches: %zu\n", image1_vf.size(), image2_vf.size(), matched_vf_pair.first.size());
-    std::printf("camera intrinsics: fx %g fy %g shear %g px %g py %g\n", K(0, 0), K(1, 1), K(0, 1), K(0, 2), K(1, 2));
-    const mvSLAM::Vector6Type se3 = pose2in1_scaled.ln();
-    std::printf("scaled transformation (se3) = %.9f %.9f %.9f %.9f %.9f %.9f\n", se3[0], se3[1], se3[2], se3[3], se3[4], se3[5]);
-    std::printf("pointsin1_scaled = %zu points\n", pointsin1_scaled.size());
-    for (size_t i = 0; i < pointsin1_scaled.size() && i < 5; ++i)
-        std::cout << pointsin1_scaled[i].x() << ", " << pointsin1_scaled[i].y() << ", " << pointsin1_scaled[i].z() << std::endl;
+    const Vector6Type xi = T_b_in_a.ln();
+    std::printf("scaled transformation (se3) = %.9f %.9f %.9f %.9f %.9f %.9f\n", xi[0], xi[1], xi[2], xi[3], xi[4], xi[5]);
+    std::printf("pointsin1_scaled = %zu points\n", cloud.size());
+    for (size_t k = 0; k < cloud.size() && k < 5; ++k)
+        std::printf("%g, %g, %g\n", cloud[k].x(), cloud[k].y(), cloud[k].z());
     return 0;
 }

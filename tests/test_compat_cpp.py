@@ -29,14 +29,14 @@ def _build_driver():
 
 
 def test_reconstruct_scene_driver_compiles():
-    """utility/reconstruct-scene.cpp's flow on the shim: only a host compiler needed"""
+    """the call sequence of utility/reconstruct-scene.cpp on the shim: only a host compiler needed"""
     _build_driver()
     assert os.path.exists(DRIVER)
 
 
 @pytest.mark.gpu
 def test_reconstruct_scene_driver_on_tsukuba(tmp_path):
-    """the reference's two-image driver, call for call, on its own tsukuba frames 1 and 2 with its camera.config:
+    """the call sequence of the reference's two-image utility on its own tsukuba frames 1 and 2 with its camera.config:
     extract -> match_and_filter -> sfm_solve gives the pose test/test-image-pair.cpp:38-45 expects, (I, (1, 0, 0))"""
     import numpy as np
 
