@@ -136,8 +136,14 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
         return st;
     if ((st = dev_alloc(b, &ho, (size_t)b->d.n_pairs * G * kHypPerBlock)) != MVS_OK)
         return st;
+    int32_t *hc = nullptr;
+    if ((st = dev_alloc(b, &hc, (size_t)b->d.n_pairs * G * kHypPerBlock)) != MVS_OK)
+        return st;
+    if (!b->d.bound && (st = dev_alloc(b, &b->d.bound, (size_t)b->d.n_pairs)) != MVS_OK)
+        return st;
     b->d.hyp_F = hf;
     b->d.hyp_okf = ho;
+    b->d.hyp_cnt = hc;
     b->d.max_groups = G;
     return MVS_OK;
 }
@@ -344,6 +350,10 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.desc1 = desc1; d.desc2 = desc2; d.kp1 = kp1; d.kp2 = kp2; d.n1 = n1; d.n2 = n2;
     d.Kinv = Kinv; d.K = K; d.gidx = gidx;
     d.wgbest = nullptr;
+    d.hyp_F = nullptr;
+    d.hyp_okf = nullptr;
+    d.hyp_cnt = nullptr;
+    d.bound = nullptr;
     d.hyp_count = nullptr;
     d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;

@@ -84,23 +84,66 @@ MVS_DEV double div_fast(double n, double d)
     return dfma(rem, r, q);
 }
 
-template <int M, int N, bool HAS_V, bool INPLACE, bool FAST>
+// CHEAP variant of the pair step (bit-identical decisions and rotations, fewer issue slots; at one wave per SIMD every
+// instruction, vector or scalar, costs a full slot).
+//
+// (1) Convergence test without the square root.  The contract's decision is
+//         rotate  <=>  !(|p| <= T),   T = fl(eps10 * fl(sqrt(ab))),   ab = fl(a * b),   eps10 = 10 * 2^-52.
+//     T^2 = eps10^2 * ab * (1 + d) with |d| < 5e-16.  With q = fl(p * p), tau = 2^-900 and e* = eps10^2 * ab:
+//         q > fl(ab * E2 * (1 + 2e-14) + tau)  =>  p^2 > T^2   (rotate)
+//         q < fl(ab * E2 * (1 - 2e-14) - tau)  =>  p^2 < T^2   (skip)
+//     For e* >= 2^-850 every quantity is a normal number with relative error < 4e-16 and tau / e* < 1e-15, so both
+//     implications hold with a margin of 1e-14; for e* < 2^-850 the first threshold is >= tau >> T^2 (still implies
+//     "rotate") and the second is negative (never taken); a q that underflows is < tau, below the first threshold, and
+//     satisfies the second only when e* > tau >> q.  Everything else -- the band, NaN -- evaluates the contract's own
+//     test, for the whole wavefront (one uniform branch, never taken in practice).  sqrt(ab) is not an input of the
+//     rotation, so nothing else changes.
+// (2) Range guard of the unscaled sqrt / div sequences as ONE running minimum instead of three compares folded into a
+//     flag: the sequences need 2^-400 <= g2 <= 2^400 and |2p| >= 2^-200 (see FAST below).  g2 = fl(4p^2 + beta^2) >= 4p^2
+//     and 4p^2 = 4q exactly, so q >= 2^-398 gives both lower bounds; and g2 <= (a + b)^2 (Cauchy-Schwarz), where a + b
+//     is bounded by the squared Frobenius norm of the matrix, which rotations preserve: checked ONCE before the sweeps
+//     (jacobi_svd_core: sum W <= 2^198).  Exec-masked lanes do not update the minimum, exactly like the flag.
+// (3) (gamma - beta) * 0.5 for beta < 0 and gamma + beta otherwise are both (gamma + |beta|) times an exact power of
+//     two: one add and one multiply by a selected constant replace two candidates and a 64-bit select (same for den).
+constexpr double kJacobiE2Hi = (kJacobiEps * kJacobiEps) * (1.0 + 2e-14);
+constexpr double kJacobiE2Lo = (kJacobiEps * kJacobiEps) * (1.0 - 2e-14);
+constexpr double kJacobiTau = 0x1p-900;
+constexpr double kGuardQMin = 0x1p-398;
+constexpr double kGuardWSumMax = 0x1p198;
+
+// v_min_f64 without the canonicalising v_max x, x that __builtin_fmin emits for each operand
+MVS_DEV void running_min(double &m, double x) { asm("v_min_f64 %0, %0, %1" : "+v"(m) : "v"(x)); }
+
+template <int M, int N, bool HAS_V, bool INPLACE, bool FAST, bool CHEAP = false>
 MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], double (&Vj)[N], double &Wi, double &Wj,
-                         bool &changed, unsigned &rot, bool &bad)
+                         bool &changed, unsigned &rot, bool &bad, double &qmin)
 {
     double a = Wi, b = Wj, p = 0.0;
 #pragma unroll
     for (int k = 0; k < M; ++k)
         p = dfma(Ai[k], Aj[k], p);
-    const double ab = a * b;
-    double sq_ab;
-    if (FAST) {
-        bad = bad || !sqrt_fast_ok(ab);
-        sq_ab = sqrt_fast(ab);
+    bool rotate;
+    double q = 0.0;
+    if (CHEAP) {
+        const double ab = a * b;
+        q = p * p;
+        const bool hi = q > dfma(ab, kJacobiE2Hi, kJacobiTau);
+        const bool lo = q < dfma(ab, kJacobiE2Lo, -kJacobiTau);
+        rotate = hi;
+        if (__builtin_expect(__any(!hi && !lo), 0))
+            rotate = !(dabs(p) <= kJacobiEps * dsqrt(a * b));
     } else {
-        sq_ab = dsqrt(ab);
+        const double ab = a * b;
+        double sq_ab;
+        if (FAST) {
+            bad = bad || !sqrt_fast_ok(ab);
+            sq_ab = sqrt_fast(ab);
+        } else {
+            sq_ab = dsqrt(ab);
+        }
+        rotate = !(dabs(p) <= kJacobiEps * sq_ab);
     }
-    if (!(dabs(p) <= kJacobiEps * sq_ab)) {
+    if (rotate) {
         p *= 2.0;
         const double beta = a - b;
         const double g2 = dfma(p, p, beta * beta);
@@ -111,10 +154,23 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
         if (FAST) {
             // with gamma and |p| in [2^-200, 2^200] every sqrt / div operand below is far from the ends of the
             // exponent range (num, den in [gamma/2, 2 gamma]; num/den in [1/2, 1]); otherwise flag the lane
-            bad = bad || !((g2 >= 0x1p-400) && (g2 <= 0x1p400) && (dabs(p) >= 0x1p-200));
+            double num, den;
+            if (CHEAP) {
+                running_min(qmin, q);
+            } else {
+                bad = bad || !((g2 >= 0x1p-400) && (g2 <= 0x1p400) && (dabs(p) >= 0x1p-200));
+            }
             const double gamma = sqrt_fast(g2);
-            const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
-            const double den = neg ? gamma : gamma * 2.0;
+            if (CHEAP) {
+                // gamma - beta == gamma + |beta| for beta < 0, and the halving / doubling are exact inside the guard:
+                // one add and one multiply by a selected power of two replace two candidates and a 64-bit select
+                const double t = gamma + dabs(beta);
+                num = t * __hiloint2double(neg ? 0x3fe00000 : 0x3ff00000, 0);
+                den = gamma * __hiloint2double(neg ? 0x3ff00000 : 0x40000000, 0);
+            } else {
+                num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
+                den = neg ? gamma : gamma * 2.0;
+            }
             x = sqrt_fast(div_fast(num, den));
             y = div_fast(p, gamma * x * 2.0);
         } else {
@@ -163,10 +219,12 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
 
 // Sweeps until a sweep without rotation (at most max(M, 30)); W ends as singular values.
 // At: N rows of length M.  Vt: N x N, initialised to identity here.
-template <int M, int N, bool INPLACE = false, bool FAST = false, bool HAS_V = true>
+template <int M, int N, bool INPLACE = false, bool FAST = false, bool HAS_V = true, bool CHEAP = false>
 MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N], unsigned &rot, unsigned &pairs,
                              bool &bad)
 {
+    static_assert(!CHEAP || FAST, "the CHEAP pair step is a form of the FAST one");
+    double qmin = 0x1p1000, wsum = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double sd = 0.0;
@@ -174,6 +232,7 @@ MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)
         for (int k = 0; k < M; ++k)
             sd = dfma(At[i][k], At[i][k], sd);
         W[i] = sd;
+        wsum += sd;
 #pragma unroll
         for (int k = 0; k < N; ++k)
             Vt[i][k] = (i == k) ? 1.0 : 0.0;
@@ -185,12 +244,15 @@ MVS_DEV void jacobi_svd_core(double (&At)[N][M], double (&Vt)[N][N], double (&W)
         for (int i = 0; i < N - 1; ++i) {
 #pragma unroll
             for (int j = i + 1; j < N; ++j)
-                jacobi_pair<M, N, HAS_V, INPLACE, FAST>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot, bad);
+                jacobi_pair<M, N, HAS_V, INPLACE, FAST, CHEAP>(At[i], At[j], Vt[i], Vt[j], W[i], W[j], changed, rot, bad,
+                                                               qmin);
         }
         pairs += N * (N - 1) / 2;
         if (!changed)
             break;
     }
+    if (CHEAP)
+        bad = bad || !((qmin >= kGuardQMin) && (wsum <= kGuardWSumMax));
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double sd = 0.0;
@@ -250,12 +312,12 @@ MVS_DEV void select_row(const double (&Mx)[N][N], int row, double (&out)[N])
 
 // Null vector of a symmetric 9x9 matrix B (= A^T A): last row of vt of cv::SVDecomp(B).
 // HAS_V = false: TIMING EXPERIMENT ONLY (V is never rotated, the result is meaningless)
-template <bool INPLACE, bool FAST, bool HAS_V = true>
+template <bool INPLACE, bool FAST, bool HAS_V = true, bool CHEAP = false>
 MVS_DEV void svd9_last_vt_row(double (&At)[9][9], double (&f)[9], unsigned &rot, unsigned &pairs, bool &bad)
 {
     double Vt[9][9], W[9];
     int tag[9];
-    jacobi_svd_core<9, 9, INPLACE, FAST, HAS_V>(At, Vt, W, rot, pairs, bad);
+    jacobi_svd_core<9, 9, INPLACE, FAST, HAS_V, CHEAP>(At, Vt, W, rot, pairs, bad);
     sort_tags_desc<9>(W, tag);
     select_row<9>(Vt, tag[8], f);
 }
@@ -472,7 +534,8 @@ MVS_DEV bool normalise8(const double (&px)[8], const double (&py)[8], double (&n
     return ok;
 }
 
-// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences (flag + recompute)
+// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences (flag + recompute);
+// 128 (with 32) = sqrt-free convergence test, range record instead of per-operand flags, selected power-of-two factors
 template <int VAR>
 MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
                          double (&F)[9], unsigned &rot9, unsigned &pairs9, bool &bad)
@@ -506,7 +569,7 @@ MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const dou
                 At[j][i] = acc;
             }
         }
-        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0, (VAR & 256) == 0>(At, f, rot9, pairs9, bad);
+        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0, (VAR & 256) == 0, (VAR & 128) != 0>(At, f, rot9, pairs9, bad);
     }
     // rank-2 enforcement (:127-136): F = u diag(w0, w1, 0) vt
     double Fn[3][3];

@@ -16,6 +16,8 @@
 // computation and needs a cross-lane reduction per dot product, whereas 64 independent
 // problems per wave keep every lane busy, need no cross-lane traffic, and give the
 // reference's sequential residual order for free.  See DESIGN.md.
+#include <algorithm>
+#include <cstdlib>
 #include "kernels.hpp"
 
 #include "device_math.hpp"
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
         // recompute this wave's hypotheses with the compiler's fully scaled sequences
         rot = 0;
         pairs = 0;
-        ok = solve_hypothesis<(VAR & ~32)>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+        ok = solve_hypothesis<(VAR & ~(32 | 128))>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
     }
 
     // score against all M matches.  Every lane reads the SAME point: the address is wave-uniform, but it is made
@@ -435,14 +437,16 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunPar
     if ((VAR & 32) && __builtin_expect(__any(bad), 0)) {
         rot = 0;
         pairs = 0;
-        ok = solve_hypothesis<(VAR & ~32)>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+        ok = solve_hypothesis<(VAR & ~(32 | 128))>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
     }
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    double *Fo = b.hyp_F + (size_t)pair * 9 * Hp + h;   // [9][Hp]: lane h of every row -> coalesced
-#pragma unroll
+    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * 9;   // [Hp][9]: 72 contiguous bytes per hypothesis (scalar loads
+#pragma unroll                                            // in ransac_count_kernel); the stores cover whole lines
     for (int k = 0; k < 9; ++k)
-        Fo[k * Hp] = F[k];
+        Fo[k] = F[k];
     b.hyp_okf[(size_t)pair * Hp + h] = ok ? 1 : 0;
+    if (g == 0 && tid == 0)
+        b.bound[pair] = 0;   // pruning bound of the scoring launch that follows on the stream
 }
 
 constexpr int kScoreChunk = 1024;   // points staged per pass: 32 KB of LDS -> 4 workgroups per CU
@@ -463,11 +467,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams
     const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
     const bool live = h < (uint32_t)H;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const double *Fi = b.hyp_F + (size_t)pair * 9 * Hp + h;
+    const double *Fi = b.hyp_F + ((size_t)pair * Hp + h) * 9;
     double F[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
-        F[k] = Fi[k * Hp];
+        F[k] = Fi[k];
     const bool ok = b.hyp_okf[(size_t)pair * Hp + h] != 0;
     const double *P = b.pts + (size_t)pair * b.max_kp * 4;
     __shared__ __attribute__((aligned(16))) double s_pts[kScoreChunk * 4];
@@ -533,6 +537,354 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams
 #pragma unroll
         for (int k = 0; k < 9; ++k)
             out->F[k] = F[k];
+    }
+}
+
+// ---- pruned scoring: ransac_count_kernel + ransac_select_kernel ------------------------------------------------------
+// The reference keeps the hypothesis with the most inliers, ties by the smaller residual sum, then by the smaller index
+// (estimator-RANSAC.cpp:76-84).  A hypothesis whose count can no longer reach a count that SOME hypothesis of the pair
+// has already achieved in full cannot be that winner, whatever its residual: it is dropped the moment
+//     count so far + points not yet visited  <  bound          (strict: ties stay in)
+// and the result is the same hypothesis, bit for bit, as scoring everything.  On the bench workload 97 % of the
+// hypotheses are contaminated and die after ~1/3 of the points.
+//
+// Mapping (the opposite of the solve): LANES ARE POINTS.  A wavefront takes four hypotheses at a time; their F are
+// wave-uniform (scalar loads of the 72-byte records the solve wrote, SGPR operands of v_fma_f64), each lane reads one
+// point of the current 64-point block from LDS and evaluates it for the hypotheses still alive, v_cmp writes the
+// inlier mask straight to an SGPR pair and s_bcnt1 counts it: 9 VALU instructions per 64 evaluations (the
+// hypothesis-per-lane scoring loop needs 15), no cross-lane traffic, and the exit test is scalar code.  Four
+// hypotheses in flight amortise the LDS read and keep the SALU / branch latency of the exit tests off the critical
+// path (the first attempt in round 1 had one hypothesis in flight and was latency-bound).
+// The bound is per pair: LDS copy per workgroup + one word in global memory (atomicMax, refreshed once per group
+// with the load issued a group ahead).  Which hypotheses get dropped depends on timing; the winner does not.
+// Residual sums are not accumulated here: ransac_select_kernel computes them, in the reference's index order, for the
+// hypotheses that tie at the final maximum only.
+constexpr int kCntSlots = 4;
+typedef __attribute__((address_space(4))) double CDouble;
+
+__device__ __forceinline__ int count_block(const double (&F)[9], const double4 &p, double thr)
+{
+    const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+    return __popcll(__ballot(r < thr));   // NaN (padding lanes, degenerate F) compares false
+}
+
+template <int kCntThreads>
+__global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, RunParams rp, int wg_per_pair)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];   // [nblk * 64][4], NaN padded
+    __shared__ int s_bound;
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8)
+        return;
+    const int H = rp.num_hypotheses;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const int nblk = (M + 63) >> 6;
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(b.pts + (size_t)pair * b.max_kp * 4);
+        double2 *dst = reinterpret_cast<double2 *>(s_cpts);
+        const double qnan = __builtin_nan("");
+        for (int i = tid; i < nblk * 128; i += kCntThreads)
+            dst[i] = i < 2 * M ? src[i] : make_double2(qnan, qnan);
+    }
+    int *gbound = b.bound + pair;
+    if (tid == 0)
+        s_bound = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double thr = pair_max_error_sq(b, rp, pair);
+    const double *Fp = b.hyp_F + (size_t)pair * Hp * 9;
+    const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
+    int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
+    const double4 *L4 = reinterpret_cast<const double4 *>(s_cpts) + lane;
+    const int n_groups = (H + kCntSlots - 1) / kCntSlots;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = wg_per_pair * (kCntThreads / 64);
+    int B = 0;
+    for (int g = blockIdx.x * (kCntThreads / 64) + wave; g < n_groups; g += n_waves) {
+        const int h0 = g * kCntSlots;
+        // the pair's bound as other workgroups see it: load now, use after this group
+        const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
+        // constant address space: wave-uniform scalar loads (s_load_dwordx16 through the scalar cache) instead of 18
+        // same-address vector loads per group, which kept the texture-address unit busier than the VALU.  The records
+        // were written by the solve launch; nothing writes them while this kernel runs.
+        double F0[9], F1[9], F2[9], F3[9];
+        const CDouble *f = (const CDouble *)(uintptr_t)(Fp + (size_t)h0 * 9);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            F0[k] = f[k];
+            F1[k] = f[9 + k];
+            F2[k] = f[18 + k];
+            F3[k] = f[27 + k];
+        }
+        // a v_fma_f64 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group,
+        // otherwise it is copied there again for every block
+#pragma unroll
+        for (int k = 6; k < 9; ++k) {
+            asm volatile("" : "+v"(F0[k]));
+            asm volatile("" : "+v"(F1[k]));
+            asm volatile("" : "+v"(F2[k]));
+            asm volatile("" : "+v"(F3[k]));
+        }
+        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
+        unsigned alive = 0;
+#pragma unroll
+        for (int k = 0; k < kCntSlots; ++k)
+            alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int blk = 0; blk < nblk && alive; ++blk) {
+            const double4 p = L4[blk * 64];
+            const int rem = max(M - (blk + 1) * 64, 0);
+            if (alive & 1u) {
+                c0 += count_block(F0, p, thr);
+                if (c0 + rem < B) alive &= ~1u;
+            }
+            if (alive & 2u) {
+                c1 += count_block(F1, p, thr);
+                if (c1 + rem < B) alive &= ~2u;
+            }
+            if (alive & 4u) {
+                c2 += count_block(F2, p, thr);
+                if (c2 + rem < B) alive &= ~4u;
+            }
+            if (alive & 8u) {
+                c3 += count_block(F3, p, thr);
+                if (c3 + rem < B) alive &= ~8u;
+            }
+        }
+        // a slot that is still alive has seen every point: its count is final
+        const int v0 = (alive & 1u) ? c0 : -1, v1 = (alive & 2u) ? c1 : -1;
+        const int v2 = (alive & 4u) ? c2 : -1, v3 = (alive & 8u) ? c3 : -1;
+        if (lane < kCntSlots)
+            cntp[h0 + lane] = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
+        const int cm = __builtin_amdgcn_readfirstlane(max(max(v0, v1), max(v2, v3)));
+        if (cm > B) {
+            B = cm;
+            if (lane == 0) {
+                atomicMax(&s_bound, cm);
+                __hip_atomic_fetch_max(gbound, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        B = max(B, __builtin_amdgcn_readfirstlane(gb));
+    }
+}
+
+// grid P, 256 threads.  bound[pair] is now the largest full count (every surviving hypothesis went through the
+// atomicMax); hypotheses at that count are collected in index order and scored once more, one per lane over the LDS
+// point stream with the fused kernel's exact operations (count AND residual sum in index order), and the best by
+// (residual, index) becomes the pair's single WgBest record; finalize_model reduces the records as before.
+constexpr int kSelThreads = 256;
+constexpr int kSelList = 1024;
+constexpr int kSelSerial = 24;   // up to this many ties are scored one at a time by the whole workgroup
+
+__global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, RunParams rp)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_spts[];   // [max_kp][4] points OR [max_kp] residuals
+    __shared__ uint32_t s_list[kSelList];
+    __shared__ double s_F[9];
+    __shared__ int s_tot[4];
+    __shared__ Cand s_c[4];
+    __shared__ Cand s_best;
+    __shared__ double s_bestF[9];
+    __shared__ uint32_t s_win;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int M = min(b.M[pair], b.max_kp);
+    const int H = rp.num_hypotheses;
+    const int G = (H + kHypPerBlock - 1) / kHypPerBlock;
+    WgBest *out = b.wgbest + (size_t)pair * b.max_groups;
+    for (int g = 1 + tid; g < G; g += kSelThreads) {
+        out[g].count = -1;
+        out[g].hyp = 0xffffffffu;
+        out[g].residual = 0.0;
+    }
+    if (tid == 0) {
+        s_best.cnt = -2;
+        s_best.hyp = 0xffffffffu;
+        s_best.res = 0.0;
+    }
+    if (M < 8) {  // estimator-RANSAC.cpp:25-29
+        if (tid == 0) {
+            out[0].count = -1;
+            out[0].hyp = 0xffffffffu;
+            out[0].residual = 0.0;
+        }
+        return;
+    }
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const double4 *P4 = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+    bool staged = false;   // the dynamic LDS block holds the pair's points (lane-per-hypothesis path) or residuals
+    __syncthreads();
+    const int cmax = b.bound[pair];
+    const int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
+    const double *Fp = b.hyp_F + (size_t)pair * Hp * 9;
+    const double thr = pair_max_error_sq(b, rp, pair);
+    const double4 *L4 = reinterpret_cast<const double4 *>(s_spts);
+    double *s_r = s_spts;
+    const int lane = tid & 63, w = tid >> 6;
+    int scan = 0;
+    while (scan < H) {
+        // collect the next <= kSelList tied hypotheses, ascending
+        int n_list = 0;
+        while (scan < H && n_list <= kSelList - kSelThreads) {
+            const int h = scan + tid;
+            const bool flag = h < H && cntp[h] == cmax;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0)
+                s_tot[w] = __popcll(bal);
+            __syncthreads();
+            int off = n_list, tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = s_tot[k];
+                off += (k < w) ? v : 0;
+                tot += v;
+            }
+            if (flag)
+                s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)h;
+            n_list += tot;
+            scan += kSelThreads;
+            __syncthreads();
+        }
+        if (n_list <= kSelSerial) {
+            // few ties (the usual case is one): the whole workgroup scores ONE hypothesis at a time -- residuals of all
+            // points in parallel, inliers compacted in index order, then one lane adds them up in that order.  The
+            // sequential replacement rule's sum is res = fma(r_i, m_i, res) with m_i in {0, 1} over all i, i.e. the
+            // inlier residuals added in index order, one rounding each: the same bits.
+            staged = false;
+            for (int q = 0; q < n_list; ++q) {
+                const uint32_t h = s_list[q];
+                if (tid < 9)
+                    s_F[tid] = Fp[(size_t)h * 9 + tid];
+                __syncthreads();
+                double F[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    F[k] = s_F[k];
+                int n_in = 0;
+                for (int start = 0; start < M; start += kSelThreads) {
+                    const int i = start + tid;
+                    double r = 0.0;
+                    bool in = false;
+                    if (i < M) {
+                        const double4 p = P4[i];
+                        r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+                        in = r < thr;
+                    }
+                    const unsigned long long bal = __ballot(in);
+                    if (lane == 0)
+                        s_tot[w] = __popcll(bal);
+                    __syncthreads();
+                    int off = n_in, tot = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int v = s_tot[k];
+                        off += (k < w) ? v : 0;
+                        tot += v;
+                    }
+                    if (in)
+                        s_r[off + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+                    n_in += tot;
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    double res = 0.0;
+                    int i = 0;
+                    for (; i + 8 <= n_in; i += 8) {
+                        const double r0 = s_r[i], r1 = s_r[i + 1], r2 = s_r[i + 2], r3 = s_r[i + 3];
+                        const double r4 = s_r[i + 4], r5 = s_r[i + 5], r6 = s_r[i + 6], r7 = s_r[i + 7];
+                        res += r0; res += r1; res += r2; res += r3;
+                        res += r4; res += r5; res += r6; res += r7;
+                    }
+                    for (; i < n_in; ++i)
+                        res += s_r[i];
+                    const Cand me{n_in, h, res};
+                    if (s_best.cnt < 0 || cand_better(me, s_best)) {
+                        s_best = me;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k)
+                            s_bestF[k] = F[k];
+                    }
+                }
+                __syncthreads();
+            }
+            continue;
+        }
+        if (!staged) {
+            const double2 *src = reinterpret_cast<const double2 *>(P4);
+            double2 *dst = reinterpret_cast<double2 *>(s_spts);
+            for (int i = tid; i < 2 * M; i += kSelThreads)
+                dst[i] = src[i];
+            staged = true;
+            __syncthreads();
+        }
+        for (int q0 = 0; q0 < n_list; q0 += kSelThreads) {
+            const bool have = q0 + tid < n_list;
+            const uint32_t h = have ? s_list[q0 + tid] : 0xffffffffu;
+            Cand me{-2, h, 0.0};
+            double F[9];
+            if (have) {
+                const double *f = Fp + (size_t)h * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    F[k] = f[k];
+                int cnt = 0;
+                double res = 0.0;
+#pragma unroll 4
+                for (int i = 0; i < M; ++i) {   // the fused kernel's loop: same operations, same order, same bits
+                    const double4 p = L4[i];
+                    const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+                    const bool in = r < thr;
+                    cnt += in ? 1 : 0;
+                    const double m = __hiloint2double(in ? 0x3ff00000 : 0, 0);
+                    res = dfma(r, m, res);
+                }
+                me.cnt = cnt;
+                me.res = res;
+            }
+            Cand red = me;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                Cand other;
+                other.cnt = __shfl_xor(red.cnt, o);
+                other.hyp = __shfl_xor(red.hyp, o);
+                other.res = __shfl_xor(red.res, o);
+                if (other.cnt >= 0 && (red.cnt < 0 || cand_better(other, red)))
+                    red = other;
+            }
+            if (lane == 0)
+                s_c[w] = red;
+            __syncthreads();
+            if (tid == 0) {
+                Cand best = s_best;
+                bool repl = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (s_c[k].cnt >= 0 && (best.cnt < 0 || cand_better(s_c[k], best))) {
+                        best = s_c[k];
+                        repl = true;
+                    }
+                s_best = best;
+                s_win = repl ? best.hyp : 0xfffffffeu;
+            }
+            __syncthreads();
+            if (have && h == s_win) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    s_bestF[k] = F[k];
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const Cand best = s_best;
+        out[0].count = best.cnt >= 0 ? best.cnt : -1;
+        out[0].hyp = best.cnt >= 0 ? best.hyp : 0xffffffffu;
+        out[0].residual = best.cnt >= 0 ? best.res : 0.0;
+        if (best.cnt >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                out[0].F[k] = s_bestF[k];
+        }
     }
 }
 
@@ -995,7 +1347,9 @@ void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2,
     hipLaunchKernelGGL(prep_points_kernel, dim3((b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b, uv1, uv2);
 }
 
-static int g_ransac_variant = 632;  // 120 fused; 632 = solve + score as two launches
+// 120 fused; 632 = solve + hypothesis-per-lane scoring as two launches (round 1); 1784 = solve (with the sqrt-free
+// convergence test, bit 128) + pruned point-per-lane scoring (bit 1024): ransac_count + ransac_select
+static int g_ransac_variant = 1784;
 void set_ransac_variant(int v) { g_ransac_variant = v; }
 int get_ransac_variant() { return g_ransac_variant; }
 
@@ -1008,20 +1362,84 @@ static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid,
         hipLaunchKernelGGL((ransac_kernel<false, VAR>), grid, block, 0, stream, b, rp);
 }
 
+static int cnt_threads()
+{
+    static int t = 0;
+    if (!t) {
+        const char *e = getenv("MVS_CNT_THREADS");   // experiment knob (512 / 1024)
+        t = (e && atoi(e) == 512) ? 512 : 1024;
+    }
+    return t;
+}
+
+static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
+{
+    // enough workgroups to fill the chip for a small launch, few enough that every wavefront works through many
+    // groups of four hypotheses (the bound only helps once the first groups have finished)
+    const int threads = cnt_threads();
+    const int n_groups4 = (rp.num_hypotheses + kCntSlots - 1) / kCntSlots;
+    const int wpw = threads / 64;
+    int wg = (512 + n_active - 1) / n_active;
+    wg = std::max(wg, 4);
+    wg = std::min(wg, std::max(1, (n_groups4 + wpw - 1) / wpw));
+    const size_t lds_cnt = (size_t)((b.max_kp + 63) / 64) * 64 * 4 * sizeof(double);
+    const size_t lds_sel = (size_t)b.max_kp * 4 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel<512>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel<1024>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_select_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
+        attr_set = true;
+    }
+    if (threads == 512)
+        hipLaunchKernelGGL(ransac_count_kernel<512>, dim3(wg, n_active), dim3(512), lds_cnt, stream, b, rp, wg);
+    else
+        hipLaunchKernelGGL(ransac_count_kernel<1024>, dim3(wg, n_active), dim3(1024), lds_cnt, stream, b, rp, wg);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
+}
+
 void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream)
 {
     const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
     const dim3 grid(G, n_active), block(kHypPerBlock);
+    // the instrumented replay and the per-hypothesis tables (every count AND every residual) stay on the
+    // hypothesis-per-lane kernels; so does a launch of one or two pairs (latency: fewer launches)
+    const bool split_ok = !stats && b.hyp_F && n_active >= 3;
     switch (g_ransac_variant) {
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
     case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream); break;   // timing experiment: no V rotations
-    case 632:   // 120 | 512: solve and scoring as two launches (stats replay stays on the fused kernel; so does a
-                // launch of one or two pairs, where the second launch costs more latency than the scoring gains)
-        if (stats || !b.hyp_F || n_active < 3) {
+    case 632:
+        if (!split_ok) {
             launch_ransac_var<120>(b, rp, grid, block, stats, stream);
         } else {
             hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
             hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
+        }
+        break;
+    case 760:   // 632 + sqrt-free convergence test
+        if (!split_ok) {
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+        } else {
+            hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
+            hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
+        }
+        break;
+    case 1656:  // 632 + pruned scoring
+    case 1784:  // 760 + pruned scoring
+        if (!split_ok) {
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+        } else {
+            if (g_ransac_variant == 1784)
+                hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
+            else
+                hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
+            if (b.hyp_count)
+                hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
+            else
+                launch_pruned_scoring(b, rp, n_active, stream);
         }
         break;
     default: launch_ransac_var<120>(b, rp, grid, block, stats, stream); break;

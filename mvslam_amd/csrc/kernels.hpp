@@ -56,8 +56,10 @@ struct BatchDev {
     mvs_match *matches;  // [P][N]
     double *pts;         // [P][N][4]  (x1, y1, x2, y2) ideal-camera coordinates of match m
     WgBest *wgbest;      // [P][max_groups]
-    double *hyp_F;       // [P][9][max_groups * 256] F of every hypothesis (split solve / score variant), may be null
+    double *hyp_F;       // [P][max_groups * 256][9] F of every hypothesis (solve -> scoring hand-over), may be null
     uint8_t *hyp_okf;    // [P][max_groups * 256] solve succeeded
+    int32_t *hyp_cnt;    // [P][max_groups * 256] full inlier count of a hypothesis that can still win, -1 otherwise
+    int32_t *bound;      // [P] largest full count seen so far (the pruning bound of ransac_count_kernel)
     double *cand_pts;    // [P][4][N][3] triangulation scratch
     FinModel *fin;       // [P]
     uint16_t *inl;       // [P][N] ordered inlier list

@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvslam_amd import capi, synth  # noqa: E402
 
 NAMES = {0: "round-1 first version", 120: "fused: LDS point stream + in-place rotation + mask-fma + unscaled sqrt/div",
-         632: "120 split into a solve and a scoring launch (default)", 376: "timing only: 120 without V rotations"}
+         632: "120 split into a solve and a scoring launch (round-1 default)", 376: "timing only: 120 without V rotations",
+         760: "632 + sqrt-free convergence test in the solve", 1656: "632 + pruned point-per-lane scoring",
+         1784: "760 + pruned point-per-lane scoring (default)"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=128)
@@ -20,6 +22,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--hyp", type=int, default=50000)
 ap.add_argument("--kp", type=int, default=2000)
 ap.add_argument("--variants", default="0,120")
+ap.add_argument("--max-error-sq", type=float, default=1e-2, help="<= 0: the reference formula 5e-2 / K00 / K11")
 ap.add_argument("--no-check", action="store_true", help="do not compare results (timing-only experimental variants)")
 args = ap.parse_args()
 variants = [int(v) for v in args.variants.split(",")]
@@ -28,7 +31,7 @@ ctx = capi.Context(0)
 data = synth.make_batch(0, args.pairs, n_kp=args.kp)
 b = capi.Batch(ctx, args.pairs, args.kp, 32)
 b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
-prm = capi.default_params(num_hypotheses=args.hyp, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
+prm = capi.default_params(num_hypotheses=args.hyp, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=args.max_error_sq)
 lib = capi.lib()
 ref = None
 t = {v: [] for v in variants}
