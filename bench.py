@@ -78,6 +78,7 @@ def cpu_baseline(data, params_kw, n_pairs_total, budget_s=25.0):
         th.join()
     dt = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "pairs/s", "cores": len(threads), "kind": "port",
+            "single_thread_pairs_per_s": round(1.0 / t_one, 3),
             "sample": "%d pairs of the same workload (full %d hypotheses each), one pair per thread; "
                       "single-thread latency %.2f s/pair" % (n_sample, params_kw["num_hypotheses"], t_one)}
 
@@ -101,6 +102,8 @@ def main():
                     "buffers over PCIe); reported as pcie_inclusive_pairs_per_s, never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--no-ref-threshold", action="store_true", help="skip the extra reference-threshold timing (profiling "
+                    "runs: keeps every launch of a kernel on the same workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,12 +146,25 @@ def main():
     rec_bytes = capi.RESULT_DTYPE.itemsize
     rec_local = torch.empty(n_local * rec_bytes, dtype=torch.uint8, device="cuda")
 
-    def step():
+    gather_ev = []   # (start, end) torch events around the all-gather of every timed step (N > 1)
+
+    def step(timed=False):
         batch.run(prm)
         if world > 1:  # the one exchange step of the path: all-gather of the pose records over RCCL/xGMI
             batch.copy_results_device(rec_local.data_ptr())
             batch.sync()
-            return mdist.gather_records(rec_local if args.backend == "nccl" else rec_local.cpu(), world)
+            if timed and args.backend == "nccl":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g = mdist.gather_records(rec_local, world)
+                e1.record()
+                gather_ev.append((e0, e1))
+                return g
+            t_g = time.perf_counter()
+            g = mdist.gather_records(rec_local if args.backend == "nccl" else rec_local.cpu(), world)
+            if timed:
+                gather_ev.append(time.perf_counter() - t_g)
+            return g
         return None
 
     def fence():
@@ -164,7 +180,7 @@ def main():
     t0 = time.perf_counter()
     gathered = None
     for _ in range(args.steps):
-        gathered = step()
+        gathered = step(timed=True)
     batch.sync()
     fence()
     elapsed = time.perf_counter() - t0
@@ -172,6 +188,16 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    gather_us = None
+    if world > 1 and gather_ev:   # communication reported separately from compute; max over ranks
+        if isinstance(gather_ev[0], tuple):
+            g_us = float(np.mean([a.elapsed_time(b2) for a, b2 in gather_ev])) * 1e3
+        else:
+            g_us = float(np.mean(gather_ev)) * 1e6
+        tg = torch.tensor([g_us], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_us = round(float(tg.item()), 1)
 
     ms_per_step = elapsed / args.steps * 1e3
     total_pairs = n_local * world
@@ -190,12 +216,21 @@ def main():
         achieved = flops / ransac_s / 1e12
         m_avg = float(res["n_matches"].mean())
         bytes_pair = algorithmic_bytes(args.kp, m_avg, float(res["n_inliers"].mean()), float(res["n_points"].mean()))
-        # HBM bytes of the RANSAC launch from the PMC run committed under profiles/ ((2*FETCH_SIZE + WRITE_SIZE) KB per
-        # MI355X_MICROARCH.md, measured with rocprofv3 --pmc in its own pass); only valid for the default workload
+        # HBM bytes of the RANSAC launches: a RECORDED value (PMC counters cannot be read inside this process): the
+        # rocprofv3 --pmc pass of this same workload committed under profiles/ ((2*FETCH_SIZE + WRITE_SIZE) KB per
+        # MI355X_MICROARCH.md, its own pass); only quoted for the default workload, null otherwise
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_ransac_hbm_traffic.json")
-        if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000:
+        tpath = os.path.join(ROOT, "profiles", "r02_ransac_hbm_traffic.json")
+        if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000 and args.max_error_sq == 1e-2:
             traffic = int(json.load(open(tpath))["hbm_bytes_per_pair"] * n_local)
+        # the reference-threshold regime (5e-2 / K00 / K11, sfm-solve.cpp:311: ~5 inliers, ties decided by the residual
+        # sum, nothing to prune) with the same kernels, in the same line
+        ref_thr = None
+        if args.max_error_sq > 0 and not args.no_ref_threshold:
+            prm_ref = capi.default_params(sampler=capi.SAMPLER_PHILOX, min_inliers=8, **dict(params_kw, max_error_sq=0.0))
+            tot_ref, k_ref = batch.time(prm_ref, steps=3, warmup=1)
+            ref_thr = {"pairs_per_s": round(n_local * 3 / (tot_ref * 1e-3), 1), "ransac_ms": round(k_ref["ransac"] / 3, 3),
+                       "max_error_sq": "5e-2/K00/K11 = %.3e" % (5e-2 / 525.0 / 525.0)}
         out = {
             "metric": "image-pairs/sec (2k kp, 50k RANSAC hyp)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -207,18 +242,23 @@ def main():
                 "pairs_per_gpu": n_local, "keypoints": args.kp, "hypotheses": args.hyp, "noise_px": args.noise_px,
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world},
             "roofline": {
-                "bound": "mfma", "kernel": "ransac_solve_kernel + ransac_score_kernel (the RANSAC stage; launch_ms is their sum)",
-                "bound_detail": "fp64 VALU (vector FMA); MI355X fp64 vector peak = fp64 MFMA dense peak = 78.6 TFLOP/s",
+                "bound": "valu_fp64",
+                "kernel": "ransac_solve_kernel<240> + ransac_count_kernel + ransac_select_kernel (the RANSAC stage; launch_ms is their sum)",
+                "bound_detail": "fp64 vector FMA rate: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (no MFMA is "
+                                "issued: v_mfma_f64 shares the double-precision pipe, profiles/r02_mfma_coissue_microbench.txt)",
                 "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r01_ransac_hbm_traffic.json; algorithmic: %d for points + arg-best, + 2 x 72 B per hypothesis for the F hand-over between the solve and the scoring launch"
+                "traffic_source": "recorded: profiles/r02_ransac_hbm_traffic.json (rocprofv3 --pmc pass of this workload)",
+                "traffic_note": "algorithmic: %d B for points + arg-best; the rest is the F hand-over between the solve and "
+                                "the scoring launches (72 B written + read per hypothesis, + 4 B count)"
                                 % int((m_avg * 32 + 88 * ((args.hyp + 255) // 256)) * n_local),
                 "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3),
                 # north_star: occupancy / LDS of the RANSAC kernel (hipcc -Rpass-analysis=kernel-resource-usage)
-                "occupancy_waves_per_simd": {"solve": 1, "score": 4}, "vgprs": {"solve": 256, "score": 124},
-                "agprs": {"solve": 123, "score": 0}, "scratch_bytes": 0, "lds_bytes_per_workgroup": {"solve": 0, "score": 32768},
-                "fp64_issue_note": "one fp64 instruction per 6.0 cycles = 86 % of the 5.14-cycle rate this part sustains "
-                                   "(profiles/r01_fp64_issue_microbench.txt)"},
+                "occupancy_waves_per_simd": {"solve": 1, "count": 8, "select": 8},
+                "vgprs": {"solve": 256, "count": 46, "select": 58}, "agprs": {"solve": 150, "count": 0, "select": 0},
+                "scratch_bytes": 0, "lds_bytes_per_workgroup": {"solve": 0, "count": 32 * ((args.kp + 63) // 64) * 64, "select": 32 * args.kp},
+                "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
+                                   "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"},
             "hbm_roofline": {
                 "achieved": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9 / HBM_PEAK_GBS, 6),
@@ -230,6 +270,11 @@ def main():
                      "rotations9_per_hyp": round(stats["rotations9"] / max(stats["hypotheses"], 1), 2),
                      "pairs9_per_hyp": round(stats["pairs9"] / max(stats["hypotheses"], 1), 2)},
         }
+        if ref_thr is not None:
+            out["reference_threshold"] = ref_thr
+        if gather_us is not None:
+            out["gather_us"] = gather_us
+            out["gather_note"] = "all-gather of the %d-byte pose records (%d per rank), timed with its own events inside the timed steps; max over ranks" % (rec_bytes, n_local)
         if world > 1 and gathered is not None:
             allrec = mdist.records_to_numpy(gathered, capi.RESULT_DTYPE)
             out["work"]["gathered_records"] = int(len(allrec))

@@ -312,15 +312,24 @@ typedef struct mvs_ba_problem {
 mvs_status mvs_ba_refine(mvs_ctx *ctx, const mvs_ba_problem *problem, const mvs_refine_params *params,
                          mvs_refine_result *frames_out, double *points_out, double *point_cov_out);
 /* Batched ImagePair::refine (front-end/image-pair.cpp:176-238) on a batch that has been run: every valid pair is refined
- * from its own results on the device (observations = the matched keypoints, covariance (sigma_px)^2 I as
- * VisualFeature::get_point_estimates gives an octave-0 ORB keypoint: sigma_px = 0.5, visual-feature.cpp:193-207).
+ * from its own results on the device.  Observations = the matched keypoints with the covariance
+ * VisualFeature::get_point_estimates gives them (vision/visual-feature.cpp:192-207): stddev = (1 << kp.octave) * 0.5 px,
+ * i.e. (sigma_px * 2^octave)^2 I with sigma_px = 0.5.  The octave of every keypoint is resident next to its
+ * coordinates: written by the device extractor (mvs_seq_upload_images), supplied by the caller for host-uploaded
+ * keypoints (mvs_batch_upload_octaves / mvs_seq_upload_octaves), 0 otherwise.
  * Asynchronous on the ctx stream; results stay resident until downloaded. */
 mvs_status mvs_batch_refine(mvs_batch *b, const mvs_refine_params *params, double sigma_px);
+/* cv::KeyPoint::octave of the keypoints uploaded with mvs_batch_upload: count x max_kp bytes per image (NULL = leave);
+ * values above 30 are rejected (MVS_ERR_INVALID_ARG).  Only mvs_batch_refine reads them. */
+mvs_status mvs_batch_upload_octaves(mvs_batch *b, int first, int count, const uint8_t *base_octave,
+                                    const uint8_t *pair_octave);
 /* refined[n_pairs]; points_xyz / point_cov: n_pairs x max_kp x 3 / 9 (NULL to skip), rows [0, results[p].n_points) */
 mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, double *points_xyz, double *point_cov);
 /* the same for the n_frames - 1 consecutive pairs of a sequence that has been run (VisualOdometer::initialize refines its
  * queued pairs, front-end/visual-odometer.cpp:282-286) */
 mvs_status mvs_seq_refine_pairs(mvs_seq *s, const mvs_refine_params *params, double sigma_px);
+/* octaves of the keypoints of frames [first, first + count) uploaded with mvs_seq_upload: count x max_kp bytes */
+mvs_status mvs_seq_upload_octaves(mvs_seq *s, int first, int count, const uint8_t *octave);
 mvs_status mvs_seq_download_refined(mvs_seq *s, mvs_refine_result *refined, double *points_xyz, double *point_cov);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -111,7 +111,7 @@ EXPORTS = [
     "mvs_seq_upload", "mvs_seq_run", "mvs_seq_sync", "mvs_seq_time", "mvs_seq_download_pairs", "mvs_seq_download_tracks",
     "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
-    "mvs_ba_refine", "mvs_seq_download_trajectory",
+    "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
 ]
 
 
@@ -502,6 +502,17 @@ class Batch:
         self.ctx._check(st, "mvs_batch_download")
         return dict(results=res, matches=mt, mask=mk, points=pts, point_idx=idx)
 
+    def upload_octaves(self, first, base_octave=None, pair_octave=None):
+        """cv::KeyPoint::octave of the uploaded keypoints, [count][max_kp] uint8 per image (observation covariances
+        of refine(): stddev = 2^octave * sigma_px)"""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.uint8) for a in (base_octave, pair_octave)]
+        count = next(a for a in arrs if a is not None).shape[0]
+        for a in arrs:
+            assert a is None or a.shape == (count, self.max_kp)
+        st = lib().mvs_batch_upload_octaves(self._h, C.c_int(first), C.c_int(count), _ptr(arrs[0], C.c_uint8),
+                                            _ptr(arrs[1], C.c_uint8))
+        self.ctx._check(st, "mvs_batch_upload_octaves")
+
     def refine(self, params=None, sigma_px=0.5):
         """ImagePair::refine of every valid pair, on the device, from the batch's own results (asynchronous)"""
         params = params or default_refine_params()
@@ -590,6 +601,12 @@ class Sequence:
                                                _ptr(ts, C.c_double))
         self.ctx._check(st, "mvs_seq_download_trajectory")
         return dict(R=R, t=t, pair_scale=ps, track_scale=ts)
+
+    def upload_octaves(self, first, octave):
+        octave = np.ascontiguousarray(octave, dtype=np.uint8)
+        assert octave.ndim == 2 and octave.shape[1] == self.max_kp
+        st = lib().mvs_seq_upload_octaves(self._h, C.c_int(first), C.c_int(octave.shape[0]), _ptr(octave, C.c_uint8))
+        self.ctx._check(st, "mvs_seq_upload_octaves")
 
     def refine_pairs(self, params=None, sigma_px=0.5):
         params = params or default_refine_params()

@@ -307,6 +307,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     mvs_status st = MVS_OK;
     uint32_t *desc1, *desc2;
     float *kp1, *kp2;
+    uint8_t *oct1, *oct2;
     int32_t *n1, *n2;
     double *Kinv, *K;
     int64_t *gidx;
@@ -315,14 +316,17 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     const size_t NI = n_frames ? (size_t)n_frames : P;  // images held by desc1 / kp1 / n1
     ALLOC(desc1, NI * N * d.desc_words);
     ALLOC(kp1, NI * N * 2);
+    ALLOC(oct1, NI * N);
     ALLOC(n1, NI);
     if (n_frames) {  // pair k's second image is frame k + 1
         desc2 = desc1 + N * d.desc_words;
         kp2 = kp1 + N * 2;
+        oct2 = oct1 + N;
         n2 = n1 + 1;
     } else {
         ALLOC(desc2, P * N * d.desc_words);
         ALLOC(kp2, P * N * 2);
+        ALLOC(oct2, P * N);
         ALLOC(n2, P);
     }
     ALLOC(Kinv, P * 9);
@@ -348,6 +352,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
         return st;
     }
     d.desc1 = desc1; d.desc2 = desc2; d.kp1 = kp1; d.kp2 = kp2; d.n1 = n1; d.n2 = n2;
+    d.oct1 = oct1; d.oct2 = oct2;
     d.Kinv = Kinv; d.K = K; d.gidx = gidx;
     d.wgbest = nullptr;
     d.hyp_F = nullptr;
@@ -361,7 +366,9 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     (void)hipMemsetAsync(desc1, 0, NI * N * d.desc_words * 4, s);
     (void)hipMemsetAsync(kp1, 0, NI * N * 2 * sizeof(float), s);
     (void)hipMemsetAsync(n1, 0, NI * sizeof(int32_t), s);
+    (void)hipMemsetAsync(oct1, 0, NI * N, s);   // octave 0 (stddev = sigma_px) unless the extractor / caller says otherwise
     if (!n_frames) {
+        (void)hipMemsetAsync(oct2, 0, P * N, s);
         (void)hipMemsetAsync(desc2, 0, P * N * d.desc_words * 4, s);
         (void)hipMemsetAsync(kp2, 0, P * N * 2 * sizeof(float), s);
         (void)hipMemsetAsync(n2, 0, P * sizeof(int32_t), s);
@@ -1694,6 +1701,45 @@ mvs_status mvs_seq_refine_pairs(mvs_seq *q, const mvs_refine_params *params, dou
     return q ? mvs_batch_refine(q->batch, params, sigma_px) : MVS_ERR_INVALID_ARG;
 }
 
+mvs_status mvs_batch_upload_octaves(mvs_batch *b, int first, int count, const uint8_t *base_octave,
+                                    const uint8_t *pair_octave)
+{
+    if (!b || first < 0 || count < 1 || first + count > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t N = b->d.max_kp, off = (size_t)first * N, bytes = (size_t)count * N;
+    for (const uint8_t *o : {base_octave, pair_octave})
+        if (o)
+            for (size_t i = 0; i < bytes; ++i)
+                if (o[i] > 30)
+                    return MVS_ERR_INVALID_ARG;   // stddev = (1 << octave) * 0.5 (visual-feature.cpp:203)
+    if (base_octave)
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t *>(b->d.oct1) + off, base_octave, bytes, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    if (pair_octave)
+        HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t *>(b->d.oct2) + off, pair_octave, bytes, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+mvs_status mvs_seq_upload_octaves(mvs_seq *q, int first, int count, const uint8_t *octave)
+{
+    if (!q || !octave || first < 0 || count < 1 || first + count > q->n_frames)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = q->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t N = q->batch->d.max_kp, bytes = (size_t)count * N;
+    for (size_t i = 0; i < bytes; ++i)
+        if (octave[i] > 30)
+            return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t *>(q->batch->d.oct1) + (size_t)first * N, octave, bytes,
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
 mvs_status mvs_seq_download_refined(mvs_seq *q, mvs_refine_result *refined, double *points_xyz, double *point_cov)
 {
     return q ? mvs_batch_download_refined(q->batch, refined, points_xyz, point_cov) : MVS_ERR_INVALID_ARG;
@@ -1779,7 +1825,8 @@ static bool orb_layout_host(int w, int h, const mvs_orb_params &p, OrbDev &d, si
 // runs the extraction of n images (host pointer) through the ctx workspace; outputs go to the given DEVICE arrays
 // (desc / kp_xy / n_kp may belong to a sequence) and, when kp_rec_out is non-null, records are also left in the workspace
 static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int h, const mvs_orb_params &prm,
-                          uint8_t *d_desc_ext, float *d_kp_xy_ext, int32_t *d_n_ext, OrbDev &d)
+                          uint8_t *d_desc_ext, float *d_kp_xy_ext, int32_t *d_n_ext, OrbDev &d,
+                          uint8_t *d_kp_oct_ext = nullptr)
 {
     if (w < 1 || h < 1 || w > 65535 || h > 65535)
         return MVS_ERR_CAPACITY;
@@ -1855,6 +1902,7 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     d.desc = d_desc_ext ? d_desc_ext : reinterpret_cast<uint8_t *>(base + o_desc);
     d.n_kp = d_n_ext ? d_n_ext : reinterpret_cast<int32_t *>(base + o_n);
     d.kp_xy = d_kp_xy_ext;
+    d.kp_oct = d_kp_oct_ext;
     hipStream_t s = ctx->stream;
     int8_t pat[1024];
     orb_pattern_host(pat);
@@ -1922,7 +1970,8 @@ mvs_status mvs_seq_upload_images(mvs_seq *q, int first, int count, const uint8_t
     OrbDev d;
     mvs_status st = orb_run(q->ctx, images, count, width, height, prm,
                             reinterpret_cast<uint8_t *>(const_cast<uint32_t *>(bd.desc1)) + off * N * 32,
-                            const_cast<float *>(bd.kp1) + off * N * 2, const_cast<int32_t *>(bd.n1) + off, d);
+                            const_cast<float *>(bd.kp1) + off * N * 2, const_cast<int32_t *>(bd.n1) + off, d,
+                            const_cast<uint8_t *>(bd.oct1) + off * N);
     if (st != MVS_OK)
         return st;
     return K ? mvs_seq_upload(q, first, count, nullptr, nullptr, nullptr, K) : MVS_OK;

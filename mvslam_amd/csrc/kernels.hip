@@ -571,7 +571,10 @@ __device__ __forceinline__ int count_block(const double (&F)[9], const double4 &
 template <int kCntThreads>
 __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, RunParams rp, int wg_per_pair)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_cpts[];   // [nblk * 64][4], NaN padded
+    // two planes of double2, [nblk * 64] each: (x1, y1) and (x2, y2), NaN padded.  A lane reads one element of each with
+    // ds_read_b128 at a 16-byte lane stride = 1 KB contiguous per wavefront: conflict-free (the AoS form, 32-byte
+    // stride, spent as many cycles in bank conflicts as the kernel was busy: profiles/r02_pmc_summary.json history)
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
     __shared__ int s_bound;
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int M = min(b.M[pair], b.max_kp);
@@ -580,12 +583,16 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
     const int H = rp.num_hypotheses;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     const int nblk = (M + 63) >> 6;
+    double2 *s_p1 = reinterpret_cast<double2 *>(s_cpts);
+    double2 *s_p2 = s_p1 + nblk * 64;
     {
-        const double2 *src = reinterpret_cast<const double2 *>(b.pts + (size_t)pair * b.max_kp * 4);
-        double2 *dst = reinterpret_cast<double2 *>(s_cpts);
+        const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
         const double qnan = __builtin_nan("");
-        for (int i = tid; i < nblk * 128; i += kCntThreads)
-            dst[i] = i < 2 * M ? src[i] : make_double2(qnan, qnan);
+        for (int i = tid; i < nblk * 64; i += kCntThreads) {
+            const double4 p = i < M ? src[i] : make_double4(qnan, qnan, qnan, qnan);
+            s_p1[i] = make_double2(p.x, p.y);
+            s_p2[i] = make_double2(p.z, p.w);
+        }
     }
     int *gbound = b.bound + pair;
     if (tid == 0)
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
     const double *Fp = b.hyp_F + (size_t)pair * Hp * 9;
     const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
     int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
-    const double4 *L4 = reinterpret_cast<const double4 *>(s_cpts) + lane;
+    const double2 *L1 = s_p1 + lane, *L2 = s_p2 + lane;
     const int n_groups = (H + kCntSlots - 1) / kCntSlots;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_waves = wg_per_pair * (kCntThreads / 64);
@@ -633,7 +640,8 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
             alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         for (int blk = 0; blk < nblk && alive; ++blk) {
-            const double4 p = L4[blk * 64];
+            const double2 pa = L1[blk * 64], pb = L2[blk * 64];
+            const double4 p = make_double4(pa.x, pa.y, pb.x, pb.y);
             const int rem = max(M - (blk + 1) * 64, 0);
             if (alive & 1u) {
                 c0 += count_block(F0, p, thr);

@@ -43,6 +43,8 @@ struct BatchDev {
     const uint32_t *desc2;  // [P][N][desc_words]   pair / query (vf2)
     const float *kp1;       // [P][N][2]
     const float *kp2;       // [P][N][2]
+    const uint8_t *oct1;    // [P][N] pyramid octave of every keypoint (cv::KeyPoint::octave), 0 where unknown
+    const uint8_t *oct2;    // [P][N]
     const int32_t *n1;      // [P]
     const int32_t *n2;      // [P]
     const double *Kinv;     // [P][9]  host-computed cofactor inverse (camera.cpp:16)
@@ -238,6 +240,7 @@ struct OrbDev {
     uint8_t *desc;         // [image][nfeatures][32]
     int32_t *n_kp;         // [image]
     float *kp_xy;          // optional [image][nfeatures][2] (the layout the matcher reads), may be null
+    uint8_t *kp_oct;       // optional [image][nfeatures] octave of every keypoint (refinement weights), may be null
 };
 hipError_t orb_prepare(int cand_cap);
 void launch_orb(const OrbDev &d, hipStream_t stream);

@@ -454,6 +454,8 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
                 d.kp_xy[2 * o] = k.x;
                 d.kp_xy[2 * o + 1] = k.y;
             }
+            if (d.kp_oct)
+                d.kp_oct[o] = (uint8_t)level;
         }
     }
 }

@@ -768,7 +768,9 @@ __global__ void refine_prep_kernel(RefineDev d, const double *cov2_0, const doub
 }
 
 // ImagePair::refine inputs (front-end/image-pair.cpp:176-209) of every pair, built from the batch's own results:
-// point j of pair p -> match point_idx[j] -> keypoints (trainIdx in the base frame, queryIdx in the pair frame)
+// point j of pair p -> match point_idx[j] -> keypoints (trainIdx in the base frame, queryIdx in the pair frame).
+// Observation covariance = VisualFeature::get_point_estimates (vision/visual-feature.cpp:192-207):
+// stddev = 2^octave * 0.5 px, i.e. information w_obs / 4^octave with w_obs = 1 / sigma_px^2 (exact scaling).
 __global__ void refine_gather_kernel(BatchDev b, double w_obs, double w_pt, int stride, int32_t *m, double *pose0,
                                      double *obs0, double *obs1, double *oinfo0, double *oinfo1, double *pts0, double *pinfo)
 {
@@ -788,8 +790,10 @@ __global__ void refine_gather_kernel(BatchDev b, double w_obs, double w_pt, int 
     obs0[2 * s + 1] = (double)b.kp1[2 * (sb + mt.trainIdx) + 1];
     obs1[2 * s] = (double)b.kp2[2 * (sb + mt.queryIdx)];
     obs1[2 * s + 1] = (double)b.kp2[2 * (sb + mt.queryIdx) + 1];
-    oinfo0[3 * s] = w_obs, oinfo0[3 * s + 1] = 0.0, oinfo0[3 * s + 2] = w_obs;
-    oinfo1[3 * s] = w_obs, oinfo1[3 * s + 1] = 0.0, oinfo1[3 * s + 2] = w_obs;
+    const double w0 = ldexp(w_obs, -2 * (int)b.oct1[sb + mt.trainIdx]);
+    const double w1 = ldexp(w_obs, -2 * (int)b.oct2[sb + mt.queryIdx]);
+    oinfo0[3 * s] = w0, oinfo0[3 * s + 1] = 0.0, oinfo0[3 * s + 2] = w0;
+    oinfo1[3 * s] = w1, oinfo1[3 * s + 1] = 0.0, oinfo1[3 * s + 2] = w1;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
         pts0[3 * s + k] = b.points[3 * (sb + j) + k];

@@ -1,0 +1,184 @@
+"""BASELINE.json configs at FULL size inside the GPU suite.
+
+configs[2]: 512 independent pairs x 2000 keypoints x 50 000 hypotheses in one resident batch -- size-independent
+properties over every pair, oracle parity on 16 sampled pairs (first, last, 14 random; the oracle needs ~0.5 s per pair
+and thread, so 16 pairs on the box's 16 threads finish in seconds).
+configs[4]: a 1000-frame sequence x 2000 keypoints, 50 000 two-view + 100 PnP hypotheses per frame -- properties over
+every pair / track, the trajectory fold against the oracle's fold, and full oracle parity on three 4-frame windows.
+The 8-GPU config (configs[3]) is these 512 pairs per rank: the rank-local part is what runs here; the gather is covered
+by tests/test_dist_gloo.py and tests/test_gather.py.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from mvslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads(fn, items, n=16):
+    out, err = [None] * len(items), []
+
+    def work(k0):
+        try:
+            for k in range(k0, len(items), n):
+                out[k] = fn(items[k])
+        except Exception as e:   # surface oracle-side failures in the main thread
+            err.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(min(n, len(items)))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    if err:
+        raise err[0]
+    return out
+
+
+def test_config3_batch512(ctx):
+    from mvslam_amd import capi
+
+    P, N, H, THR = 512, 2000, 50000, 1e-2
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=THR)
+    data = synth.make_batch(0, P, n_kp=N)
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+             data["global_index"])
+    b.run(prm)
+    b.sync()
+    out = b.download()
+    b.run(prm)                      # determinism of the whole batch (the pruned scoring drops hypotheses in a
+    b.sync()                        # timing-dependent order; the winners must not depend on it)
+    out2 = b.download(matches=False, mask=True, points=True)
+    b.close()
+    res = out["results"]
+    assert res.tobytes() == out2["results"].tobytes()
+    assert res["valid"].all() and (res["n_matches"] > 1200).all() and (res["n_points"] > 600).all()
+    Kinv = np.linalg.inv(synth.K_DEFAULT)
+    for i in range(P):
+        r = res[i]
+        M, n = int(r["n_matches"]), int(r["n_points"])
+        assert np.array_equal(out["mask"][i][:M], out2["mask"][i][:M])
+        assert out["points"][i][:n].tobytes() == out2["points"][i][:n].tobytes()
+        mt = out["matches"][i][:M]
+        key = mt["distance"].astype(np.int64) * 65536 + mt["queryIdx"]
+        assert (np.diff(key) > 0).all()                                          # sorted by (distance, queryIdx)
+        assert out["mask"][i][:M].sum() == r["n_inliers"] == r["best_count"]
+        idx = out["point_idx"][i][:n]
+        assert (np.diff(idx) > 0).all() and out["mask"][i][idx].all()            # ordered subset of the inliers
+        pts = out["points"][i][:n]
+        assert (pts[:, 2] > 0).all() and ((r["R1to2"] @ pts.T).T[:, 2] + r["t1to2"][2] > 0).all()   # cheirality
+        x1 = (Kinv @ np.c_[data["kp1"][i][mt["trainIdx"]].astype(float), np.ones(M)].T).T
+        x2 = (Kinv @ np.c_[data["kp2"][i][mt["queryIdx"]].astype(float), np.ones(M)].T).T
+        e = np.abs(np.einsum("ij,jk,ik->i", x2, r["F"], x1))
+        inl = out["mask"][i][:M].astype(bool)
+        assert (e[inl] < THR * (1 + 1e-9)).all() and (e[~inl] > THR * (1 - 1e-9)).all()
+        assert abs(np.linalg.norm(r["t1to2"]) - 1.0) < 1e-9 and np.abs(r["R"] @ r["R"].T - np.eye(3)).max() < 1e-9
+    # shard invariance: a pair gives the same record alone (fused small-launch path) as inside the batch
+    b1 = capi.Batch(ctx, 1, N, 32)
+    for i in (0, 257, 511):
+        sl = slice(i, i + 1)
+        b1.upload(0, data["desc1"][sl], data["kp1"][sl], data["n1"][sl], data["desc2"][sl], data["kp2"][sl],
+                  data["n2"][sl], data["K"][sl], data["global_index"][sl])
+        b1.run(prm)
+        b1.sync()
+        assert b1.download(matches=False, mask=False, points=False)["results"][0].tobytes() == res[i].tobytes()
+    b1.close()
+    # oracle parity on 16 sampled pairs
+    rng = np.random.default_rng(2)
+    sample = [0, P - 1] + sorted(rng.choice(np.arange(1, P - 1), size=14, replace=False).tolist())
+
+    def oracle(i):
+        return o.image_pair(data["desc1"][i], data["kp1"][i], data["desc2"][i], data["kp2"][i],
+                            data["K"][i].reshape(3, 3),
+                            o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(data["global_index"][i]), THR), 0.7, 10.0)
+
+    for i, ref in zip(sample, _threads(oracle, sample)):
+        r = res[i]
+        M, n = ref["n_matches"], ref["n_points"]
+        assert r["n_matches"] == M and out["matches"][i][:M].tobytes() == ref["matches"].tobytes()
+        assert ref["ok"] and r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"]
+        assert r["best_residual"] == ref["best_residual"]
+        assert np.array_equal(out["mask"][i][:M], ref["mask"])                    # inlier set: bit-exact
+        assert r["n_points"] == n and np.array_equal(out["point_idx"][i][:n], ref["point_idx"])
+        assert np.abs(out["points"][i][:n] - ref["points"]).max() <= 1e-12 * max(1.0, np.abs(ref["points"]).max())
+        assert np.abs(r["R"] - ref["R"]).max() <= 1e-12 and np.abs(r["t"] - ref["t"]).max() <= 1e-12
+
+
+def test_config5_sequence1000(ctx):
+    from mvslam_amd import capi
+    from test_sequence import oracle_sequence
+
+    F, N, H, HP = 1000, 2000, 50000, 100
+    prm = dict(H=H, seed=synth.SEED_BASE, thr=1e-2)
+    pprm = dict(H=HP, seed=7, err=2.0)
+    seq = synth.make_sequence(F, n_kp=N)
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    s.run(capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=prm["seed"], max_error_sq=prm["thr"]),
+          capi.default_pnp_params(num_hypotheses=HP, seed=pprm["seed"], reproj_error=pprm["err"]))
+    gp, gt, tr = s.download_pairs(), s.download_tracks(), s.download_trajectory()
+    s.close()
+    res, trk = gp["results"], gt["tracks"]
+    assert res["valid"].sum() >= F - 3 and trk["ok"].sum() >= F - 5
+    assert (res["n_matches"][res["valid"] == 1] > 300).all()
+    for k in range(F - 1):
+        r = res[k]
+        M, n = int(r["n_matches"]), int(r["n_points"])
+        assert gp["mask"][k][:M].sum() == r["n_inliers"]
+        idx = gp["point_idx"][k][:n]
+        assert (np.diff(idx) > 0).all() and gp["mask"][k][idx].all()
+        if r["valid"]:
+            assert (gp["points"][k][:n][:, 2] > 0).all() and abs(np.linalg.norm(r["t1to2"]) - 1.0) < 1e-9
+    for q in range(F - 2):
+        t = trk[q]
+        nc, ni = int(t["n_corr"]), int(t["n_inliers"])
+        assert 0 <= ni <= nc <= N
+        if t["ok"]:
+            ii = gt["inlier_idx"][q][:ni]
+            assert (np.diff(ii) > 0).all() and (ii < nc).all()
+            assert np.abs(t["R"] @ t["R"].T - np.eye(3)).max() < 1e-9
+    # the scale-propagation fold (visual-odometer.cpp:577-588) over all 1000 frames: the oracle's fold, same bits
+    want = o.seq_chain(res["R"], res["t"], res["valid"], trk["R"], trk["t"], trk["ok"])
+    for k in ("R", "t", "pair_scale", "track_scale"):
+        assert tr[k].tobytes() == want[k].tobytes(), k
+    # ground truth: the heading follows the synthetic yaw (0.005 rad per frame).  The translation SCALE is not asserted:
+    # at this config's 0.05 m baseline and 0.5 px noise the per-step scale ratio of a 3-point PnP pose is only good to
+    # tens of per cent (monocular scale drift; the reference's VO has it too and relies on BA, which is out of scope)
+    cam = [(R.T, -R.T @ t) for R, t in seq["poses"]]
+    rot_err = [float(np.abs(tr["R"][k] - cam[0][0].T @ cam[k][0]).max()) for k in (10, 100, 500, 999)]
+    print("config5 heading error at frames 10/100/500/999:", rot_err, "median |track_scale - 1|:",
+          float(np.median(np.abs(tr["track_scale"] - 1.0))))
+    assert rot_err[0] < 0.05 and rot_err[1] < 0.1
+    for k in range(F):
+        assert np.abs(tr["R"][k] @ tr["R"][k].T - np.eye(3)).max() < 1e-6
+    # full oracle parity on three 4-frame windows (start, middle, end)
+    wins = [0, F // 2 - 2, F - 4]
+
+    def oracle(k0):
+        sub = dict(desc=seq["desc"][k0:k0 + 4], kp=seq["kp"][k0:k0 + 4], n_kp=seq["n_kp"][k0:k0 + 4], K=seq["K"])
+        return oracle_sequence(sub, dict(H=H, seed=prm["seed"] + k0, thr=prm["thr"]),
+                               dict(H=HP, seed=pprm["seed"] + k0, err=pprm["err"]))
+
+    for k0, (pairs, tracks) in zip(wins, _threads(oracle, wins, n=3)):
+        for j, ref in enumerate(pairs):
+            k = k0 + j
+            r, M = res[k], ref["n_matches"]
+            assert r["n_matches"] == M and gp["matches"][k][:M].tobytes() == ref["matches"].tobytes()
+            assert bool(r["valid"]) == ref["ok"] and np.array_equal(gp["mask"][k][:M], ref["mask"])
+            if ref["ok"]:
+                n = ref["n_points"]
+                assert r["best_hyp"] == ref["best_hyp"] and np.array_equal(gp["point_idx"][k][:n], ref["point_idx"])
+                assert gp["points"][k][:n].tobytes() == ref["points"].tobytes()
+        for j, ref in enumerate(tracks):
+            q = k0 + j
+            t, nc = trk[q], len(ref["X"])
+            assert t["n_corr"] == nc and gt["corr_xyz"][q][:nc].tobytes() == ref["X"].tobytes()
+            assert gt["corr_uv"][q][:nc].tobytes() == ref["uv"].tobytes()
+            assert bool(t["ok"]) == ref["ok"] and t["best_hyp"] == ref["best_hyp"]
+            if ref["ok"]:
+                ni = len(ref["inliers"])
+                assert t["n_inliers"] == ni and np.array_equal(gt["inlier_idx"][q][:ni], ref["inliers"])
+                assert t["R"].tobytes() == ref["R"].tobytes() and t["t"].tobytes() == ref["t"].tobytes()

@@ -246,18 +246,28 @@ def test_gpu_extract_against_golden_and_argument_errors(ctx):
     assert int(again["n"][0]) == n
 
 
+# (hypotheses, sampler, max_error_sq [0 = the reference formula 5e-2 / K00 / K11, sfm-solve.cpp:311], max_dist)
+TSUKUBA_PARAMS = {
+    "build": (2000, 1, 1e-3, 50.0),                 # the build's sampler, a wide matcher gate
+    "reference-defaults": (2000, 1, 0.0, 10.0),     # ImagePair::get_default_params (image-pair.cpp:22-23) + sfm-solve.cpp:311
+    "reference-as-shipped": (1, 0, 0.0, 10.0),      # ... with the reference's single identity-sample iteration (sfm-solve.cpp:67)
+}
+
+
 @pytest.mark.gpu
-def test_gpu_images_to_poses_tsukuba_sequence(ctx):
+@pytest.mark.parametrize("which", list(TSUKUBA_PARAMS))
+def test_gpu_images_to_poses_tsukuba_sequence(ctx, which):
     """BASELINE configs[0] ('plumbing'): the reference's tsukuba frames through extraction -> matching -> two-view
-    RANSAC -> refinement -> PnP, everything on the device; frames 1, 2 must give (I, (1, 0, 0)) as
-    test/test-image-pair.cpp:38-45 expects."""
+    RANSAC -> refinement -> PnP, everything on the device; frames 1, 2 must give (I, (1, 0, 0)) within 1e-3 AFTER
+    refinement, as test/test-image-pair.cpp:13,38-45 expects -- with the reference's default parameters too."""
     from mvslam_amd import capi
 
+    H, sampler, thr, max_dist = TSUKUBA_PARAMS[which]
     imgs, K = tsukuba()
     F, N = len(imgs), 512
     s = capi.Sequence(ctx, F, N, 32)
     s.upload_images(0, imgs, K, capi.default_orb_params())
-    prm = capi.default_params(num_hypotheses=2000, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-3, max_dist=50.0)
+    prm = capi.default_params(num_hypotheses=H, sampler=sampler, seed=1, max_error_sq=thr, max_dist=max_dist)
     pprm = capi.default_pnp_params(num_hypotheses=100, seed=7, reproj_error=1.0)
     s.run(prm, pprm)      # run + sync
     pairs = s.download_pairs()
@@ -266,9 +276,9 @@ def test_gpu_images_to_poses_tsukuba_sequence(ctx):
     refined = s.download_refined()["refined"]
     s.close()
     assert np.all(refined["ok"] == 1)
-    for p in range(F - 1):            # test-image-pair.cpp:38-45 asserts this AFTER refinement
-        assert np.abs(refined["t"][p] - np.array([1.0, 0, 0])).max() < 1e-2, (p, refined["t"][p])
-        assert np.abs(refined["R"][p] - np.eye(3)).max() < 1e-2
+    for p in range(F - 1):            # test-image-pair.cpp:13,38-45 asserts this AFTER refinement, at 1e-3
+        assert np.abs(refined["t"][p] - np.array([1.0, 0, 0])).max() < 1e-3, (p, refined["t"][p])
+        assert np.abs(refined["R"][p] - np.eye(3)).max() < 1e-3
     res = pairs["results"]
     assert np.all(res["valid"] == 1)
     # frames are 1 px apart horizontally in a rectified rig: every consecutive pair is a pure x translation
@@ -281,7 +291,37 @@ def test_gpu_images_to_poses_tsukuba_sequence(ctx):
         a, b = ex[p], ex[p + 1]
         kp1 = np.stack([a["kp"]["x"], a["kp"]["y"]], 1).astype(np.float32)
         kp2 = np.stack([b["kp"]["x"], b["kp"]["y"]], 1).astype(np.float32)
-        want = o.image_pair(a["desc"], kp1, b["desc"], kp2, K, o.make_params(2000, o.SAMPLER_PHILOX, 1 + p, 1e-3), 0.7, 50.0)
+        want = o.image_pair(a["desc"], kp1, b["desc"], kp2, K, o.make_params(H, sampler, 1 + p, thr), 0.7, max_dist)
         assert want["valid"] and want["n_matches"] == res["n_matches"][p] and want["n_points"] == res["n_points"][p]
         assert want["best_hyp"] == res["best_hyp"][p]
-    assert np.all(tracks["tracks"]["ok"] == 1)
+    if which == "build":
+        assert np.all(tracks["tracks"]["ok"] == 1)
+
+
+@pytest.mark.gpu
+def test_gpu_tsukuba_visual_odometer_fixture(ctx):
+    """The reference's own VO fixture (test/test-visual-odometer.cpp:60-107): the five tsukuba frames, pose of frame i
+    = (I, (i, 0, 0)) within i * 1e-3 (check_similar_SE3: component-wise on the se3 logarithm).  Pins row f2's
+    scale-propagation fold (visual-odometer.cpp:577-588) with reference-held data, on the device and in the oracle."""
+    from mvslam_amd import capi
+
+    imgs, K = tsukuba()
+    F, N = len(imgs), 512
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload_images(0, imgs, K, capi.default_orb_params())
+    prm = capi.default_params(num_hypotheses=2000, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-3, max_dist=50.0)
+    # pnp_solve with the reference's own values: 100 iterations, reprojectionError 0.05 px (pnp-solve.cpp:47-49) -- at
+    # that gate only the (exact, integer-disparity) level-0 keypoints of this rendered sequence are inliers
+    pprm = capi.default_pnp_params(num_hypotheses=100, seed=7, reproj_error=0.05)
+    s.run(prm, pprm)
+    gp, gt, tr = s.download_pairs(), s.download_tracks(), s.download_trajectory()
+    s.close()
+    res, trk = gp["results"], gt["tracks"]
+    assert np.all(res["valid"] == 1) and np.all(trk["ok"] == 1)
+    want = o.seq_chain(res["R"], res["t"], res["valid"], trk["R"], trk["t"], trk["ok"])      # the oracle's fold
+    for k in ("R", "t", "pair_scale", "track_scale"):
+        assert tr[k].tobytes() == want[k].tobytes(), k
+    for traj in (tr, want):
+        for i in range(1, F):
+            xi = o.se3_ln(traj["R"][i], traj["t"][i])
+            assert np.abs(xi - np.array([i, 0, 0, 0, 0, 0.0])).max() <= i * 1e-3, (i, xi)

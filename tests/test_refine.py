@@ -419,14 +419,24 @@ def test_gpu_refine_argument_errors(ctx):
 
 @pytest.mark.gpu
 def test_gpu_batch_refine_matches_oracle_and_improves_reprojection(ctx):
-    """ImagePair::refine on the device for a whole batch, from the batch's own results."""
+    """ImagePair::refine on the device for a whole batch, from the batch's own results; every keypoint weighted by
+    its pyramid octave as VisualFeature::get_point_estimates does (visual-feature.cpp:192-207: stddev = 2^octave / 2)."""
     from mvslam_amd import capi, synth
 
     n_pairs, n_kp = 4, 600
     data = synth.make_batch(0, n_pairs, n_kp=n_kp)
+    rng = np.random.default_rng(5)
+    oct1 = rng.integers(0, 4, size=(n_pairs, n_kp)).astype(np.uint8)
+    oct2 = rng.integers(0, 4, size=(n_pairs, n_kp)).astype(np.uint8)
+    oct2[3] = 0                     # one pair with the default everywhere in the second image
     b = capi.Batch(ctx, n_pairs, n_kp)
     b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
              data["global_index"])
+    b.upload_octaves(0, oct1, None)
+    b.upload_octaves(0, None, oct2[:3])      # pair 3's second image keeps the octave-0 default
+    with pytest.raises(capi.MvsError) as e:
+        b.upload_octaves(0, np.full((1, n_kp), 31, np.uint8), None)
+    assert e.value.status == capi.MVS_ERR_INVALID_ARG
     prm = capi.default_params(num_hypotheses=2048, sampler=capi.SAMPLER_PHILOX, seed=11, max_error_sq=1e-2)
     b.run(prm)
     b.refine(sigma_px=0.5)
@@ -445,8 +455,11 @@ def test_gpu_batch_refine_matches_oracle_and_improves_reprojection(ctx):
         mt = out["matches"][p][out["point_idx"][p][:n]]
         p1 = data["kp1"][p][mt["trainIdx"]].astype(np.float64)
         p2 = data["kp2"][p][mt["queryIdx"]].astype(np.float64)
-        cov = np.tile((np.eye(2) * 0.25).reshape(4), (n, 1))
-        want = o.sfm_refine(p1, cov, p2, cov, K, r["R"], r["t"], out["points"][p][:n])
+        s1 = 0.5 * 2.0 ** oct1[p][mt["trainIdx"]].astype(np.float64)
+        s2 = 0.5 * 2.0 ** oct2[p][mt["queryIdx"]].astype(np.float64)
+        cov1 = (s1 * s1)[:, None] * np.eye(2).reshape(1, 4)
+        cov2 = (s2 * s2)[:, None] * np.eye(2).reshape(1, 4)
+        want = o.sfm_refine(p1, cov1, p2, cov2, K, r["R"], r["t"], out["points"][p][:n])
         got = ref["refined"][p]
         assert got["ok"] == 1 and want["ok"]
         assert abs(got["error"] - want["error"]) <= 1e-9 * want["error"]
@@ -454,10 +467,10 @@ def test_gpu_batch_refine_matches_oracle_and_improves_reprojection(ctx):
         assert np.abs(ref["points"][p][:n] - want["points"]).max() < 1e-8
         _close(got["pose_cov"], want["pose_cov"], 1e-6, "pose_cov")
         _close(ref["point_cov"][p][:n], want["point_cov"], 1e-6, "point_cov")
-        # reprojection RMS over both images does not get worse
+        # whitened reprojection RMS over both images does not get worse
         def rms(R, t, X):
-            e1 = proj(K, np.eye(3), np.zeros(3), X) - p1
-            e2 = proj(K, R, t, X) - p2
+            e1 = (proj(K, np.eye(3), np.zeros(3), X) - p1) / s1[:, None]
+            e2 = (proj(K, R, t, X) - p2) / s2[:, None]
             return np.sqrt(np.mean(np.concatenate([e1, e2]) ** 2))
         assert rms(got["R"], got["t"], ref["points"][p][:n]) <= rms(r["R"], r["t"], out["points"][p][:n]) + 1e-12
         n_checked += 1

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from mvslam_amd import capi, synth
 import oracle_lib as o
+import test_gpu_parity as TG
 import test_pnp as TP
 import test_refine as TR
 import test_orb as TO
@@ -19,7 +20,7 @@ args = ap.parse_args()
 rng = np.random.default_rng(2026)
 ctx = capi.Context(0)
 bad = []
-cnt = dict(pairs=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0)
+cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0)
 t0 = time.time()
 
 # 1. whole image pairs through the batch API: ragged keypoint counts, varying noise / outliers / hypothesis counts
@@ -41,7 +42,22 @@ prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=99
 b.run(prm)
 b.sync()
 out = b.download()
+# 1b. the same pairs at the reference threshold 5e-2 / K00 / K11 (sfm-solve.cpp:311): tiny inlier sets, MANY hypotheses
+# tie at the best count, so the residual tie-break of ransac_select_kernel (both its paths) decides the winner
+prm0 = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=5)
+b.run(prm0)
+b.sync()
+out0 = b.download(points=False)
 b.close()
+for i, p in enumerate(data):
+    want = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(H, o.SAMPLER_PHILOX, 5 + i, 0.0), 0.7, 10.0)
+    r = out0["results"][i]
+    M = int(r["n_matches"])
+    ok = (bool(r["valid"]) == want["valid"] and int(r["best_hyp"]) == want["best_hyp"] and int(r["best_count"]) == want["best_count"]
+          and float(r["best_residual"]) == want["best_residual"] and np.array_equal(out0["mask"][i][:M], want["mask"]))
+    cnt["pairs_ref_threshold"] += 1
+    if not ok:
+        bad.append(("pair_ref_threshold", i))
 for i, p in enumerate(data):
     n = int(sizes[i])
     want = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(H, o.SAMPLER_PHILOX, 99 + i, 1e-2), 0.7, 10.0)
@@ -75,6 +91,22 @@ for i in range(args.cases // 4):
     cnt["match"] += 1
     if not np.array_equal(got, want.astype(capi.MATCH_DTYPE)):
         bad.append(("match", i))
+
+# 2b. the RANSAC stage alone with per-hypothesis tables: every count and residual sum, winner, mask, F -- bit for bit
+for i in range(max(args.cases, 200)):
+    m = int(rng.integers(8, 1800))
+    Hh = int(rng.choice([1, 17, 256, 700, 2049]))
+    thr = float(rng.choice([1e-7, 1e-4, 1e-3, 1e-2]))
+    p1, p2 = TG._scene(7000 + i, m, float(rng.choice([0.0, 1e-4, 1e-3])), outliers=float(rng.choice([0.0, 0.3, 0.7])))
+    seed = int(rng.integers(0, 1 << 40))
+    want = o.ransac_fundamental(p1, p2, thr, Hh, o.SAMPLER_PHILOX, seed=seed, per_hyp=True)
+    got = ctx.ransac_fundamental(p1, p2, thr, Hh, capi.SAMPLER_PHILOX, seed=seed, per_hyp=True)
+    cnt["ransac"] += 1
+    if not (np.array_equal(got["count"], want["count"]) and got["residual"].tobytes() == want["residual"].tobytes()
+            and got["best_hyp"] == want["best_hyp"] and got["best_count"] == want["best_count"]
+            and got["best_residual"] == want["best_residual"] and np.array_equal(got["mask"], want["mask"])
+            and got["F"].tobytes() == want["F"].tobytes() and got["ok"] == want["ok"]):
+        bad.append(("ransac", i, m, Hh, thr))
 
 # 3. pnp_solve
 for i in range(args.cases // 4):
