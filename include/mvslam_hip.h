@@ -113,6 +113,17 @@ mvs_status mvs_two_view(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, 
                         const mvs_params *params, double R[9], double t[3], double *points_xyz,
                         int64_t *point_idx, int *n_points, uint8_t *inlier_mask, mvs_pair_result *result);
 
+/* ImagePair::ImagePair + ImagePair::reconstruct (front-end/image-pair.cpp:30-71,116-174) of ONE pair in a single device
+ * pass: match(base = train, pair = query) -> gather + normalise -> sfm_solve, one upload, one synchronisation, one
+ * download (the match_visual_features + sfm_solve call pair costs two round trips).  base_kp / pair_kp: n x (x, y)
+ * float = cv::KeyPoint::pt.  Outputs (any but `result` may be NULL): matches[<= n_pair] in the canonical order,
+ * inlier_mask[n_matches], points_xyz[n_points x 3], point_idx[n_points] (index into matches).  Returns MVS_NO_MODEL when
+ * the reference's constructor leaves `valid == false`; result->n_matches etc. are filled either way. */
+mvs_status mvs_image_pair(mvs_ctx *ctx, const uint8_t *base_desc, const float *base_kp, int n_base,
+                          const uint8_t *pair_desc, const float *pair_kp, int n_pair, int desc_bytes, const double K[9],
+                          const mvs_params *params, mvs_pair_result *result, mvs_match *matches, uint8_t *inlier_mask,
+                          double *points_xyz, int64_t *point_idx);
+
 /* sfm_triangulate(p1, p2, K, pose1, pose2, points, point_indexes) (sfm-solve.cpp:370-394, decl sfm.hpp:47-53).
  * R1to2 / t1to2 = (pose2^-1 * pose1), composed by the caller-side shim exactly as the reference does. */
 mvs_status mvs_triangulate(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, int m, const double K[9],
@@ -171,6 +182,17 @@ mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *b
                             const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
                             const int32_t *n_pair, const double *K, const int64_t *global_index);
 
+/* Asynchronous form: enqueues the copies on the ctx stream and returns.  The host buffers must stay valid and unchanged
+ * until mvs_batch_sync; with buffers from mvs_host_alloc (pinned) the copies are true DMA transfers that overlap the
+ * kernels of another batch / ctx (double buffering: upload batch k+1 while batch k runs).  K^-1 and the default indices
+ * are staged in pinned memory owned by the batch. */
+mvs_status mvs_batch_upload_async(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
+                                  const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
+                                  const int32_t *n_pair, const double *K, const int64_t *global_index);
+/* pinned (page-locked) host memory for the asynchronous transfers; any entry point accepts pageable memory too */
+mvs_status mvs_host_alloc(size_t bytes, void **out);
+void mvs_host_free(void *p);
+
 /* Enqueue the whole pipeline for pairs [0, n_active) on the ctx stream (asynchronous). */
 mvs_status mvs_batch_run(mvs_batch *b, const mvs_params *params, int n_active);
 mvs_status mvs_batch_sync(mvs_batch *b);
@@ -184,9 +206,18 @@ mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, 
                           float *ms_total, float *ms_kernel);
 
 /* Results (host).  Any pointer may be NULL.  results: count;  matches: count x max_kp;  mask: count x max_kp;
- * points: count x max_kp x 3;  point_idx: count x max_kp. */
+ * points: count x max_kp x 3;  point_idx: count x max_kp.  Valid rows of pair p: matches / mask [0, results[p].n_matches),
+ * points / point_idx [0, results[p].n_points); every row past them is ZERO (the kernels clear the tails on every run, so
+ * the whole-capacity copy is deterministic). */
 mvs_status mvs_batch_download(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
                               uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx);
+
+/* Asynchronous form of mvs_batch_download: enqueues the copies after whatever is already on the ctx stream (no sync is
+ * needed between mvs_batch_run and this call) and returns; the data is valid after mvs_batch_sync.  point_idx32 is the
+ * device's native int32 index (the synchronous form widens to the reference's size_t on the host).  Row ranges as for
+ * mvs_batch_download; rows past them are zero. */
+mvs_status mvs_batch_download_async(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                                    uint8_t *inlier_mask, double *points_xyz, int32_t *point_idx32);
 
 /* Work statistics of the last run (for the roofline's algorithmic flop count): executed 9x9 Jacobi rotations,
  * visited 9x9 pairs, hypotheses, hypothesis x point evaluations, summed over pairs [0, n_active).

@@ -12,6 +12,11 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmvslam_hip.so")
+# diagnostics build with the mvs_debug_* hooks (make -C mvslam_amd/csrc): never loaded by this package unless a tool asks
+# for it explicitly with MVS_USE_DEBUG_LIB=1 (tools/ab_ransac.py) -- tests load it side by side through ctypes
+DBG_LIB_PATH = os.path.join(_PKG, "lib", "libmvslam_hip_dbg.so")
+if os.environ.get("MVS_USE_DEBUG_LIB") == "1":
+    LIB_PATH = DBG_LIB_PATH
 
 MVS_OK = 0
 MVS_NO_MODEL = 1
@@ -112,6 +117,7 @@ EXPORTS = [
     "mvs_refine_params_default", "mvs_sfm_refine", "mvs_pnp_refine", "mvs_batch_refine", "mvs_batch_download_refined",
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
     "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
+    "mvs_batch_upload_async", "mvs_batch_download_async", "mvs_host_alloc", "mvs_host_free", "mvs_image_pair",
 ]
 
 
@@ -192,6 +198,30 @@ def _f64(a, shape=None):
     return a if shape is None else a.reshape(shape)
 
 
+def pinned_empty(shape, dtype):
+    """numpy array over pinned (page-locked) host memory from mvs_host_alloc: the asynchronous transfers of
+    Batch.upload_async / download_async are true DMA copies on such buffers.  Free with pinned_free()."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    st = lib().mvs_host_alloc(C.c_size_t(max(n, 1)), C.byref(p))
+    if st != MVS_OK:
+        raise MvsError(st, "mvs_host_alloc")
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _PINNED[a.ctypes.data] = p
+    return a
+
+
+_PINNED = {}
+
+
+def pinned_free(a):
+    p = _PINNED.pop(a.ctypes.data, None)
+    if p is not None:
+        lib().mvs_host_free(p)
+
+
 class Context:
     """One mvs_ctx: one HIP stream on one GPU."""
 
@@ -238,6 +268,30 @@ class Context:
             C.c_double(max_dist), out.ctypes.data_as(C.c_void_p), C.byref(n))
         self._check(st, "mvs_match_hamming")
         return out[:n.value].copy()
+
+    # ImagePair::ImagePair + reconstruct of one pair in one device pass
+    def image_pair(self, base_desc, base_kp, pair_desc, pair_kp, K, params):
+        base_desc = np.ascontiguousarray(base_desc, dtype=np.uint8)
+        pair_desc = np.ascontiguousarray(pair_desc, dtype=np.uint8)
+        base_kp = np.ascontiguousarray(base_kp, dtype=np.float32).reshape(-1, 2)
+        pair_kp = np.ascontiguousarray(pair_kp, dtype=np.float32).reshape(-1, 2)
+        n1, n2 = len(base_desc), len(pair_desc)
+        res = PairResult()
+        mt = np.zeros(max(n2, 1), dtype=MATCH_DTYPE)
+        mask = np.zeros(max(n2, 1), dtype=np.uint8)
+        pts = np.zeros((max(n2, 1), 3))
+        idx = np.zeros(max(n2, 1), dtype=np.int64)
+        st = lib().mvs_image_pair(self._h, _ptr(base_desc, C.c_uint8), _ptr(base_kp, C.c_float), C.c_int(n1),
+                                  _ptr(pair_desc, C.c_uint8), _ptr(pair_kp, C.c_float), C.c_int(n2),
+                                  C.c_int(int(base_desc.shape[1])), _ptr(_f64(K, (9,)), C.c_double), C.byref(params),
+                                  C.byref(res), mt.ctypes.data_as(C.c_void_p), _ptr(mask, C.c_uint8),
+                                  _ptr(pts, C.c_double), _ptr(idx, C.c_int64))
+        self._check(st, "mvs_image_pair", allow_no_model=True)
+        r = np.frombuffer(bytes(res), dtype=RESULT_DTYPE)[0]
+        out = self._unpack(res, mask, pts, idx, int(r["n_matches"]))
+        out["matches"] = mt[:int(r["n_matches"])].copy()
+        out["ok"] = st == MVS_OK
+        return out
 
     @staticmethod
     def _unpack(res, mask, pts, idx, m):
@@ -465,6 +519,28 @@ class Batch:
                                     _ptr(pair_kp, C.c_float), _ptr(n_pair, C.c_int32), _ptr(K, C.c_double),
                                     _ptr(gi, C.c_int64))
         self.ctx._check(st, "mvs_batch_upload")
+
+    def upload_async(self, first, base_desc, base_kp, n_base, pair_desc, pair_kp, n_pair, K, global_index):
+        """enqueue the upload; the arrays (ideally pinned_empty() ones, exactly typed and contiguous: they are NOT
+        copied) must stay alive and unchanged until sync()"""
+        count = len(n_base)
+        for a, t in ((base_desc, np.uint8), (pair_desc, np.uint8), (base_kp, np.float32), (pair_kp, np.float32),
+                     (n_base, np.int32), (n_pair, np.int32), (K, np.float64), (global_index, np.int64)):
+            assert a.dtype == t and a.flags["C_CONTIGUOUS"]
+        assert K.size == 9 * count
+        st = lib().mvs_batch_upload_async(self._h, C.c_int(first), C.c_int(count), _ptr(base_desc, C.c_uint8),
+                                          _ptr(base_kp, C.c_float), _ptr(n_base, C.c_int32), _ptr(pair_desc, C.c_uint8),
+                                          _ptr(pair_kp, C.c_float), _ptr(n_pair, C.c_int32), _ptr(K, C.c_double),
+                                          _ptr(global_index, C.c_int64))
+        self.ctx._check(st, "mvs_batch_upload_async")
+
+    def download_async(self, first, count, results, matches=None, mask=None, points=None, point_idx32=None):
+        """enqueue the download into caller-owned (ideally pinned) arrays; valid after sync()"""
+        st = lib().mvs_batch_download_async(
+            self._h, C.c_int(first), C.c_int(count), results.ctypes.data_as(C.c_void_p),
+            None if matches is None else matches.ctypes.data_as(C.c_void_p), _ptr(mask, C.c_uint8),
+            _ptr(points, C.c_double), _ptr(point_idx32, C.c_int32))
+        self.ctx._check(st, "mvs_batch_download_async")
 
     def run(self, params, n_active=None):
         st = lib().mvs_batch_run(self._h, C.byref(params), C.c_int(n_active or self.n_pairs))

@@ -904,22 +904,40 @@ public:
           m_base(&base_frame_), m_pair(&pair_frame_), m_K(K)
     {
         assert(base_frame_.id != pair_frame_.id);
-        const auto matches = VisualFeature::match_visual_features(base_frame_.visual_feature, pair_frame_.visual_feature,
-                                                                  params.max_match_inlier_distance);
-        const auto bp = base_frame_.visual_feature.get_image_points(), pp = pair_frame_.visual_feature.get_image_points();
-        std::vector<ImagePoint> base_points, pair_points;
-        for (const auto &m : matches) {  // image-pair.cpp:123-140
-            base_points.push_back(bp[m.trainIdx]);
-            pair_points.push_back(pp[m.queryIdx]);
-        }
-        std::vector<Point3> points;
-        std::vector<size_t> idx;
-        valid = matches.size() >= 1 && sfm_solve(base_points, pair_points, K, T_pair_to_base, points, idx);
+        // match(base = train, pair = query) -> gather -> sfm_solve (image-pair.cpp:57-65,116-174) as ONE device pass
+        // (mvs_image_pair): same results as the two calls, one upload / synchronisation / download instead of two
+        const VisualFeature &vb = base_frame_.visual_feature, &vp = pair_frame_.visual_feature;
+        assert(vb.valid() && vp.valid());
+        auto pack = [](const VisualFeature &vf) {
+            std::vector<float> xy(2 * vf.size());
+            for (size_t i = 0; i < vf.size(); ++i) {
+                xy[2 * i] = vf.get_keypoints()[i].pt.x;
+                xy[2 * i + 1] = vf.get_keypoints()[i].pt.y;
+            }
+            return xy;
+        };
+        const std::vector<float> kb = pack(vb), kq = pack(vp);
+        const int nq = (int)vp.size();
+        mvs_params prm = make_params_();
+        prm.ratio = 0.7;                                   // visual-feature.cpp:23
+        prm.max_dist = params.max_match_inlier_distance;
+        std::vector<DMatch> matches(nq);
+        std::vector<double> pts(3 * (size_t)nq);
+        std::vector<int64_t> idx(nq);
+        mvs_pair_result res;
+        const mvs_status st = mvs_image_pair(hip::context(), vb.get_descriptors().data.data(), kb.data(), (int)vb.size(),
+                                             vp.get_descriptors().data.data(), kq.data(), nq, vb.get_descriptors().cols,
+                                             K.data(), &prm, &res, matches.data(), nullptr,
+                                             pts.data(), idx.data());
+        hip::check(st, "ImagePair");
+        valid = st == MVS_OK;
         if (valid) {
-            match_inlier_count = (uint32_t)idx.size();
-            for (size_t k = 0; k < idx.size(); ++k) {  // points[k] belongs to match idx[k] (the reference indexes
-                const auto &m = matches[idx[k]];        // points[idx], image-pair.cpp:164 -- SURVEY Q12, not copied)
-                matched_points.push_back(MatchedPoint{points[k], (size_t)m.trainIdx, (size_t)m.queryIdx});
+            T_pair_to_base = se3_from_arrays_(res.R, res.t);
+            match_inlier_count = (uint32_t)res.n_points;
+            for (int k = 0; k < res.n_points; ++k) {    // point k belongs to match idx[k] (the reference indexes
+                const auto &m = matches[idx[k]];          // points[idx], image-pair.cpp:164 -- SURVEY Q12, not copied)
+                matched_points.push_back(MatchedPoint{Point3(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]),
+                                                      (size_t)m.trainIdx, (size_t)m.queryIdx});
                 match_inlier_ssd += (uint32_t)sqr(m.distance);
             }
             m_state = State::RECONSTRUCTED;

@@ -33,6 +33,10 @@ struct mvs_ctx {
     hipGraphExec_t orb_graph = nullptr;
     OrbDev orb_graph_key{};
     bool orb_graph_valid = false;
+    // pinned staging arena of the single-shot entry points: small parameters and results travel through it with
+    // hipMemcpyAsync on the ctx stream (no synchronous pageable copies, no sync "so that a stack temporary may die")
+    char *h_pin = nullptr;
+    size_t h_pin_cap = 0, h_pin_off = 0;
 };
 
 struct mvs_seq;
@@ -47,6 +51,7 @@ struct mvs_batch {
     hipEvent_t ev[8]{};
     RefineDev refine{};     // allocated by the first mvs_batch_refine
     bool refine_ready = false, refine_ran = false;
+    char *h_pin = nullptr;  // pinned staging of the per-pair parameters derived on the host (K^-1, default indices)
 };
 
 struct mvs_seq {
@@ -68,6 +73,57 @@ struct mvs_seq {
             return MVS_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)
+
+// ---- pinned staging arena -------------------------------------------------------------------------------------------
+// pin_begin() opens a call: the arena is made large enough for everything the call will stage (growing it waits for
+// the stream first, nothing of an earlier call may still be in flight) and the cursor rewinds.  pin_put() copies a host
+// block in and returns its pinned address, pin_get() reserves room for a device -> host copy.
+static mvs_status pin_begin(mvs_ctx *ctx, size_t bytes)
+{
+    bytes += 4096;
+    if (ctx->h_pin_cap < bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pin)
+            (void)hipHostFree(ctx->h_pin);
+        ctx->h_pin = nullptr;
+        ctx->h_pin_cap = 0;
+        const size_t cap = std::max<size_t>(bytes * 2, size_t(1) << 20);
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_pin, cap, hipHostMallocDefault));
+        ctx->h_pin_cap = cap;
+    }
+    ctx->h_pin_off = 0;
+    return MVS_OK;
+}
+static void *pin_get(mvs_ctx *ctx, size_t bytes)
+{
+    const size_t off = (ctx->h_pin_off + 63) & ~size_t(63);
+    if (off + bytes > ctx->h_pin_cap)
+        return nullptr;   // pin_begin() was given too small a figure: a bug, reported as MVS_ERR_HIP by the callers
+    ctx->h_pin_off = off + bytes;
+    return ctx->h_pin + off;
+}
+static void *pin_put(mvs_ctx *ctx, const void *src, size_t bytes)
+{
+    void *p = pin_get(ctx, bytes);
+    if (p && bytes)
+        std::memcpy(p, src, bytes);
+    return p;
+}
+#define PIN_TRY(ctx_, ptr_)                                   \
+    do {                                                      \
+        if (!(ptr_)) {                                        \
+            (ctx_)->err = "pinned staging arena exhausted";   \
+            return MVS_ERR_HIP;                               \
+        }                                                     \
+    } while (0)
+// host block -> pinned arena -> device, asynchronous
+static mvs_status up_async(mvs_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    void *p = pin_put(ctx, src, bytes);
+    PIN_TRY(ctx, p);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MVS_OK;
+}
 
 static RunParams to_run(const mvs_params &p)
 {
@@ -152,6 +208,10 @@ extern "C" {
 
 int mvs_abi_version(void) { return MVS_ABI_VERSION; }
 
+#ifdef MVS_DEBUG_HOOKS
+// Diagnostics, compiled ONLY into libmvslam_hip_dbg.so (make dbg; tests/ and tools/ load that library explicitly).  The
+// product library has neither symbol: a process-global kernel-variant switch is not something a caller of the
+// reference's interface should be able to reach.
 // diagnostics only (not in the public header): bitwise comparison of the unscaled sqrt / div device sequences with
 // the compiler's IEEE ones on host-supplied operands.  counts[4] = {sqrt mismatches, div mismatches, sqrt checked,
 // div checked}
@@ -165,12 +225,12 @@ int mvs_debug_fastmath_check(mvs_ctx *ctx, const double *x, const double *y, int
     HIP_TRY(ctx, hipMalloc((void **)&dx, (size_t)n * 8));
     HIP_TRY(ctx, hipMalloc((void **)&dy, (size_t)n * 8));
     HIP_TRY(ctx, hipMalloc((void **)&dc, 32));
-    HIP_TRY(ctx, hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(dy, y, (size_t)n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(dc, 0, 32));
+    HIP_TRY(ctx, hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dy, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dc, 0, 32, ctx->stream));
     launch_fastmath_check(dx, dy, n, dc, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(counts, dc, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(counts, dc, 32, hipMemcpyDeviceToHost));
     (void)hipFree(dx);
     (void)hipFree(dy);
     (void)hipFree(dc);
@@ -184,6 +244,8 @@ int mvs_debug_set_ransac_variant(int v)
     set_ransac_variant(v);
     return old;
 }
+
+#endif  // MVS_DEBUG_HOOKS
 
 const char *mvs_status_str(mvs_status s)
 {
@@ -268,6 +330,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->orb_graph) (void)hipGraphExecDestroy(ctx->orb_graph);
     if (ctx->d_orb) (void)hipFree(ctx->d_orb);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -398,12 +461,14 @@ void mvs_batch_destroy(mvs_batch *b)
     for (auto &e : b->ev)
         if (e)
             (void)hipEventDestroy(e);
+    if (b->h_pin)
+        (void)hipHostFree(b->h_pin);
     delete b;
 }
 
-mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
-                            const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
-                            const int32_t *n_pair, const double *K, const int64_t *global_index)
+static mvs_status batch_upload_impl(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
+                                    const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
+                                    const int32_t *n_pair, const double *K, const int64_t *global_index, bool sync)
 {
     if (!b || first < 0 || count < 1 || first + count > b->d.n_pairs)
         return MVS_ERR_INVALID_ARG;
@@ -420,21 +485,27 @@ mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *b
         for (int i = 0; i < count; ++i)
             if (n_pair[i] < 0 || n_pair[i] > (int)N)
                 return MVS_ERR_CAPACITY;
-    std::vector<double> kinv;
+    // host-derived per-pair parameters live in pinned memory owned by the batch (slot = pair index), so that the
+    // asynchronous form needs no temporaries that outlive the call
+    if (!b->h_pin)
+        HIP_TRY(ctx, hipHostMalloc((void **)&b->h_pin, (size_t)d.n_pairs * (9 * sizeof(double) + sizeof(int64_t)),
+                                   hipHostMallocDefault));
+    double *kinv = reinterpret_cast<double *>(b->h_pin) + (size_t)first * 9;
+    int64_t *gi = reinterpret_cast<int64_t *>(b->h_pin + (size_t)d.n_pairs * 9 * sizeof(double)) + first;
     if (K) {
-        kinv.resize((size_t)count * 9);
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < count; ++i)
             if (!affine_K(K + 9 * i))
                 return MVS_ERR_BAD_INTRINSICS;
-            mat3_inverse(K + 9 * i, kinv.data() + 9 * i);
-        }
+        HIP_TRY(ctx, hipStreamSynchronize(s));   // an earlier asynchronous upload may still be reading the slots
+        for (int i = 0; i < count; ++i)
+            mat3_inverse(K + 9 * i, kinv + 9 * i);
     }
-    std::vector<int64_t> gi;
     if (!global_index) {
-        gi.resize(count);
+        if (!K)
+            HIP_TRY(ctx, hipStreamSynchronize(s));
         for (int i = 0; i < count; ++i)
             gi[i] = first + i;
-        global_index = gi.data();
+        global_index = gi;
     }
     const size_t off = first;
 #define UP(dst, src, bytes_per_pair)                                                                                   \
@@ -448,12 +519,41 @@ mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *b
     UP(const_cast<int32_t *>(d.n1), n_base, sizeof(int32_t));
     UP(const_cast<int32_t *>(d.n2), n_pair, sizeof(int32_t));
     UP(const_cast<double *>(d.K), K, 9 * sizeof(double));
-    const double *kinv_p = K ? kinv.data() : nullptr;
+    const double *kinv_p = K ? kinv : nullptr;
     UP(const_cast<double *>(d.Kinv), kinv_p, 9 * sizeof(double));
     UP(const_cast<int64_t *>(d.gidx), global_index, sizeof(int64_t));
 #undef UP
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (sync)
+        HIP_TRY(ctx, hipStreamSynchronize(s));
     return MVS_OK;
+}
+
+mvs_status mvs_batch_upload(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
+                            const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
+                            const int32_t *n_pair, const double *K, const int64_t *global_index)
+{
+    return batch_upload_impl(b, first, count, base_desc, base_kp, n_base, pair_desc, pair_kp, n_pair, K, global_index, true);
+}
+
+mvs_status mvs_batch_upload_async(mvs_batch *b, int first, int count, const uint8_t *base_desc, const float *base_kp,
+                                  const int32_t *n_base, const uint8_t *pair_desc, const float *pair_kp,
+                                  const int32_t *n_pair, const double *K, const int64_t *global_index)
+{
+    return batch_upload_impl(b, first, count, base_desc, base_kp, n_base, pair_desc, pair_kp, n_pair, K, global_index, false);
+}
+
+mvs_status mvs_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0)
+        return MVS_ERR_INVALID_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? MVS_OK : MVS_ERR_HIP;
+}
+
+void mvs_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
 }
 
 static mvs_status check_params(const mvs_params *p)
@@ -549,6 +649,28 @@ mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, 
     return MVS_OK;
 }
 
+// enqueue the device -> host copies of a batch's outputs on the ctx stream (after whatever has been enqueued: a
+// preceding mvs_batch_run needs no synchronisation in between)
+static mvs_status batch_download_enqueue(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                                         uint8_t *inlier_mask, double *points_xyz, int32_t *point_idx32)
+{
+    mvs_ctx *ctx = b->ctx;
+    hipStream_t s = ctx->stream;
+    const BatchDev &d = b->d;
+    const size_t N = d.max_kp, off = first, cnt = count;
+    if (results)
+        HIP_TRY(ctx, hipMemcpyAsync(results, d.results + off, cnt * sizeof(mvs_pair_result), hipMemcpyDeviceToHost, s));
+    if (matches)
+        HIP_TRY(ctx, hipMemcpyAsync(matches, d.matches + off * N, cnt * N * sizeof(mvs_match), hipMemcpyDeviceToHost, s));
+    if (inlier_mask)
+        HIP_TRY(ctx, hipMemcpyAsync(inlier_mask, d.mask + off * N, cnt * N, hipMemcpyDeviceToHost, s));
+    if (points_xyz)
+        HIP_TRY(ctx, hipMemcpyAsync(points_xyz, d.points + off * N * 3, cnt * N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (point_idx32)
+        HIP_TRY(ctx, hipMemcpyAsync(point_idx32, d.point_idx + off * N, cnt * N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return MVS_OK;
+}
+
 mvs_status mvs_batch_download(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
                               uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx)
 {
@@ -556,25 +678,25 @@ mvs_status mvs_batch_download(mvs_batch *b, int first, int count, mvs_pair_resul
         return MVS_ERR_INVALID_ARG;
     mvs_ctx *ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const BatchDev &d = b->d;
-    const size_t N = d.max_kp, off = first, cnt = count;
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (results)
-        HIP_TRY(ctx, hipMemcpy(results, d.results + off, cnt * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
-    if (matches)
-        HIP_TRY(ctx, hipMemcpy(matches, d.matches + off * N, cnt * N * sizeof(mvs_match), hipMemcpyDeviceToHost));
-    if (inlier_mask)
-        HIP_TRY(ctx, hipMemcpy(inlier_mask, d.mask + off * N, cnt * N, hipMemcpyDeviceToHost));
-    if (points_xyz)
-        HIP_TRY(ctx, hipMemcpy(points_xyz, d.points + off * N * 3, cnt * N * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (point_idx) {
-        std::vector<int32_t> tmp(cnt * N);
-        HIP_TRY(ctx, hipMemcpy(tmp.data(), d.point_idx + off * N, cnt * N * sizeof(int32_t), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cnt * N; ++i)
-            point_idx[i] = tmp[i];  // reference type: size_t (sfm.hpp:35)
-    }
+    const size_t N = b->d.max_kp, cnt = count;
+    std::vector<int32_t> tmp(point_idx ? cnt * N : 0);
+    mvs_status st = batch_download_enqueue(b, first, count, results, matches, inlier_mask, points_xyz,
+                                           point_idx ? tmp.data() : nullptr);
+    if (st != MVS_OK)
+        return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < tmp.size(); ++i)
+        point_idx[i] = tmp[i];  // reference type: size_t (sfm.hpp:35)
     return MVS_OK;
+}
+
+mvs_status mvs_batch_download_async(mvs_batch *b, int first, int count, mvs_pair_result *results, mvs_match *matches,
+                                    uint8_t *inlier_mask, double *points_xyz, int32_t *point_idx32)
+{
+    if (!b || first < 0 || count < 1 || first + count > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+    return batch_download_enqueue(b, first, count, results, matches, inlier_mask, points_xyz, point_idx32);
 }
 
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out)
@@ -685,35 +807,60 @@ static mvs_status stage_points(mvs_ctx *ctx, const double *p1_uv, const double *
     mat3_inverse(K, kinv);
     const int64_t zero = 0;
     const int32_t M = m;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_uv1, p1_uv, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_uv2, p2_uv, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.K), K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.Kinv), kinv, 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(b->d.M, &M, sizeof(M), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));  // host temporaries above go out of scope
+    const size_t pb = (size_t)m * 2 * sizeof(double);
+    // results come back through the same arena (fetch_single): size it for both directions now
+    if ((st = pin_begin(ctx, 2 * pb + 1024 + sizeof(mvs_pair_result) + (size_t)b->d.max_kp * (1 + 24 + 4 + 16) + 512)) != MVS_OK)
+        return st;
+    if ((st = up_async(ctx, ctx->d_uv1, p1_uv, pb)) != MVS_OK) return st;
+    if ((st = up_async(ctx, ctx->d_uv2, p2_uv, pb)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.K), K, 9 * sizeof(double))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.Kinv), kinv, 9 * sizeof(double))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero))) != MVS_OK) return st;
+    if ((st = up_async(ctx, b->d.M, &M, sizeof(M))) != MVS_OK) return st;
     launch_prep_points(b->d, ctx->d_uv1, ctx->d_uv2, 1, s);
     return MVS_OK;
 }
 
+// results of a single-shot call: asynchronous copies into the pinned arena (opened by the staging half of the call),
+// ONE synchronisation, then plain memcpy into the caller's buffers.  The row counts are only known after the copy, so
+// the m-row capacity is fetched (m <= 4096: at most 180 KB).
 static mvs_status fetch_single(mvs_ctx *ctx, int m, mvs_pair_result *res, double *points_xyz, int64_t *point_idx,
-                               uint8_t *mask)
+                               uint8_t *mask, mvs_match *matches = nullptr)
 {
     mvs_batch *b = ctx->scratch;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t s = ctx->stream;
+    const size_t rows = (size_t)std::max(m, 0);
+    mvs_pair_result *h_res = static_cast<mvs_pair_result *>(pin_get(ctx, sizeof(mvs_pair_result)));
+    uint8_t *h_mask = (mask && rows) ? static_cast<uint8_t *>(pin_get(ctx, rows)) : nullptr;
+    double *h_pts = (points_xyz && rows) ? static_cast<double *>(pin_get(ctx, rows * 3 * sizeof(double))) : nullptr;
+    int32_t *h_idx = (point_idx && rows) ? static_cast<int32_t *>(pin_get(ctx, rows * sizeof(int32_t))) : nullptr;
+    mvs_match *h_mt = (matches && rows) ? static_cast<mvs_match *>(pin_get(ctx, rows * sizeof(mvs_match))) : nullptr;
+    PIN_TRY(ctx, h_res);
+    if ((mask && rows && !h_mask) || (points_xyz && rows && !h_pts) || (point_idx && rows && !h_idx) || (matches && rows && !h_mt))
+        PIN_TRY(ctx, (void *)nullptr);
+    HIP_TRY(ctx, hipMemcpyAsync(h_res, b->d.results, sizeof(*res), hipMemcpyDeviceToHost, s));
+    if (h_mask)
+        HIP_TRY(ctx, hipMemcpyAsync(h_mask, b->d.mask, rows, hipMemcpyDeviceToHost, s));
+    if (h_pts)
+        HIP_TRY(ctx, hipMemcpyAsync(h_pts, b->d.points, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h_idx)
+        HIP_TRY(ctx, hipMemcpyAsync(h_idx, b->d.point_idx, rows * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (h_mt)
+        HIP_TRY(ctx, hipMemcpyAsync(h_mt, b->d.matches, rows * sizeof(mvs_match), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpy(res, b->d.results, sizeof(*res), hipMemcpyDeviceToHost));
-    if (mask && m > 0)
-        HIP_TRY(ctx, hipMemcpy(mask, b->d.mask, (size_t)m, hipMemcpyDeviceToHost));
+    *res = *h_res;
+    const size_t M = (size_t)std::min<int>(std::max(res->n_matches, 0), (int)rows);
+    if (h_mask)
+        std::memcpy(mask, h_mask, matches ? M : rows);
     const int n = res->valid ? res->n_points : 0;
-    if (n > 0 && points_xyz)
-        HIP_TRY(ctx, hipMemcpy(points_xyz, b->d.points, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (n > 0 && point_idx) {
-        std::vector<int32_t> tmp(n);
-        HIP_TRY(ctx, hipMemcpy(tmp.data(), b->d.point_idx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n > 0 && h_pts)
+        std::memcpy(points_xyz, h_pts, (size_t)n * 3 * sizeof(double));
+    if (n > 0 && h_idx)
         for (int i = 0; i < n; ++i)
-            point_idx[i] = tmp[i];
-    }
+            point_idx[i] = h_idx[i];   // reference type: size_t (sfm.hpp:35)
+    if (h_mt && M)
+        std::memcpy(matches, h_mt, M * sizeof(mvs_match));
     return MVS_OK;
 }
 
@@ -735,26 +882,35 @@ mvs_status mvs_match_hamming(mvs_ctx *ctx, const uint8_t *train_desc, int n_trai
     hipStream_t s = ctx->stream;
     const int32_t n1 = n_train, n2 = n_query;
     const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t *>(b->d.desc1), train_desc, (size_t)n_train * desc_bytes,
-                                hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t *>(b->d.desc2), query_desc, (size_t)n_query * desc_bytes,
-                                hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int32_t *>(b->d.n1), &n1, sizeof(n1), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int32_t *>(b->d.n2), &n2, sizeof(n2), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.Kinv), eye, sizeof(eye), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.K), eye, sizeof(eye), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    const size_t cap = (size_t)std::min(n_train, n_query);   // a query matches at most once
+    (void)cap;
+    const size_t tb = (size_t)n_train * desc_bytes, qb = (size_t)n_query * desc_bytes;
+    if ((st = pin_begin(ctx, tb + qb + 1024 + sizeof(int32_t) + ((size_t)n_query) * sizeof(mvs_match))) != MVS_OK)
+        return st;
+    // descriptors (<= 4096 x 64 B per image) and the small parameters all go through the pinned arena: every device copy
+    // is an asynchronous DMA, whatever memory the caller's cv::Mat lives in
+    if ((st = up_async(ctx, const_cast<uint32_t *>(b->d.desc1), train_desc, tb)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<uint32_t *>(b->d.desc2), query_desc, qb)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int32_t *>(b->d.n1), &n1, sizeof(n1))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int32_t *>(b->d.n2), &n2, sizeof(n2))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.Kinv), eye, sizeof(eye))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.K), eye, sizeof(eye))) != MVS_OK) return st;
     RunParams rp{};
     rp.ratio = ratio;
     rp.max_dist = max_dist;
     launch_match_topk(b->d, rp, 1, s);
     launch_match_compact(b->d, rp, 1, s);
+    int32_t *h_M = static_cast<int32_t *>(pin_get(ctx, sizeof(int32_t)));
+    mvs_match *h_mt = static_cast<mvs_match *>(pin_get(ctx, (size_t)n_query * sizeof(mvs_match)));
+    PIN_TRY(ctx, h_M);
+    PIN_TRY(ctx, h_mt);
+    HIP_TRY(ctx, hipMemcpyAsync(h_M, b->d.M, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(h_mt, b->d.matches, (size_t)n_query * sizeof(mvs_match), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipGetLastError());
-    int32_t M = 0;
-    HIP_TRY(ctx, hipMemcpy(&M, b->d.M, sizeof(M), hipMemcpyDeviceToHost));
+    const int32_t M = *h_M;
     if (M > 0)
-        HIP_TRY(ctx, hipMemcpy(out, b->d.matches, (size_t)M * sizeof(mvs_match), hipMemcpyDeviceToHost));
+        std::memcpy(out, h_mt, (size_t)M * sizeof(mvs_match));
     *n_out = M;
     return MVS_OK;
 }
@@ -805,12 +961,64 @@ mvs_status mvs_two_view(mvs_ctx *ctx, const double *p1_uv, const double *p2_uv, 
     return MVS_OK;
 }
 
+// ImagePair::ImagePair + reconstruct (front-end/image-pair.cpp:30-71,116-174) of ONE pair in one device pass: the
+// descriptors and keypoints go up once, the four stages run back to back on the stream, everything comes back through the
+// pinned arena after a single synchronisation (match -> host gather -> sfm_solve as separate calls costs two round trips).
+mvs_status mvs_image_pair(mvs_ctx *ctx, const uint8_t *base_desc, const float *base_kp, int n_base,
+                          const uint8_t *pair_desc, const float *pair_kp, int n_pair, int desc_bytes, const double K[9],
+                          const mvs_params *params, mvs_pair_result *result, mvs_match *matches, uint8_t *inlier_mask,
+                          double *points_xyz, int64_t *point_idx)
+{
+    if (!ctx || !base_desc || !base_kp || !pair_desc || !pair_kp || !K || !result)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    if (n_base < 2 || n_pair < 1)   // visual-feature.cpp:56,67
+        return MVS_ERR_INVALID_ARG;
+    if (!(desc_bytes == 16 || desc_bytes == 32 || desc_bytes == 64))
+        return MVS_ERR_INVALID_ARG;
+    if (!affine_K(K))
+        return MVS_ERR_BAD_INTRINSICS;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((st = ensure_scratch(ctx, std::max(n_base, n_pair), desc_bytes)) != MVS_OK)
+        return st;
+    mvs_batch *b = ctx->scratch;
+    if ((st = ensure_groups(b, params->num_hypotheses)) != MVS_OK)
+        return st;
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    const size_t db1 = (size_t)n_base * desc_bytes, db2 = (size_t)n_pair * desc_bytes;
+    const size_t kb1 = (size_t)n_base * 2 * sizeof(float), kb2 = (size_t)n_pair * 2 * sizeof(float);
+    if ((st = pin_begin(ctx, db1 + db2 + kb1 + kb2 + 2048 + sizeof(mvs_pair_result) + (size_t)n_pair * (1 + 24 + 4 + 16) + 512)) != MVS_OK)
+        return st;
+    double kinv[9];
+    mat3_inverse(K, kinv);
+    const int32_t n1 = n_base, n2 = n_pair;
+    const int64_t zero = 0;
+    // <= 4096 x 64 B per image: through the pinned arena (a memcpy of ~100 KB), so that the device copies are true
+    // asynchronous DMA whatever memory the caller's cv::Mat / std::vector lives in
+    if ((st = up_async(ctx, const_cast<uint32_t *>(b->d.desc1), base_desc, db1)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<uint32_t *>(b->d.desc2), pair_desc, db2)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<float *>(b->d.kp1), base_kp, kb1)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<float *>(b->d.kp2), pair_kp, kb2)) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int32_t *>(b->d.n1), &n1, sizeof(n1))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int32_t *>(b->d.n2), &n2, sizeof(n2))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.K), K, 9 * sizeof(double))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.Kinv), kinv, 9 * sizeof(double))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero))) != MVS_OK) return st;
+    if ((st = enqueue_pipeline(b, to_run(*params), 1, false, nullptr)) != MVS_OK)
+        return st;
+    if ((st = fetch_single(ctx, n_pair, result, points_xyz, point_idx, inlier_mask, matches)) != MVS_OK)
+        return st;
+    return result->valid ? MVS_OK : MVS_NO_MODEL;
+}
+
 static mvs_status upload_mask(mvs_ctx *ctx, const uint8_t *mask, int m)
 {
     mvs_batch *b = ctx->scratch;
-    if (mask) {
+    if (mask) {   // the caller's buffer outlives the call: every entry point synchronises before it returns
         HIP_TRY(ctx, hipMemcpyAsync(b->d.mask, mask, (size_t)m, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->d.mask, 1, (size_t)m, ctx->stream));
     }
@@ -833,7 +1041,8 @@ mvs_status mvs_triangulate(mvs_ctx *ctx, const double *p1_uv, const double *p2_u
     std::memset(&res, 0, sizeof(res));
     std::memcpy(res.R1to2, R1to2, sizeof(res.R1to2));
     std::memcpy(res.t1to2, t1to2, sizeof(res.t1to2));
-    HIP_TRY(ctx, hipMemcpy(b->d.results, &res, sizeof(res), hipMemcpyHostToDevice));
+    if ((st = up_async(ctx, b->d.results, &res, sizeof(res))) != MVS_OK)
+        return st;
     if ((st = upload_mask(ctx, nullptr, m)) != MVS_OK)
         return st;
     RunParams rp{};
@@ -862,7 +1071,8 @@ mvs_status mvs_recover_pose(mvs_ctx *ctx, const double E[9], const double *p1_uv
     mvs_pair_result res;
     std::memset(&res, 0, sizeof(res));
     std::memcpy(res.E, E, sizeof(res.E));
-    HIP_TRY(ctx, hipMemcpy(b->d.results, &res, sizeof(res), hipMemcpyHostToDevice));
+    if ((st = up_async(ctx, b->d.results, &res, sizeof(res))) != MVS_OK)
+        return st;
     if ((st = upload_mask(ctx, inlier_mask, m)) != MVS_OK)
         return st;
     RunParams rp{};
@@ -934,12 +1144,13 @@ mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const doubl
     const int32_t M = m;
     const int64_t zero = 0;
     const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    HIP_TRY(ctx, hipMemcpyAsync(b->d.pts, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(b->d.M, &M, sizeof(M), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.K), eye, sizeof(eye), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(b->d.Kinv), eye, sizeof(eye), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if ((st = pin_begin(ctx, packed.size() * sizeof(double) + 2048 + sizeof(mvs_pair_result) + (size_t)m + 256)) != MVS_OK)
+        return st;
+    if ((st = up_async(ctx, b->d.pts, packed.data(), packed.size() * sizeof(double))) != MVS_OK) return st;
+    if ((st = up_async(ctx, b->d.M, &M, sizeof(M))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.K), eye, sizeof(eye))) != MVS_OK) return st;
+    if ((st = up_async(ctx, const_cast<double *>(b->d.Kinv), eye, sizeof(eye))) != MVS_OK) return st;
     if (count || residual) {
         if (b->hyp_table_cap < num_hypotheses) {
             int32_t *hc;

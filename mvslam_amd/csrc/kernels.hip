@@ -176,10 +176,16 @@ __global__ __launch_bounds__(1024) void match_compact_kernel(BatchDev b)
     int local = 0;
     const double *Ki = b.Kinv + (size_t)pair * 9;
     const double k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5];
-    for (int m = tid; m < n2; m += 1024) {
-        const uint32_t key = s_key[m];
-        if (key == 0xffffffffu)
+    // rows [M, max_kp) of the match list are cleared, so that a download of the whole capacity is deterministic
+    // (valid keys sort first: row m is a match iff its key is valid)
+    for (int m = tid; m < b.max_kp; m += 1024) {
+        const uint32_t key = m < n2 ? s_key[m] : 0xffffffffu;
+        if (key == 0xffffffffu) {
+            mvs_match z;
+            z.queryIdx = 0; z.trainIdx = 0; z.imgIdx = 0; z.distance = 0.f;
+            b.matches[base + m] = z;
             continue;
+        }
         ++local;
         const int q = (int)(key & 0xffffu);
         const int tr = b.knn_train[base + q];
@@ -1057,6 +1063,8 @@ __global__ __launch_bounds__(kFinThreads) void finalize_model_kernel(BatchDev b,
             }
         }
         __syncthreads();
+        for (int i = M + tid; i < b.max_kp; i += kFinThreads)   // rows past the match list: cleared (deterministic downloads)
+            mask[i] = 0;
         if (!s_proceed) {
             for (int i = tid; i < M; i += kFinThreads)
                 mask[i] = 0;
@@ -1246,9 +1254,19 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
     __shared__ int s_win;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const FinModel *fm = b.fin + pair;
-    if (!fm->proceed)
-        return;
     const size_t base = (size_t)pair * b.max_kp;
+    // rows [n_points, max_kp) of points / point_idx are cleared on every path (deterministic whole-capacity downloads)
+    auto clear_tail = [&](int from) {
+        for (int i = from + tid; i < b.max_kp; i += kFinThreads) {
+            double *d = b.points + (base + i) * 3;
+            d[0] = 0.0; d[1] = 0.0; d[2] = 0.0;
+            b.point_idx[base + i] = 0;
+        }
+    };
+    if (!fm->proceed) {
+        clear_tail(0);
+        return;
+    }
     mvs_pair_result *res = b.results + pair;
     const int n_inl = fm->n_inl, ncand = fm->ncand;
     const uint8_t *okf = b.okf + (size_t)pair * 4 * b.max_kp;
@@ -1284,8 +1302,10 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
     }
     __syncthreads();
     const int win = s_win;
-    if (win < 0)
+    if (win < 0) {
+        clear_tail(0);
         return;  // recover_pose_and_points returned false
+    }
     // ---- compact the winner's points in index order ----
     const double *src = b.cand_pts + ((size_t)pair * 4 + win) * b.max_kp * 3;
     const uint8_t *okw = okf + (size_t)win * b.max_kp;
@@ -1297,6 +1317,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
             d[0] = src[j * 3]; d[1] = src[j * 3 + 1]; d[2] = src[j * 3 + 2];
             b.point_idx[base + pos] = inl[j];
         });
+    clear_tail(n_pts);
     // ---- pose2in1 = SE3(SO3(R), t).inverse()  (sfm-solve.cpp:364; lie-group.hpp:212-216) ----
     if (tid == 0) {
         const double *Rw = fm->R[win >> 1];

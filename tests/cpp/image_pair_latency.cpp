@@ -1,0 +1,73 @@
+// What a caller of the reference's ImagePair constructor waits for (front-end/image-pair.cpp:30-71): wall time of the
+// shim's ImagePair ctor for one synthetic 2000-keypoint pair at 50 000 hypotheses, host buffers in, host objects out.
+// Prints one JSON line.   usage: image_pair_latency [n_kp] [hypotheses] [repeats]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../mvslam_amd/compat/mvslam_compat.hpp"
+
+using namespace mvSLAM;
+
+int main(int argc, char **argv)
+{
+    const int n_kp = argc > 1 ? atoi(argv[1]) : 2000, H = argc > 2 ? atoi(argv[2]) : 50000, reps = argc > 3 ? atoi(argv[3]) : 50;
+    std::mt19937_64 rng(7);
+    std::normal_distribution<double> noise(0.0, 0.5);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    CameraIntrinsics K = CameraIntrinsics::Identity();
+    K(0, 0) = 525; K(1, 1) = 525; K(0, 2) = 320; K(1, 2) = 240;
+    // cam 2 = 0.3 m to the right with a small yaw; 2000 points in front of both
+    const double yaw = 0.03, c = std::cos(yaw), s = std::sin(yaw);
+    std::vector<KeyPoint> k1(n_kp), k2(n_kp);
+    Mat8u d1, d2;
+    d1.cols = d2.cols = 32; d1.rows = d2.rows = n_kp;
+    d1.data.resize((size_t)n_kp * 32); d2.data.resize((size_t)n_kp * 32);
+    for (int i = 0; i < n_kp; ++i) {
+        const double Z = 2 + 8 * U(rng), X = (U(rng) - 0.5) * Z, Y = (U(rng) - 0.5) * 0.8 * Z;
+        const double X2 = c * X - s * Z - 0.3, Z2 = s * X + c * Z;
+        k1[i] = KeyPoint{};
+        k2[i] = KeyPoint{};
+        k1[i].pt.x = (float)(525 * X / Z + 320 + noise(rng)); k1[i].pt.y = (float)(525 * Y / Z + 240 + noise(rng));
+        k2[i].pt.x = (float)(525 * X2 / Z2 + 320 + noise(rng)); k2[i].pt.y = (float)(525 * Y / Z2 + 240 + noise(rng));
+        for (int b = 0; b < 32; ++b) {
+            const uint8_t v = (uint8_t)(rng() & 0xff);
+            d1.data[(size_t)i * 32 + b] = v;
+            d2.data[(size_t)i * 32 + b] = (i % 10 < 7) ? (uint8_t)(v ^ ((rng() % 50 == 0) ? 1 : 0)) : (uint8_t)(rng() & 0xff);
+        }
+    }
+    Frame f1{1, VisualFeature(k1, d1, 640, 480)}, f2{2, VisualFeature(k2, d2, 640, 480)};
+    hip::ransac_config().num_hypotheses = H;
+    hip::ransac_config().sampler = MVS_SAMPLER_PHILOX;
+    hip::ransac_config().seed = 1;
+    hip::ransac_config().max_error_sq = 1e-2;
+    size_t inl = 0;
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {   // warm-up: allocations, first-launch costs
+        ImagePair ip(f1, f2, K);
+        ok = ok && ip.valid;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) {
+        ImagePair ip(f1, f2, K);
+        inl += ip.match_inlier_count;
+        ok = ok && ip.valid;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    // the same through the two separate reference calls (match_visual_features + sfm_solve): two round trips
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) {
+        const auto matches = VisualFeature::match_visual_features(f1.visual_feature, f2.visual_feature, 10);
+        const auto bp = f1.visual_feature.get_image_points(), pp = f2.visual_feature.get_image_points();
+        std::vector<ImagePoint> a, b;
+        for (const auto &m : matches) { a.push_back(bp[m.trainIdx]); b.push_back(pp[m.queryIdx]); }
+        Transformation T; std::vector<Point3> P; std::vector<size_t> I;
+        ok = sfm_solve(a, b, K, T, P, I) && ok;
+    }
+    const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() / reps;
+    std::printf("{\"what\": \"shim ImagePair ctor wall time, host buffers in, host objects out\", \"keypoints\": %d, "
+                "\"hypotheses\": %d, \"repeats\": %d, \"image_pair_ctor_ms\": %.4f, \"match_then_sfm_solve_ms\": %.4f, "
+                "\"avg_points\": %.1f, \"all_valid\": %s}\n", n_kp, H, reps, ms, ms2, (double)inl / reps, ok ? "true" : "false");
+    return ok ? 0 : 1;
+}

@@ -85,8 +85,15 @@ def test_unscaled_sqrt_div_are_ieee_exact(ctx):
     x[:len(special)] = special
     y[:len(special)] = [1.0, 3.0, 7.0, -2.0 ** -200, 2.0 ** 200, 3.0, 2.0 ** 200, 2.0 ** -200, -3.0, 5.0]
     counts = (C.c_ulonglong * 4)()
-    st = capi.lib().mvs_debug_fastmath_check(ctx._h, x.ctypes.data_as(C.POINTER(C.c_double)),
-                                             y.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(n), counts)
+    # the checker lives in the diagnostics build only (the product library exports no mvs_debug_* symbol)
+    assert not hasattr(capi.lib(), "mvs_debug_fastmath_check") and not hasattr(capi.lib(), "mvs_debug_set_ransac_variant")
+    dbg = C.CDLL(capi.DBG_LIB_PATH)
+    h = C.c_void_p()
+    assert dbg.mvs_ctx_create(C.c_int(0), C.byref(h)) == 0
+    dbg.mvs_ctx_destroy.argtypes = [C.c_void_p]
+    st = dbg.mvs_debug_fastmath_check(h, x.ctypes.data_as(C.POINTER(C.c_double)),
+                                      y.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(n), counts)
+    dbg.mvs_ctx_destroy(h)
     assert st == 0
     assert counts[2] > n // 2 and counts[3] > n // 3       # the guards admitted most of the operands
     assert counts[0] == 0, "sqrt_fast differs from IEEE sqrt on %d operands" % counts[0]
@@ -341,9 +348,8 @@ def test_full_size_properties(ctx):
     data, out = _run_batch(ctx, 200, 3, 2000, prm)
     data1, out1 = _run_batch(ctx, 201, 1, 2000, prm)
     assert out["results"][1].tobytes() == out1["results"][0].tobytes()          # shard invariance + determinism
-    M1 = out["results"][1]["n_matches"]
-    assert out["matches"][1][:M1].tobytes() == out1["matches"][0][:M1].tobytes()
-    assert np.array_equal(out["mask"][1][:M1], out1["mask"][0][:M1])
+    assert out["matches"][1].tobytes() == out1["matches"][0].tobytes()        # whole capacity: the tails are zero
+    assert np.array_equal(out["mask"][1], out1["mask"][0]) and out["points"][1].tobytes() == out1["points"][0].tobytes()
     for i in range(3):
         r = out["results"][i]
         M, n = r["n_matches"], r["n_points"]

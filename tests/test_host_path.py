@@ -1,0 +1,112 @@
+"""The host side of the boundary: the single-pass ImagePair entry, the asynchronous pinned-buffer
+batch transfers, and the guarantee that whole-capacity downloads are deterministic (rows past the valid ranges are zero)."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from mvslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_kp,H,thr", [(300, 512, 1e-2), (2000, 3000, 1e-2), (700, 64, 0.0)])
+def test_image_pair_single_pass_is_the_two_reference_calls(ctx, n_kp, H, thr):
+    """mvs_image_pair = match_visual_features + gather + sfm_solve (front-end/image-pair.cpp:57-65,116-174) in one device
+    pass: identical to the oracle's composition, and to the two separate C-ABI calls."""
+    from mvslam_amd import capi
+
+    p = synth.make_pair(77 + n_kp, n_kp=n_kp)
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=5, max_error_sq=thr)
+    got = ctx.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], prm)
+    ref = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(H, o.SAMPLER_PHILOX, 5, thr), 0.7, 10.0)
+    M, n = ref["n_matches"], ref["n_points"]
+    assert got["ok"] == ref["ok"] and got["n_matches"] == M
+    assert got["matches"].tobytes() == ref["matches"].tobytes()
+    assert got["best_hyp"] == ref["best_hyp"] and got["best_count"] == ref["best_count"]
+    assert np.array_equal(got["mask"], ref["mask"])
+    if ref["ok"]:
+        assert np.array_equal(got["point_idx"], ref["point_idx"]) and len(got["points"]) == n
+        assert np.abs(got["points"] - ref["points"]).max() <= 1e-12 * max(1.0, np.abs(ref["points"]).max())
+        assert np.abs(got["R"] - ref["R"]).max() <= 1e-12 and np.abs(got["t"] - ref["t"]).max() <= 1e-12
+    # the two separate calls give the same bits as the single pass
+    mt = ctx.match_hamming(p["desc1"], p["desc2"], 0.7, 10.0)
+    assert mt.tobytes() == got["matches"].tobytes()
+    uv1 = p["kp1"][mt["trainIdx"]].astype(np.float64)
+    uv2 = p["kp2"][mt["queryIdx"]].astype(np.float64)
+    two = ctx.two_view(uv1, uv2, p["K"], prm)
+    assert two["ok"] == got["ok"] and two["best_hyp"] == got["best_hyp"]
+    if got["ok"]:
+        assert two["R"].tobytes() == got["R"].tobytes() and two["points"].tobytes() == got["points"].tobytes()
+
+
+def test_image_pair_argument_errors(ctx):
+    from mvslam_amd import capi
+
+    p = synth.make_pair(1, n_kp=100)
+    prm = capi.default_params(num_hypotheses=16, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-2)
+    Kbad = p["K"].copy()
+    Kbad[2, 0] = 0.5
+    with pytest.raises(capi.MvsError) as e:
+        ctx.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], Kbad, prm)
+    assert e.value.status == capi.MVS_ERR_BAD_INTRINSICS
+    with pytest.raises(capi.MvsError) as e:      # a train image with one row: visual-feature.cpp:67 needs two neighbours
+        ctx.image_pair(p["desc1"][:1], p["kp1"][:1], p["desc2"], p["kp2"], p["K"], prm)
+    assert e.value.status == capi.MVS_ERR_INVALID_ARG
+    # too few matches for a model: false, never an abort (estimator-RANSAC.cpp:25-29)
+    got = ctx.image_pair(p["desc1"][:5], p["kp1"][:5], p["desc2"][:5], p["kp2"][:5], p["K"], prm)
+    assert not got["ok"] and got["n_matches"] <= 5
+
+
+def test_async_pinned_transfers_match_the_synchronous_path_and_tails_are_zero(ctx):
+    from mvslam_amd import capi
+
+    P, N, H = 6, 500, 700
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=9, max_error_sq=1e-2)
+    data = synth.make_batch(40, P, n_kp=N)
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
+    b.run(prm)
+    want = b.download()
+    # second run of the SAME batch object with far fewer keypoints: every row past the new valid ranges must be zero
+    small = synth.make_batch(40, P, n_kp=N)
+    n_small = np.full(P, 60, dtype=np.int32)
+    pin = {k: capi.pinned_empty(np.asarray(small[k]).shape, np.asarray(small[k]).dtype)
+           for k in ("desc1", "kp1", "desc2", "kp2", "global_index")}
+    for k in pin:
+        pin[k][...] = small[k]
+    pin_n = capi.pinned_empty((P,), np.int32)
+    pin_n[...] = n_small
+    pin_K = capi.pinned_empty((P, 9), np.float64)
+    pin_K[...] = small["K"].reshape(P, 9)
+    o_res = capi.pinned_empty((P,), capi.RESULT_DTYPE)
+    o_mt = capi.pinned_empty((P, N), capi.MATCH_DTYPE)
+    o_mk = capi.pinned_empty((P, N), np.uint8)
+    o_pt = capi.pinned_empty((P, N, 3), np.float64)
+    o_ix = capi.pinned_empty((P, N), np.int32)
+    for a in (o_mt, o_mk, o_pt, o_ix):
+        a.view(np.uint8)[...] = 0xAB                       # poison: the download must overwrite everything
+    b.upload_async(0, pin["desc1"], pin["kp1"], pin_n, pin["desc2"], pin["kp2"], pin_n, pin_K, pin["global_index"])
+    b.run(prm)                                             # no sync between upload, run and download: stream order
+    b.download_async(0, P, o_res, o_mt, o_mk, o_pt, o_ix)
+    b.sync()
+    for i in range(P):
+        ref = o.image_pair(small["desc1"][i][:60], small["kp1"][i][:60], small["desc2"][i][:60], small["kp2"][i][:60],
+                           small["K"][i].reshape(3, 3), o.make_params(H, o.SAMPLER_PHILOX, 9 + int(small["global_index"][i]), 1e-2),
+                           0.7, 10.0)
+        M, n = ref["n_matches"], ref["n_points"] if ref["ok"] else 0
+        assert o_res[i]["n_matches"] == M and M <= 60 < want["results"][i]["n_matches"]
+        assert o_mt[i][:M].tobytes() == ref["matches"].tobytes() and np.array_equal(o_mk[i][:M], ref["mask"])
+        assert bool(o_res[i]["valid"]) == ref["ok"]
+        if ref["ok"]:
+            assert np.array_equal(o_ix[i][:n], ref["point_idx"]) and o_pt[i][:n].tobytes() == ref["points"].tobytes()
+        # tails: zero, not the previous run's rows and not the poison
+        assert not o_mt[i][M:].view(np.uint8).any() and not o_mk[i][M:].any()
+        assert not o_pt[i][n:].any() and not o_ix[i][n:].any()
+    # the synchronous download of the same state is byte-identical
+    again = b.download()
+    assert again["results"].tobytes() == o_res.tobytes() and again["matches"].tobytes() == o_mt.tobytes()
+    assert again["mask"].tobytes() == o_mk.tobytes() and again["points"].tobytes() == o_pt.tobytes()
+    assert np.array_equal(again["point_idx"], o_ix.astype(np.int64))
+    b.close()
+    for a in list(pin.values()) + [pin_n, pin_K, o_res, o_mt, o_mk, o_pt, o_ix]:
+        capi.pinned_free(a)

@@ -9,6 +9,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MVS_USE_DEBUG_LIB"] = "1"   # the variant switch exists in the diagnostics build only
 from mvslam_amd import capi, synth  # noqa: E402
 
 NAMES = {0: "round-1 first version", 120: "fused: LDS point stream + in-place rotation + mask-fma + unscaled sqrt/div",
