@@ -161,7 +161,10 @@ typedef struct mvs_pnp_params {
     uint64_t seed;
     double reproj_error;    /* 0.05 (pnp-solve.cpp:48), pixels of the given image points */
     int32_t min_inliers;    /* 4: the model points of the RANSAC kernel */
-    int32_t reserved;
+    int32_t refit;          /* 0 (default): return the best P3P hypothesis.  1: then minimise the reprojection error over
+                               ALL inliers (pose only, points fixed), the refit cv::solvePnPRansac ends with
+                               (pnp-solve.cpp:53-64); the inlier set stays the RANSAC one.  mvs_pnp_solve only: the
+                               batched tracks of a sequence are refined by the caller (mvs_pnp_refine) */
 } mvs_pnp_params;
 mvs_status mvs_pnp_params_default(mvs_pnp_params *p);
 mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *image_uv, int n, const double K[9],
@@ -239,6 +242,11 @@ mvs_status mvs_batch_results_device(mvs_batch *b, void **dev_ptr, size_t *record
 /* Asynchronous device-to-device copy (on the ctx stream) of the result records of pairs [first, first + count)
  * into caller-owned DEVICE memory, e.g. a torch tensor that is then all-gathered over RCCL. */
 mvs_status mvs_batch_copy_results_device(mvs_batch *b, int first, int count, void *dst_device);
+/* The one exchange step of the sharded path (pairs are independent: front-end/image-pair.hpp:56-57): one
+ * ncclAllGather over RCCL / xGMI of the records of pairs [0, n_active), enqueued on the ctx stream after the batch's
+ * kernels.  rccl_comm: the caller's ncclComm_t (one rank per GPU); dst_device: world_size x n_active x
+ * sizeof(mvs_pair_result) bytes of device memory, rank-major.  Asynchronous; librccl.so is loaded on first use. */
+mvs_status mvs_batch_gather_results(mvs_batch *b, int n_active, void *rccl_comm, void *dst_device);
 
 /* ---- frame sequences, device resident -------------------------------------------------
  * What VisualOdometer::add_frame chains per frame (front-end/visual-odometer.cpp:129-194,384-445,502-615):

@@ -67,7 +67,7 @@ assert RESULT_DTYPE.itemsize == C.sizeof(PairResult)
 
 class PnpParams(C.Structure):
     _fields_ = [("num_hypotheses", C.c_int32), ("sampler", C.c_int32), ("seed", C.c_uint64),
-                ("reproj_error", C.c_double), ("min_inliers", C.c_int32), ("reserved", C.c_int32)]
+                ("reproj_error", C.c_double), ("min_inliers", C.c_int32), ("refit", C.c_int32)]
 
 
 TRACK_DTYPE = np.dtype([("ok", "<i4"), ("n_corr", "<i4"), ("n_inliers", "<i4"), ("best_hyp", "<i4"),
@@ -118,6 +118,7 @@ EXPORTS = [
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
     "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
     "mvs_batch_upload_async", "mvs_batch_download_async", "mvs_host_alloc", "mvs_host_free", "mvs_image_pair",
+    "mvs_batch_gather_results",
 ]
 
 

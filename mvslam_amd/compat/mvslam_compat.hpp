@@ -8,9 +8,9 @@
 // (front-end/image-pair.cpp:57,146; utility/reconstruct-scene.cpp:40,48) into source/vision/.
 //
 // OpenCV and Eigen are not available in the build image, so layout-compatible stand-ins are
-// defined here (KeyPoint, DMatch, Mat8u, Vector3Type, Matrix3Type).  In the real tree compile with
-// -DMVSLAM_HAVE_OPENCV / -DMVSLAM_HAVE_EIGEN and the adapters at the bottom convert from the real
-// types without touching the call sites.
+// defined here (KeyPoint, DMatch, Mat8u, Vector3Type, Matrix3Type) and this header is what the C++
+// tests compile.  For the real tree the same forwarding bodies are written against the real types
+// (cv::Mat, cv::KeyPoint, Eigen matrices) as replacement translation units: integration/source/vision/.
 #pragma once
 
 #include <algorithm>
@@ -661,6 +661,7 @@ struct PnpConfig  // what the reference hard-codes in pnp-solve.cpp:47-49
     int sampler = MVS_SAMPLER_PHILOX;
     uint64_t seed = 0;
     double reproj_error = 0.05;
+    int refit = 1;   // cv::solvePnPRansac refits the pose on all inliers (pnp-solve.cpp:53-64)
 };
 inline PnpConfig &pnp_config()
 {
@@ -683,6 +684,7 @@ inline bool pnp_solve(const std::vector<Point3> &world_points, const std::vector
     prm.sampler = cfg.sampler;
     prm.seed = cfg.seed;
     prm.reproj_error = cfg.reproj_error;
+    prm.refit = cfg.refit;
     std::vector<int64_t> idx(n);
     double R[9], t[3];
     int ni = 0;

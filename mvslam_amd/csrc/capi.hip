@@ -1,5 +1,6 @@
 // capi.hip -- host side of libmvslam_hip.so: contexts, resident batches, the C ABI of include/mvslam_hip.h.
 // No CPU fallback exists anywhere in this file: every entry point ends in a HIP kernel launch.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -697,6 +698,45 @@ mvs_status mvs_batch_download_async(mvs_batch *b, int first, int count, mvs_pair
         return MVS_ERR_INVALID_ARG;
     HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
     return batch_download_enqueue(b, first, count, results, matches, inlier_mask, points_xyz, point_idx32);
+}
+
+// The one exchange step of the path: all-gather of the fixed-size result records over RCCL, callable from
+// host C++.  librccl is resolved at the first call (dlopen), so the library itself carries no link-time dependency on it
+// and single-GPU callers never load it.  `rccl_comm` is the caller's ncclComm_t (one rank per GPU, created by the caller:
+// ncclCommInitRank with an id it distributes however it likes); the collective is enqueued on the ctx stream, i.e. after
+// the kernels of a preceding mvs_batch_run, and the call returns without waiting.
+mvs_status mvs_batch_gather_results(mvs_batch *b, int n_active, void *rccl_comm, void *dst_device)
+{
+    if (!b || !rccl_comm || !dst_device || n_active < 1 || n_active > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+    typedef const char *(*errstr_fn)(int);
+    static allgather_fn fn = nullptr;
+    static errstr_fn es = nullptr;
+    if (!fn) {
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) {
+            ctx->err = std::string("dlopen(librccl.so): ") + dlerror();
+            return MVS_ERR_HIP;
+        }
+        fn = reinterpret_cast<allgather_fn>(dlsym(h, "ncclAllGather"));
+        es = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
+        if (!fn) {
+            ctx->err = "librccl.so has no ncclAllGather";
+            return MVS_ERR_HIP;
+        }
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = fn(b->d.results, dst_device, (size_t)n_active * sizeof(mvs_pair_result), /* ncclUint8 */ 1, rccl_comm,
+                      ctx->stream);
+    if (rc != 0) {
+        ctx->err = std::string("ncclAllGather: ") + (es ? es(rc) : "error");
+        return MVS_ERR_HIP;
+    }
+    return MVS_OK;
 }
 
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out)
@@ -1495,7 +1535,7 @@ mvs_status mvs_pnp_params_default(mvs_pnp_params *p)
     p->seed = 0;
     p->reproj_error = 0.05;   // pnp-solve.cpp:48
     p->min_inliers = 4;
-    p->reserved = 0;
+    p->refit = 0;
     return MVS_OK;
 }
 
@@ -1575,15 +1615,37 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
         *best_hyp = out.best_hyp;
     if (!out.ok)
         return MVS_NO_MODEL;
+    *n_inliers = out.n_inliers;
+    std::vector<int32_t> tmp;
+    if ((inlier_idx || params->refit) && out.n_inliers > 0) {
+        tmp.resize(out.n_inliers);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), p.inliers, (size_t)out.n_inliers * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (inlier_idx)
+            for (int i = 0; i < out.n_inliers; ++i)
+                inlier_idx[i] = tmp[i];
+    }
+    if (params->refit && out.n_inliers >= 4) {
+        // cv::solvePnPRansac ends with a refit over the inliers (pnp-solve.cpp:53-64).  Here: the refinement kernel as
+        // a motion-only problem -- the inliers' world points held by a prior of sigma 1e-9 (fixed), identity image
+        // covariances (unweighted pixels), no prior on the pose.  A failed refit keeps the RANSAC pose.
+        const size_t m = out.n_inliers;
+        std::vector<double> X(3 * m), XC(9 * m, 0.0), uv(2 * m);
+        for (size_t i = 0; i < m; ++i) {
+            std::memcpy(&X[3 * i], world_xyz + 3 * (size_t)tmp[i], 3 * sizeof(double));
+            std::memcpy(&uv[2 * i], image_uv + 2 * (size_t)tmp[i], 2 * sizeof(double));
+            XC[9 * i] = XC[9 * i + 4] = XC[9 * i + 8] = 1e-18;
+        }
+        mvs_refine_params rp;
+        mvs_refine_params_default(&rp);
+        rp.pose_sigma[0] = rp.pose_sigma[1] = 1e6;
+        mvs_refine_result rr;
+        if (mvs_pnp_refine(ctx, X.data(), XC.data(), uv.data(), nullptr, (int)m, K, out.R, out.t, &rp, &rr) == MVS_OK && rr.ok) {
+            std::memcpy(out.R, rr.R, sizeof(out.R));
+            std::memcpy(out.t, rr.t, sizeof(out.t));
+        }
+    }
     if (R) std::memcpy(R, out.R, sizeof(out.R));
     if (t) std::memcpy(t, out.t, sizeof(out.t));
-    *n_inliers = out.n_inliers;
-    if (inlier_idx && out.n_inliers > 0) {
-        std::vector<int32_t> tmp(out.n_inliers);
-        HIP_TRY(ctx, hipMemcpy(tmp.data(), p.inliers, (size_t)out.n_inliers * sizeof(int32_t), hipMemcpyDeviceToHost));
-        for (int i = 0; i < out.n_inliers; ++i)
-            inlier_idx[i] = tmp[i];
-    }
     return MVS_OK;
 }
 

@@ -143,3 +143,38 @@ def test_gpu_pnp_errors(ctx):
     got = ctx.pnp_solve(Xx, uvx, Kx, capi.default_pnp_params(num_hypotheses=64, min_inliers=10))
     ref = o.pnp_solve(Xx, uvx, Kx, o.make_pnp_params(64, o.SAMPLER_PHILOX, 0, min_inliers=10))
     assert got["ok"] == ref["ok"] and not got["ok"]
+
+
+@pytest.mark.gpu
+def test_gpu_pnp_refit_is_the_reprojection_minimiser_over_the_inliers(ctx):
+    """mvs_pnp_params.refit = 1: the refit cv::solvePnPRansac ends with (pnp-solve.cpp:53-64).  The inlier set is the
+    RANSAC one; the pose is the minimiser of the reprojection error over it (checked against scipy on the same
+    residuals) and is closer to the truth than the best 3-point hypothesis; the cube fixture stays exact."""
+    from scipy.optimize import least_squares
+
+    from mvslam_amd import capi
+
+    K, X, uv = _cube_rig()
+    r = ctx.pnp_solve(X, uv, K, capi.default_pnp_params(num_hypotheses=100, seed=0, refit=1))
+    assert r["ok"] and r["inliers"].tolist() == list(range(8))
+    assert np.abs(o.se3_ln(r["R"], r["t"]) - [1, 0, 0, 0, 0, 0]).max() < 1e-6          # test/test-pnp.cpp:14-60, 1e-3
+    better = 0
+    for seed in range(6):
+        K, X, uv, R, t, bad = _scene(40 + seed, 400, 0.5, 80)
+        Rc, tc = o.se3_inverse(R, t)                                                    # truth: camera in world
+        base = ctx.pnp_solve(X, uv, K, capi.default_pnp_params(num_hypotheses=300, seed=seed, reproj_error=2.0))
+        got = ctx.pnp_solve(X, uv, K, capi.default_pnp_params(num_hypotheses=300, seed=seed, reproj_error=2.0, refit=1))
+        assert base["ok"] and got["ok"] and got["best_hyp"] == base["best_hyp"]
+        assert np.array_equal(got["inliers"], base["inliers"])                          # the inlier set is not re-voted
+        Xi, ui = X[got["inliers"]], uv[got["inliers"]]
+
+        def res(x):
+            Rw, tw = o.se3_inverse(o.rodrigues(x[:3]) @ got["R"], got["t"] + x[3:])
+            return (o.project_points(K, Rw, tw, Xi) - ui).ravel()
+
+        s = least_squares(res, np.zeros(6), method="lm", xtol=1e-14, ftol=1e-14)
+        assert np.abs(s.x).max() < 1e-6, s.x                                            # already at the minimiser
+        e_base = np.abs(base["t"] - tc).max() + np.abs(base["R"] - Rc).max()
+        e_got = np.abs(got["t"] - tc).max() + np.abs(got["R"] - Rc).max()
+        better += e_got < e_base
+    assert better >= 5
