@@ -277,6 +277,9 @@ mvs_status mvs_seq_sync(mvs_seq *s);
 /* `steps` timed passes after `warmup`; ms_total = wall ms of the timed passes (HIP events on the ctx stream) */
 mvs_status mvs_seq_time(mvs_seq *s, const mvs_params *two_view, const mvs_pnp_params *pnp, int warmup, int steps,
                         float *ms_total);
+/* per-stage HIP-event timing of the sequence step (the kernels' own stream): ms_stage[4] = summed ms over `steps`
+ * instrumented passes of {pair pipeline, join, pnp_solve, scale propagation} */
+mvs_status mvs_seq_time_stages(mvs_seq *s, const mvs_params *two_view, const mvs_pnp_params *pnp, int steps, float *ms_stage);
 /* pairs [first, first + count) of the n_frames - 1 pairs: same layout as mvs_batch_download */
 mvs_status mvs_seq_download_pairs(mvs_seq *s, int first, int count, mvs_pair_result *results, mvs_match *matches,
                                   uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx);

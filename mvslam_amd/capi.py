@@ -118,7 +118,7 @@ EXPORTS = [
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
     "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
     "mvs_batch_upload_async", "mvs_batch_download_async", "mvs_host_alloc", "mvs_host_free", "mvs_image_pair",
-    "mvs_batch_gather_results",
+    "mvs_batch_gather_results", "mvs_seq_time_stages",
 ]
 
 
@@ -659,6 +659,12 @@ class Sequence:
         st = lib().mvs_seq_time(self._h, C.byref(params), C.byref(pnp_params), C.c_int(warmup), C.c_int(steps), C.byref(ms))
         self.ctx._check(st, "mvs_seq_time")
         return ms.value
+
+    def time_stages(self, params, pnp_params, steps):
+        ms = (C.c_float * 4)()
+        st = lib().mvs_seq_time_stages(self._h, C.byref(params), C.byref(pnp_params), C.c_int(steps), ms)
+        self.ctx._check(st, "mvs_seq_time_stages")
+        return {n: ms[i] / steps for i, n in enumerate(("pairs", "join", "pnp", "chain"))}
 
     def upload_images(self, first, images, K, params=None):
         """extract keypoints + descriptors of frames [first, first + len(images)) on the device, straight into the

@@ -1471,6 +1471,42 @@ mvs_status mvs_seq_time(mvs_seq *q, const mvs_params *two_view, const mvs_pnp_pa
     return MVS_OK;
 }
 
+// per-stage HIP-event timing of the sequence step on the kernels' own stream: ms_stage[4] = summed ms over `steps`
+// instrumented passes of {pair pipeline, join, pnp_solve (prep + ransac + finalize), chain}
+mvs_status mvs_seq_time_stages(mvs_seq *q, const mvs_params *two_view, const mvs_pnp_params *pnp, int steps, float *ms_stage)
+{
+    if (steps < 1 || !ms_stage)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = seq_prepare(q, two_view, pnp);
+    if (st != MVS_OK)
+        return st;
+    const RunParams rp = to_run(*two_view);
+    hipStream_t s = q->ctx->stream;
+    hipEvent_t *ev = q->batch->ev;
+    for (int k = 0; k < 4; ++k)
+        ms_stage[k] = 0.f;
+    for (int i = 0; i < steps; ++i) {
+        HIP_TRY(q->ctx, hipEventRecord(ev[0], s));
+        if ((st = enqueue_pipeline(q->batch, rp, q->n_frames - 1, false, nullptr)) != MVS_OK)
+            return st;
+        HIP_TRY(q->ctx, hipEventRecord(ev[1], s));
+        launch_seq_join(q->join, s);
+        HIP_TRY(q->ctx, hipEventRecord(ev[2], s));
+        launch_pnp(q->pnp, s);
+        HIP_TRY(q->ctx, hipEventRecord(ev[3], s));
+        q->chain.n_corr = q->pnp.n;
+        launch_seq_chain(q->chain, s);
+        HIP_TRY(q->ctx, hipEventRecord(ev[4], s));
+        HIP_TRY(q->ctx, hipEventSynchronize(ev[4]));
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIP_TRY(q->ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            ms_stage[k] += ms;
+        }
+    }
+    return MVS_OK;
+}
+
 mvs_status mvs_seq_download_pairs(mvs_seq *q, int first, int count, mvs_pair_result *results, mvs_match *matches,
                                   uint8_t *inlier_mask, double *points_xyz, int64_t *point_idx)
 {

@@ -25,6 +25,7 @@ s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
 prm = capi.default_params(num_hypotheses=args.hyp, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
 pprm = capi.default_pnp_params(num_hypotheses=args.pnp_hyp, seed=7, reproj_error=2.0)
 ms = s.time(prm, pprm, steps=args.steps, warmup=1) / args.steps
+stage_ms = s.time_stages(prm, pprm, steps=args.steps)
 s.run(prm, pprm)
 gp, gt = s.download_pairs(), s.download_tracks()
 res, tr = gp["results"], gt["tracks"]
@@ -61,4 +62,17 @@ print(json.dumps({
     "valid_pairs": int(res["valid"].sum()), "avg_matches": round(float(res["n_matches"].mean()), 1),
     "avg_points": round(float(res["n_points"].mean()), 1), "tracks_ok": int(tr["ok"].sum()),
     "avg_corr": round(float(tr["n_corr"].mean()), 1), "avg_pnp_inliers": round(float(tr["n_inliers"].mean()), 1),
+    "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+    # what bounds pnp_solve here: algorithmic fp64 flops = per hypothesis ~1 900 (Grunert coefficients,
+    # Ferrari quartic with 64 bisections, <= 4 poses from two triangle frames, 4th-point selection) + 28 per
+    # (hypothesis, correspondence) evaluation (11 fma + 2 mul + compare + count).  With the reference's 100 hypotheses
+    # a track is ONE workgroup with 100 of 256 lanes live and ~n sequential point evaluations per lane behind a
+    # ~700-instruction dependent bisection chain: the launch is latency / occupancy bound (one short workgroup per
+    # track, <= 1000 workgroups), two orders of magnitude under the fp64 roof -- by construction of the reference's
+    # parameters, not of the kernel (at 4096 hypotheses per track the same kernel reaches the figure in `pnp_roofline_4k`)
+    "pnp_roofline": {"bound": "latency (one 100-lane workgroup per track)", "unit": "TFLOP/s", "peak": 78.6,
+                     "flops_per_launch": int(sum(args.pnp_hyp * (1900 + 28 * int(n)) for n in tr["n_corr"])),
+                     "launch_ms": round(stage_ms["pnp"], 4),
+                     "achieved": round(sum(args.pnp_hyp * (1900 + 28 * int(n)) for n in tr["n_corr"]) / (stage_ms["pnp"] * 1e-3) / 1e12, 4),
+                     "frac": round(sum(args.pnp_hyp * (1900 + 28 * int(n)) for n in tr["n_corr"]) / (stage_ms["pnp"] * 1e-3) / 78.6e12, 5)},
     "data_generation_s": round(gen_s, 1), "cpu_baseline": cpu}))
