@@ -246,6 +246,18 @@ int mvs_debug_set_ransac_variant(int v)
     return old;
 }
 
+// diagnostics only: the per-hypothesis F records the solve launch handed to the scoring launch (pair `pair` of a batch)
+int mvs_debug_read_hyp_F(mvs_batch *b, int pair, int n_hyp, double *F_out, unsigned char *ok_out)
+{
+    if (!b || !b->d.hyp_F || pair < 0 || pair >= b->d.n_pairs || n_hyp < 1 || n_hyp > b->d.max_groups * kHypPerBlock)
+        return MVS_ERR_INVALID_ARG;
+    const size_t Hp = (size_t)b->d.max_groups * kHypPerBlock;
+    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(b->ctx, hipMemcpy(F_out, b->d.hyp_F + (size_t)pair * Hp * 9, (size_t)n_hyp * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    if (ok_out)
+        HIP_TRY(b->ctx, hipMemcpy(ok_out, b->d.hyp_okf + (size_t)pair * Hp, (size_t)n_hyp, hipMemcpyDeviceToHost));
+    return MVS_OK;
+}
 #endif  // MVS_DEBUG_HOOKS
 
 const char *mvs_status_str(mvs_status s)

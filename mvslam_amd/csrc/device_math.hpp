@@ -310,6 +310,249 @@ MVS_DEV void select_row(const double (&Mx)[N][N], int row, double (&out)[N])
     }
 }
 
+// ---------------------------------------------------------------------------------
+// A / V wavefront pair (ransac_solve_av_kernel).  The 9x9 solve of one hypothesis per lane needs A^T (81) + V^T (81)
+// doubles = 324 registers: one wavefront per SIMD, a third of V^T parked in AGPRs, ~50 accumulator moves per rotation,
+// and at one wave per SIMD every instruction of any kind costs a full issue slot.  Split by ROLE instead: the A-wave
+// owns A^T, decides and computes every rotation (c, s) exactly as jacobi_pair does and applies it to A^T; the V-wave
+// (same lanes = same hypotheses, same SIMD) owns V^T and applies the SAME (c, s) to it.  Each fits in 256 registers,
+// so both are resident on the SIMD: two waves per SIMD, no AGPR traffic, and the V-wave's 36 fp64 instructions per
+// rotation issue in the shadow of the A-wave's dependent sqrt / div chains.  Every rotation is the same operation on
+// the same operands in the same order as in the single-wave form: bit-identical results.
+//
+// Channel (LDS, one per pair): a ring of kAvRing slots, slot = visit number mod kAvRing.  Per (i, j) visit the A-wave
+// writes (c, s) of its rotating lanes, then the 64-bit mask of rotating lanes, then the slot's sequence number
+// (release); the V-wave polls the sequence number (acquire), reads the mask and, where set, (c, s).  Both walk the
+// same static (i, j) order; the V-wave derives the end of the loop from the masks (a sweep without any rotation).
+// LDS operations of one wavefront execute in order, so data -> mask -> sequence needs no further fence than the
+// compiler-level release / acquire.  Every spin is bounded: a stuck partner raises `abort`, both leave, the
+// hypotheses are reported as failed -- the grid always drains.
+constexpr int kAvRing = 8;
+constexpr unsigned kAvSpinLimit = 1u << 22;
+
+typedef double av_dbl2 __attribute__((ext_vector_type(2)));   // plain vector type: volatile LDS accesses (ds_*_b128)
+
+struct AvChannel {
+    av_dbl2 cs[kAvRing][64];
+    unsigned long long mask[kAvRing];
+    unsigned seq[kAvRing];
+    unsigned cons;     // visits the V-wave has consumed (published every 4th visit)
+    unsigned abort;
+    unsigned fin_a, fin_v;
+    int tag8[64];
+    double f[9][64];
+};
+
+// LDS operations of one wavefront are executed in program order by the LDS unit, so "data, then mask, then sequence
+// number" needs no s_waitcnt between the stores: plain volatile accesses plus a compiler barrier (an atomic release
+// store would drain lgkmcnt before every sequence-number write: ~250 stalls of an LDS round trip per hypothesis)
+MVS_DEV unsigned av_load(const unsigned *p)
+{
+    const unsigned v = *(const volatile unsigned *)p;
+    asm volatile("" ::: "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+MVS_DEV void av_store(unsigned *p, unsigned v)
+{
+    asm volatile("" ::: "memory");
+    *(volatile unsigned *)p = v;
+}
+// wait until *p - want >= 0 (wrap-safe); false = gave up (abort raised).  SLEEP: s_sleep argument between polls (x 64
+// clocks): the V-wave has ~400 clocks of slack per visit, every poll costs a VALU slot (v_readfirstlane)
+template <int SLEEP = 1>
+MVS_DEV bool av_wait_ge(AvChannel &ch, const unsigned *p, unsigned want)
+{
+    unsigned spins = 0;
+#pragma nounroll
+    while ((int)(av_load(p) - want) < 0) {
+        __builtin_amdgcn_s_sleep(SLEEP);
+        if ((++spins & 63u) == 0 && (spins > kAvSpinLimit || av_load(&ch.abort))) {
+            av_store(&ch.abort, 1u);
+            return false;
+        }
+    }
+    return true;
+}
+
+// The 36 (i, j) visits of a sweep are expanded by template recursion: every row index is a compile-time constant, so
+// A^T / V^T stay in registers (with #pragma unroll the outer loop was not unrolled around the spin loops and the
+// matrices were demoted to scratch memory).
+struct AState {
+    double W[9];
+    double qmin;
+    unsigned visit, cons_seen;
+    bool active, alive, changed;
+};
+
+template <int I, int J>
+MVS_DEV void av_A_visit(double (&At)[9][9], AState &st, AvChannel &ch, int lane)
+{
+    double (&Ai)[9] = At[I];
+    double (&Aj)[9] = At[J];
+    double a = st.W[I], b = st.W[J], p = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        p = dfma(Ai[k], Aj[k], p);
+    const double ab = a * b;
+    const double q = p * p;
+    const bool hi = q > dfma(ab, kJacobiE2Hi, kJacobiTau);
+    const bool lo = q < dfma(ab, kJacobiE2Lo, -kJacobiTau);
+    bool rotate = hi;
+    if (__builtin_expect(__any(!hi && !lo), 0))
+        rotate = !(dabs(p) <= kJacobiEps * dsqrt(a * b));
+    rotate = rotate && st.active;
+    const unsigned long long m = __ballot(rotate);
+    const unsigned slot = st.visit & (kAvRing - 1);
+    if (__builtin_expect(st.visit - st.cons_seen >= (unsigned)kAvRing, 0)) {   // ring full as far as this wave knows
+        st.alive = st.alive && av_wait_ge(ch, &ch.cons, st.visit - kAvRing + 1);
+        st.cons_seen = av_load(&ch.cons);
+    }
+    if (rotate) {
+        p *= 2.0;
+        const double beta = a - b;
+        const double g2 = dfma(p, p, beta * beta);
+        const bool neg = beta < 0.0;
+        running_min(st.qmin, q);
+        const double gamma = sqrt_fast(g2);
+        const double t = gamma + dabs(beta);
+        const double num = t * __hiloint2double(neg ? 0x3fe00000 : 0x3ff00000, 0);
+        const double den = gamma * __hiloint2double(neg ? 0x3ff00000 : 0x40000000, 0);
+        const double x = sqrt_fast(div_fast(num, den));
+        const double y = div_fast(p, gamma * x * 2.0);
+        const double c = neg ? y : x;
+        const double s = neg ? x : y;
+        const av_dbl2 csv = {c, s};
+        *(volatile av_dbl2 *)&ch.cs[slot][lane] = csv;
+        a = 0.0;
+        b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            rotate_inplace(Ai[k], Aj[k], c, s);
+            a = dfma(Ai[k], Ai[k], a);
+            b = dfma(Aj[k], Aj[k], b);
+        }
+        st.W[I] = a;
+        st.W[J] = b;
+        st.changed = true;
+    }
+    if (lane == 0) {
+        *(volatile unsigned long long *)&ch.mask[slot] = m;
+        av_store(&ch.seq[slot], st.visit + 1);
+    }
+    ++st.visit;
+    if constexpr (J < 8)
+        av_A_visit<I, J + 1>(At, st, ch, lane);
+    else if constexpr (I < 7)
+        av_A_visit<I + 1, I + 2>(At, st, ch, lane);
+}
+
+// A-wave: jacobi_svd_core<9, 9, INPLACE, FAST, /*HAS_V*/ false, CHEAP> with a wave-uniform sweep loop (a converged
+// lane stays in the loop, inactive: it would not rotate again anyway -- its state no longer changes) and the channel
+// writes.  W ends as the singular values.  Returns false if the partner was lost.
+MVS_DEV bool jacobi_A_wave(double (&At)[9][9], double (&W)[9], AvChannel &ch, int lane, bool &bad)
+{
+    AState st;
+    double wsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double sd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            sd = dfma(At[i][k], At[i][k], sd);
+        st.W[i] = sd;
+        wsum += sd;
+    }
+    st.qmin = 0x1p1000;
+    st.visit = 0;
+    st.cons_seen = 0;
+    st.active = true;
+    st.alive = true;
+    for (int iter = 0; iter < 30; ++iter) {
+        st.changed = false;
+        av_A_visit<0, 1>(At, st, ch, lane);
+        st.active = st.active && st.changed;
+        if (!__any(st.active) || !st.alive)
+            break;
+    }
+    bad = bad || !((st.qmin >= kGuardQMin) && (wsum <= kGuardWSumMax));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double sd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            sd = dfma(At[i][k], At[i][k], sd);
+        W[i] = dsqrt(sd);
+    }
+    return st.alive;
+}
+
+struct VState {
+    unsigned visit;
+    unsigned long long any;
+    bool alive;
+};
+
+template <int I, int J>
+MVS_DEV void av_V_visit(double (&Vt)[9][9], VState &st, AvChannel &ch, int lane)
+{
+    const unsigned slot = st.visit & (kAvRing - 1);
+    st.alive = st.alive && av_wait_ge<1>(ch, &ch.seq[slot], st.visit + 1);
+    const unsigned long long mv = *(const volatile unsigned long long *)&ch.mask[slot];
+    // the builtin returns a SIGNED int: widen through unsigned, or bit 31 smears over the upper half of the mask
+    const unsigned m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mv >> 32));
+    const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mv);
+    const unsigned long long m = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
+    st.any |= m;
+    if (st.alive && ((m >> lane) & 1ull)) {
+        const av_dbl2 cs = *(const volatile av_dbl2 *)&ch.cs[slot][lane];
+        const double c = cs.x, s = cs.y;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            rotate_inplace(Vt[I][k], Vt[J][k], c, s);
+    }
+    ++st.visit;
+    if ((st.visit & 3u) == 0 && lane == 0)
+        av_store(&ch.cons, st.visit);
+    if constexpr (J < 8)
+        av_V_visit<I, J + 1>(Vt, st, ch, lane);
+    else if constexpr (I < 7)
+        av_V_visit<I + 1, I + 2>(Vt, st, ch, lane);
+}
+
+// V-wave: follows the A-wave's rotations on V^T (initialised to the identity here), then hands back the row of V^T the
+// A-wave names (the right singular vector of the smallest singular value).
+MVS_DEV void jacobi_V_wave(AvChannel &ch, int lane)
+{
+    double Vt[9][9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            Vt[i][k] = (i == k) ? 1.0 : 0.0;
+    VState st;
+    st.visit = 0;
+    st.alive = true;
+    for (int iter = 0; iter < 30; ++iter) {
+        st.any = 0;
+        av_V_visit<0, 1>(Vt, st, ch, lane);
+        if (st.any == 0 || !st.alive)
+            break;
+    }
+    if (lane == 0)
+        av_store(&ch.cons, st.visit + kAvRing);   // nothing left to wait for on the A side
+    if (!(st.alive && av_wait_ge(ch, &ch.fin_a, 1u)))
+        return;
+    const int row = ch.tag8[lane];
+    double f[9];
+    select_row<9>(Vt, row, f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        ch.f[k][lane] = f[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+        av_store(&ch.fin_v, 1u);
+}
+
 // Null vector of a symmetric 9x9 matrix B (= A^T A): last row of vt of cv::SVDecomp(B).
 // HAS_V = false: TIMING EXPERIMENT ONLY (V is never rotated, the result is meaningless)
 template <bool INPLACE, bool FAST, bool HAS_V = true, bool CHEAP = false>
@@ -534,44 +777,44 @@ MVS_DEV bool normalise8(const double (&px)[8], const double (&py)[8], double (&n
     return ok;
 }
 
-// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences (flag + recompute);
-// 128 (with 32) = sqrt-free convergence test, range record instead of per-operand flags, selected power-of-two factors
-template <int VAR>
-MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
-                         double (&F)[9], unsigned &rot9, unsigned &pairs9, bool &bad)
-{
-    double f[9];
+struct EightNorm {   // the two Hartley normalisations of one sample
     double s1, s2, m1x, m1y, m2x, m2y;
-    bool ok;
-    {
-        double a1[8], b1[8], a2[8], b2[8];
-        ok = normalise8(x1, y1, a1, b1, s1, m1x, m1y);
-        ok = normalise8(x2, y2, a2, b2, s2, m2x, m2y) && ok;
-        // design matrix rows [x2x1, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1]  (:78-87)
-        double A[8][9];
+};
+
+// front half of find_fundamental_matrix: normalise both sets (:18-54), design matrix (:78-87), A^T A (:104-111)
+MVS_DEV bool eight_point_front(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
+                               double (&At)[9][9], EightNorm &nm)
+{
+    double a1[8], b1[8], a2[8], b2[8];
+    bool ok = normalise8(x1, y1, a1, b1, nm.s1, nm.m1x, nm.m1y);
+    ok = normalise8(x2, y2, a2, b2, nm.s2, nm.m2x, nm.m2y) && ok;
+    // design matrix rows [x2x1, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1]  (:78-87)
+    double A[8][9];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            A[i][0] = a2[i] * a1[i]; A[i][1] = a2[i] * b1[i]; A[i][2] = a2[i];
-            A[i][3] = b2[i] * a1[i]; A[i][4] = b2[i] * b1[i]; A[i][5] = b2[i];
-            A[i][6] = a1[i];         A[i][7] = b1[i];         A[i][8] = 1.0;
-        }
-        // A^T A, sequential k, separate mul / add (:104-111); symmetric by construction
-        double At[9][9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-#pragma unroll
-            for (int j = i; j < 9; ++j) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    acc += A[k][i] * A[k][j];
-                At[i][j] = acc;
-                At[j][i] = acc;
-            }
-        }
-        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0, (VAR & 256) == 0, (VAR & 128) != 0>(At, f, rot9, pairs9, bad);
+    for (int i = 0; i < 8; ++i) {
+        A[i][0] = a2[i] * a1[i]; A[i][1] = a2[i] * b1[i]; A[i][2] = a2[i];
+        A[i][3] = b2[i] * a1[i]; A[i][4] = b2[i] * b1[i]; A[i][5] = b2[i];
+        A[i][6] = a1[i];         A[i][7] = b1[i];         A[i][8] = 1.0;
     }
-    // rank-2 enforcement (:127-136): F = u diag(w0, w1, 0) vt
+    // A^T A, sequential k, separate mul / add (:104-111); symmetric by construction
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int j = i; j < 9; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                acc += A[k][i] * A[k][j];
+            At[i][j] = acc;
+            At[j][i] = acc;
+        }
+    }
+    return ok;
+}
+
+// back half: rank-2 enforcement (:127-136) and de-normalisation (:245) of the null vector f
+MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double (&F)[9])
+{
     double Fn[3][3];
     {
         double Fp[3][3] = {{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}};
@@ -586,8 +829,9 @@ MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const dou
                 Fn[i][j] = a * Vt[0][j] + b * Vt[1][j];
         }
     }
-    // de-normalise (:245): F = T2^T Fn T1, T = [s 0 -m0 s; 0 s -m1 s; 0 0 1]
-    const double tx1 = -m1x * s1, ty1 = -m1y * s1, tx2 = -m2x * s2, ty2 = -m2y * s2;
+    // F = T2^T Fn T1, T = [s 0 -m0 s; 0 s -m1 s; 0 0 1]
+    const double s1 = nm.s1, s2 = nm.s2;
+    const double tx1 = -nm.m1x * s1, ty1 = -nm.m1y * s1, tx2 = -nm.m2x * s2, ty2 = -nm.m2y * s2;
     double G[3][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -601,6 +845,23 @@ MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const dou
         F[i * 3 + 1] = G[i][1] * s1;
         F[i * 3 + 2] = (G[i][0] * tx1 + G[i][1] * ty1) + G[i][2];
     }
+}
+
+// VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences (flag + recompute);
+// 128 (with 32) = sqrt-free convergence test, range record instead of per-operand flags, selected power-of-two factors
+template <int VAR>
+MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
+                         double (&F)[9], unsigned &rot9, unsigned &pairs9, bool &bad)
+{
+    double f[9];
+    EightNorm nm;
+    bool ok;
+    {
+        double At[9][9];
+        ok = eight_point_front(x1, y1, x2, y2, At, nm);
+        svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0, (VAR & 256) == 0, (VAR & 128) != 0>(At, f, rot9, pairs9, bad);
+    }
+    eight_point_back(f, nm, F);
     return ok;
 }
 

@@ -546,6 +546,90 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams
     }
 }
 
+// ---- A / V wavefront pairs (device_math.hpp: jacobi_A_wave / jacobi_V_wave) --------------------------------------------
+// grid (G, P) as ransac_solve_kernel, but 512 threads: wavefronts 0..3 solve the 256 hypotheses of the group (A role),
+// wavefronts 4..7 carry V^T of the same lanes (V role).  Wavefront w and w + 4 share a SIMD (wavefronts of a workgroup
+// are dealt round-robin to the four SIMDs), each needs <= 256 registers, so the SIMD holds two waves instead of one and
+// nothing lives in AGPRs.  Same F bits as ransac_solve_kernel (the rotations are the same operations in the same
+// order); a violated fast-math guard or a lost partner falls back to the single-wave solve of that wavefront.
+template <int VAR>
+__global__ __launch_bounds__(512, 1) void ransac_solve_av_kernel(BatchDev b, RunParams rp)
+{
+    __shared__ AvChannel s_ch[4];
+    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int M = b.M[pair];
+    if (M < 8)
+        return;
+    const int wave = tid >> 6, lane = tid & 63, role = wave >> 2, pidx = wave & 3;
+    if (tid < 4) {
+        AvChannel &c = s_ch[tid];
+#pragma unroll
+        for (int k = 0; k < kAvRing; ++k)
+            c.seq[k] = 0u;
+        c.cons = 0u;
+        c.abort = 0u;
+        c.fin_a = 0u;
+        c.fin_v = 0u;
+    }
+    __syncthreads();
+    AvChannel &ch = s_ch[pidx];
+    if (role == 1) {
+        jacobi_V_wave(ch, lane);
+        return;
+    }
+    const int H = rp.num_hypotheses;
+    const int ta = pidx * 64 + lane;
+    const uint32_t h = (uint32_t)g * kHypPerBlock + ta;
+    const uint32_t hh = h < (uint32_t)H ? h : (uint32_t)(H - 1);
+    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+    double F[9];
+    bool bad = false, ok, alive;
+    {
+        int idx[8];
+        sample8(seed, hh, M, rp.sampler, idx);
+        double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
+            x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
+        }
+        EightNorm nm;
+        double f[9];
+        {
+            double At[9][9], W[9];
+            ok = eight_point_front(x1, y1, x2, y2, At, nm);
+            alive = jacobi_A_wave(At, W, ch, lane, bad);
+            int tag[9];
+            sort_tags_desc<9>(W, tag);
+            ch.tag8[lane] = tag[8];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            av_store(&ch.fin_a, 1u);
+        alive = alive && av_wait_ge(ch, &ch.fin_v, 1u);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            f[k] = ch.f[k][lane];
+        eight_point_back(f, nm, F);
+    }
+    if (__builtin_expect(__any(bad) || !alive, 0)) {
+        // a fast-math guard was violated (never for Hartley-normalised samples) or the partner was lost: this wavefront
+        // recomputes its 64 hypotheses alone with the compiler's fully scaled sqrt / div (spills to scratch: cold)
+        unsigned rot = 0, pairs = 0;
+        bool bad2 = false;
+        ok = solve_hypothesis<16>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad2);
+    }
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        Fo[k] = F[k];
+    b.hyp_okf[(size_t)pair * Hp + h] = ok ? 1 : 0;
+    if (g == 0 && tid == 0)
+        b.bound[pair] = 0;
+}
+
 // ---- pruned scoring: ransac_count_kernel + ransac_select_kernel ------------------------------------------------------
 // The reference keeps the hypothesis with the most inliers, ties by the smaller residual sum, then by the smaller index
 // (estimator-RANSAC.cpp:76-84).  A hypothesis whose count can no longer reach a count that SOME hypothesis of the pair
@@ -1454,6 +1538,14 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
         } else {
             hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
             hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
+        }
+        break;
+    case 3832:  // 1784 with the solve as A / V wavefront pairs
+        if (!split_ok || b.hyp_count) {
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+        } else {
+            hipLaunchKernelGGL((ransac_solve_av_kernel<240>), grid, dim3(512), 0, stream, b, rp);
+            launch_pruned_scoring(b, rp, n_active, stream);
         }
         break;
     case 1656:  // 632 + pruned scoring
