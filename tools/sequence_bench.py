@@ -67,9 +67,8 @@ print(json.dumps({
     # Ferrari quartic with 64 bisections, <= 4 poses from two triangle frames, 4th-point selection) + 28 per
     # (hypothesis, correspondence) evaluation (11 fma + 2 mul + compare + count).  With the reference's 100 hypotheses
     # a track is ONE workgroup with 100 of 256 lanes live and ~n sequential point evaluations per lane behind a
-    # ~700-instruction dependent bisection chain: the launch is latency / occupancy bound (one short workgroup per
-    # track, <= 1000 workgroups), two orders of magnitude under the fp64 roof -- by construction of the reference's
-    # parameters, not of the kernel (at 4096 hypotheses per track the same kernel reaches the figure in `pnp_roofline_4k`)
+    # ~700-instruction dependent bisection chain: the launch is latency / lane-occupancy bound (one short workgroup
+    # per track, <= 1000 workgroups) -- by construction of the reference's parameter, not of the kernel
     "pnp_roofline": {"bound": "latency (one 100-lane workgroup per track)", "unit": "TFLOP/s", "peak": 78.6,
                      "flops_per_launch": int(sum(args.pnp_hyp * (1900 + 28 * int(n)) for n in tr["n_corr"])),
                      "launch_ms": round(stage_ms["pnp"], 4),
