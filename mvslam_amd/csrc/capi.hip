@@ -458,7 +458,11 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
             mvs_batch_destroy(b);
             return MVS_ERR_HIP;
         }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        ctx->err = "mvs_batch_create: hipStreamSynchronize failed";
+        mvs_batch_destroy(b);
+        return MVS_ERR_HIP;
+    }
     *out = b;
     return MVS_OK;
 }
@@ -1295,9 +1299,18 @@ mvs_status mvs_seq_create(mvs_ctx *ctx, int n_frames, int max_kp, int desc_bytes
     std::vector<int64_t> g(T);
     for (size_t i = 0; i < T; ++i)
         g[i] = (int64_t)i;
-    HIP_TRY(ctx, hipMemcpy(gidx, g.data(), T * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(n_corr, 0, T * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMemset(po, 0, T * sizeof(PnpOut)));
+    {   // on the ctx stream (it is non-blocking: NULL-stream copies would not be ordered against the kernels that write
+        // these buffers later), and with the partly built object released on failure
+        hipError_t e = hipMemcpyAsync(gidx, g.data(), T * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(n_corr, 0, T * sizeof(int32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(po, 0, T * sizeof(PnpOut), ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // `g` lives on this frame
+        if (e != hipSuccess) {
+            ctx->err = std::string("mvs_seq_create: ") + hipGetErrorString(e);
+            mvs_seq_destroy(q);
+            return MVS_ERR_HIP;
+        }
+    }
     const BatchDev &d = q->batch->d;
     q->join.n_tracks = q->n_tracks;
     q->join.max_kp = d.max_kp;

@@ -72,6 +72,22 @@ MVS_DEV double sqrt_fast(double x)
     g = dfma(d, h, g);
     return (x == 0.0 || x == __builtin_inf()) ? x : g;
 }
+// sqrt_fast for operands known to be finite and non-zero (inside a guarded range): without the final 0 / inf select
+// (v_cmp_class + two v_cndmask).  The result for such x is the same correctly rounded root.
+MVS_DEV double sqrt_fast_nz(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = dfma(-h, g, 0.5);
+    g = dfma(g, r, g);
+    h = dfma(h, r, h);
+    double d = dfma(-g, g, x);
+    g = dfma(d, h, g);
+    d = dfma(-g, g, x);
+    g = dfma(d, h, g);
+    return g;
+}
 MVS_DEV double div_fast(double n, double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -160,7 +176,9 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
             } else {
                 bad = bad || !((g2 >= 0x1p-400) && (g2 <= 0x1p400) && (dabs(p) >= 0x1p-200));
             }
-            const double gamma = sqrt_fast(g2);
+            // CHEAP: g2 >= 2^-400 and num / den in [1/2, 1] are guarded (a violated guard recomputes the wavefront with
+            // the full sequences), so neither root needs sqrt_fast's zero / infinity select
+            const double gamma = CHEAP ? sqrt_fast_nz(g2) : sqrt_fast(g2);
             if (CHEAP) {
                 // gamma - beta == gamma + |beta| for beta < 0, and the halving / doubling are exact inside the guard:
                 // one add and one multiply by a selected power of two replace two candidates and a 64-bit select
@@ -171,7 +189,7 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
                 num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
                 den = neg ? gamma : gamma * 2.0;
             }
-            x = sqrt_fast(div_fast(num, den));
+            x = CHEAP ? sqrt_fast_nz(div_fast(num, den)) : sqrt_fast(div_fast(num, den));
             y = div_fast(p, gamma * x * 2.0);
         } else {
             const double gamma = dsqrt(g2);
@@ -413,11 +431,11 @@ MVS_DEV void av_A_visit(double (&At)[9][9], AState &st, AvChannel &ch, int lane)
         const double g2 = dfma(p, p, beta * beta);
         const bool neg = beta < 0.0;
         running_min(st.qmin, q);
-        const double gamma = sqrt_fast(g2);
+        const double gamma = sqrt_fast_nz(g2);
         const double t = gamma + dabs(beta);
         const double num = t * __hiloint2double(neg ? 0x3fe00000 : 0x3ff00000, 0);
         const double den = gamma * __hiloint2double(neg ? 0x3ff00000 : 0x40000000, 0);
-        const double x = sqrt_fast(div_fast(num, den));
+        const double x = sqrt_fast_nz(div_fast(num, den));
         const double y = div_fast(p, gamma * x * 2.0);
         const double c = neg ? y : x;
         const double s = neg ? x : y;

@@ -729,9 +729,14 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
         for (int k = 0; k < kCntSlots; ++k)
             alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        double2 pa_n = L1[0], pb_n = L2[0];
         for (int blk = 0; blk < nblk && alive; ++blk) {
-            const double2 pa = L1[blk * 64], pb = L2[blk * 64];
-            const double4 p = make_double4(pa.x, pa.y, pb.x, pb.y);
+            const double4 p = make_double4(pa_n.x, pa_n.y, pb_n.x, pb_n.y);
+            // the next block's point is requested before this block's arithmetic (the uniform branches below keep the
+            // compiler from hoisting it): the LDS round trip hides under the four slots
+            const int nb = min(blk + 1, nblk - 1);
+            pa_n = L1[nb * 64];
+            pb_n = L2[nb * 64];
             const int rem = max(M - (blk + 1) * 64, 0);
             if (alive & 1u) {
                 c0 += count_block(F0, p, thr);
