@@ -658,7 +658,11 @@ __device__ __forceinline__ int count_block(const double (&F)[9], const double4 &
     return __popcll(__ballot(r < thr));   // NaN (padding lanes, degenerate F) compares false
 }
 
-template <int kCntThreads>
+// PPL = points per lane and block (1: 64-point blocks, 2: 128-point blocks).  With two points per lane the scalar work per
+// (hypothesis, block) -- count add, exit test, slot skip: the scalar unit is shared by the four SIMDs and was ~70 % busy
+// with 8 scalar instructions per 9 vector ones -- is amortised over 18 vector instructions; a dying hypothesis is noticed
+// up to 64 points later.
+template <int kCntThreads, int PPL>
 __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, RunParams rp, int wg_per_pair)
 {
     // two planes of double2, [nblk * 64] each: (x1, y1) and (x2, y2), NaN padded.  A lane reads one element of each with
@@ -672,13 +676,14 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
         return;
     const int H = rp.num_hypotheses;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const int nblk = (M + 63) >> 6;
+    constexpr int BW = 64 * PPL;                  // points per block
+    const int nblk = (M + BW - 1) / BW;
     double2 *s_p1 = reinterpret_cast<double2 *>(s_cpts);
-    double2 *s_p2 = s_p1 + nblk * 64;
+    double2 *s_p2 = s_p1 + nblk * BW;
     {
         const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
         const double qnan = __builtin_nan("");
-        for (int i = tid; i < nblk * 64; i += kCntThreads) {
+        for (int i = tid; i < nblk * BW; i += kCntThreads) {
             const double4 p = i < M ? src[i] : make_double4(qnan, qnan, qnan, qnan);
             s_p1[i] = make_double2(p.x, p.y);
             s_p2[i] = make_double2(p.z, p.w);
@@ -729,30 +734,49 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
         for (int k = 0; k < kCntSlots; ++k)
             alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        double2 pa_n = L1[0], pb_n = L2[0];
+        double2 pa_n[PPL], pb_n[PPL];
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            pa_n[u] = L1[u * 64];
+            pb_n[u] = L2[u * 64];
+        }
         for (int blk = 0; blk < nblk && alive; ++blk) {
-            const double4 p = make_double4(pa_n.x, pa_n.y, pb_n.x, pb_n.y);
-            // the next block's point is requested before this block's arithmetic (the uniform branches below keep the
-            // compiler from hoisting it): the LDS round trip hides under the four slots
-            const int nb = min(blk + 1, nblk - 1);
-            pa_n = L1[nb * 64];
-            pb_n = L2[nb * 64];
-            const int rem = max(M - (blk + 1) * 64, 0);
+            double4 p[PPL];
+#pragma unroll
+            for (int u = 0; u < PPL; ++u)
+                p[u] = make_double4(pa_n[u].x, pa_n[u].y, pb_n[u].x, pb_n[u].y);
+            // the next block's points are requested before this block's arithmetic (the uniform branches below keep
+            // the compiler from hoisting the loads): the LDS round trip hides under the four slots
+            const int nb = min(blk + 1, nblk - 1) * BW;
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) {
+                pa_n[u] = L1[nb + u * 64];
+                pb_n[u] = L2[nb + u * 64];
+            }
+            const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
             if (alive & 1u) {
-                c0 += count_block(F0, p, thr);
-                if (c0 + rem < B) alive &= ~1u;
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c0 += count_block(F0, p[u], thr);
+                if (c0 < need) alive &= ~1u;
             }
             if (alive & 2u) {
-                c1 += count_block(F1, p, thr);
-                if (c1 + rem < B) alive &= ~2u;
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c1 += count_block(F1, p[u], thr);
+                if (c1 < need) alive &= ~2u;
             }
             if (alive & 4u) {
-                c2 += count_block(F2, p, thr);
-                if (c2 + rem < B) alive &= ~4u;
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c2 += count_block(F2, p[u], thr);
+                if (c2 < need) alive &= ~4u;
             }
             if (alive & 8u) {
-                c3 += count_block(F3, p, thr);
-                if (c3 + rem < B) alive &= ~8u;
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c3 += count_block(F3, p[u], thr);
+                if (c3 < need) alive &= ~8u;
             }
         }
         // a slot that is still alive has seen every point: its count is final
@@ -1480,42 +1504,46 @@ static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid,
         hipLaunchKernelGGL((ransac_kernel<false, VAR>), grid, block, 0, stream, b, rp);
 }
 
-static int cnt_threads()
+static int env_int(const char *name, int dflt)
 {
-    static int t = 0;
-    if (!t) {
-        const char *e = getenv("MVS_CNT_THREADS");   // experiment knob (512 / 1024)
-        t = (e && atoi(e) == 512) ? 512 : 1024;
-    }
-    return t;
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
 {
     // enough workgroups to fill the chip for a small launch, few enough that every wavefront works through many
     // groups of four hypotheses (the bound only helps once the first groups have finished)
-    const int threads = cnt_threads();
+    static const int threads = env_int("MVS_CNT_THREADS", 1024) == 512 ? 512 : 1024;   // experiment knobs
+    static const int ppl = env_int("MVS_CNT_PPL", 2) == 1 ? 1 : 2;
     const int n_groups4 = (rp.num_hypotheses + kCntSlots - 1) / kCntSlots;
     const int wpw = threads / 64;
     int wg = (512 + n_active - 1) / n_active;
     wg = std::max(wg, 4);
     wg = std::min(wg, std::max(1, (n_groups4 + wpw - 1) / wpw));
-    const size_t lds_cnt = (size_t)((b.max_kp + 63) / 64) * 64 * 4 * sizeof(double);
+    const int bw = 64 * ppl;
+    const size_t lds_cnt = (size_t)((b.max_kp + bw - 1) / bw) * bw * 4 * sizeof(double);
     const size_t lds_sel = (size_t)b.max_kp * 4 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel<512>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_count_kernel<1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ransac_select_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
+        const void *fns[] = {reinterpret_cast<const void *>(ransac_count_kernel<512, 1>),
+                             reinterpret_cast<const void *>(ransac_count_kernel<1024, 1>),
+                             reinterpret_cast<const void *>(ransac_count_kernel<512, 2>),
+                             reinterpret_cast<const void *>(ransac_count_kernel<1024, 2>),
+                             reinterpret_cast<const void *>(ransac_select_kernel)};
+        for (const void *f : fns)
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
         attr_set = true;
     }
-    if (threads == 512)
-        hipLaunchKernelGGL(ransac_count_kernel<512>, dim3(wg, n_active), dim3(512), lds_cnt, stream, b, rp, wg);
+    const dim3 grid(wg, n_active);
+    if (threads == 512 && ppl == 1)
+        hipLaunchKernelGGL((ransac_count_kernel<512, 1>), grid, dim3(512), lds_cnt, stream, b, rp, wg);
+    else if (threads == 512)
+        hipLaunchKernelGGL((ransac_count_kernel<512, 2>), grid, dim3(512), lds_cnt, stream, b, rp, wg);
+    else if (ppl == 1)
+        hipLaunchKernelGGL((ransac_count_kernel<1024, 1>), grid, dim3(1024), lds_cnt, stream, b, rp, wg);
     else
-        hipLaunchKernelGGL(ransac_count_kernel<1024>, dim3(wg, n_active), dim3(1024), lds_cnt, stream, b, rp, wg);
+        hipLaunchKernelGGL((ransac_count_kernel<1024, 2>), grid, dim3(1024), lds_cnt, stream, b, rp, wg);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
