@@ -393,6 +393,28 @@ def test_batch_capacity_and_odd_sizes(ctx, n_kp, H, desc_bytes):
         assert (out["results"]["n_matches"] > 2048).all()
 
 
+@pytest.mark.parametrize("n_kp,H,desc_bytes,count,thr", [(4096, 300, 32, 3, 1e-2), (1000, 1, 32, 4, 1e-2), (777, 257, 16, 3, 1e-2),
+                                                         (513, 1025, 64, 5, 1e-2), (300, 3, 32, 3, 1e-2), (640, 2050, 32, 4, 0.0)])
+def test_pruned_scoring_path_capacity_and_odd_sizes(ctx, n_kp, H, desc_bytes, count, thr):
+    """The same edge sizes through the solve -> count -> select launches (batches of three or more pairs take that path;
+    one or two pairs stay on the fused kernel): maximum capacity (128 KB of LDS per workgroup), hypothesis counts that
+    are not multiples of 4 or 256 (partial groups of four, padded lanes), a single hypothesis, the reference threshold
+    (hundreds of ties through the lane-per-hypothesis path of ransac_select)."""
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=4711, max_error_sq=thr)
+    data = synth.make_batch(900, count, n_kp=n_kp, desc_bytes=desc_bytes, common_frac=0.9)
+    n1, n2 = data["n1"].copy(), data["n2"].copy()
+    if count >= 4:
+        n2[1] = 5                      # a pair with fewer than 8 matches in the middle of the batch
+    b = capi.Batch(ctx, count, n_kp, desc_bytes)
+    b.upload(0, data["desc1"], data["kp1"], n1, data["desc2"], data["kp2"], n2, data["K"], data["global_index"])
+    b.run(prm)
+    out = b.download()
+    b.close()
+    _check_batch_against_oracle(data, out, prm, n1, n2)
+    if count >= 4:
+        assert not out["results"]["valid"][1] and out["results"]["best_hyp"][1] == -1
+
+
 def test_batch_capacity_errors(ctx):
     with pytest.raises(capi.MvsError):
         capi.Batch(ctx, 1, 4097, 32)          # beyond the LDS-resident capacity
