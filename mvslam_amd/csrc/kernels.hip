@@ -1553,7 +1553,8 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     const dim3 grid(G, n_active), block(kHypPerBlock);
     // the instrumented replay and the per-hypothesis tables (every count AND every residual) stay on the
     // hypothesis-per-lane kernels; so does a launch of one or two pairs (latency: fewer launches)
-    const bool split_ok = !stats && b.hyp_F && n_active >= 3;
+    static const int split_min = env_int("MVS_SPLIT_MIN_PAIRS", 3);   // experiment knob
+    const bool split_ok = !stats && b.hyp_F && n_active >= split_min;
     switch (g_ransac_variant) {
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
     case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream); break;   // timing experiment: no V rotations
@@ -1584,7 +1585,12 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     case 1656:  // 632 + pruned scoring
     case 1784:  // 760 + pruned scoring
         if (!split_ok) {
-            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+            // one or two pairs, per-hypothesis tables: the fused kernel (with the same sqrt-free pair step for 1784);
+            // the instrumented replay stays on variant 120, whose counters the flop model was derived with
+            if (g_ransac_variant == 1784 && !stats)
+                launch_ransac_var<248>(b, rp, grid, block, false, stream);
+            else
+                launch_ransac_var<120>(b, rp, grid, block, stats, stream);
         } else {
             if (g_ransac_variant == 1784)
                 hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
