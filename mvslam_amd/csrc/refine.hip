@@ -204,12 +204,16 @@ struct Prob {
 
 // linearise point i at (R, t, p): Hpp (+ prior), gp, Hcp; when ACC, the frames' own Hcc / gc blocks and the cost go
 // straight into the thread's accumulators
-template <int F, bool ACC>
+// [LO, HI): the slice of the accumulator vector {S packed, b, cost} this call adds to (build_schur accumulates the
+// vector in two passes over the points: all 91 accumulators at once do not fit in the register file beside the
+// linearisation temporaries and went to scratch memory)
+template <int F, bool ACC, int LO = 0, int HI = Dims<F>::NV>
 __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
                                                 const double (&p)[3], int i, double (&Hpp)[6], double (&gp)[3],
                                                 double (&Hcp)[6 * F][3], double (&acc)[Dims<F>::NV])
 {
     constexpr int NL = Dims<F>::NL, NC = Dims<F>::NC;
+    auto in = [](int idx) { return idx >= LO && idx < HI; };
     double L[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
@@ -246,9 +250,11 @@ __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (
             if (ACC) {
 #pragma unroll
                 for (int b = 0; b <= a; ++b)
-                    acc[lidx(6 * f + a, 6 * f + b)] =
-                        acc[lidx(6 * f + a, 6 * f + b)] + fd2(Jc[a], WJc[b], Jc[6 + a], WJc[6 + b]);
-                acc[NL + 6 * f + a] = acc[NL + 6 * f + a] - fd2(Jc[a], wr0, Jc[6 + a], wr1);
+                    if (in(lidx(6 * f + a, 6 * f + b)))
+                        acc[lidx(6 * f + a, 6 * f + b)] =
+                            acc[lidx(6 * f + a, 6 * f + b)] + fd2(Jc[a], WJc[b], Jc[6 + a], WJc[6 + b]);
+                if (in(NL + 6 * f + a))
+                    acc[NL + 6 * f + a] = acc[NL + 6 * f + a] - fd2(Jc[a], wr0, Jc[6 + a], wr1);
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -264,7 +270,7 @@ __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (
         for (int k = 0; k < 3; ++k)
             gp[k] = fma(Jp[3 + k], wr1, fma(Jp[k], wr0, gp[k]));
     }
-    if (ACC)
+    if (ACC && in(NL + NC))
         acc[NL + NC] = acc[NL + NC] + cost;
 }
 
@@ -383,20 +389,17 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[N * (N + 1) / 2], 
     }
 }
 
-// reduced camera system at (R, t, pts) with damping lam.  On return acc = {S packed, b, cost} on every thread.
-template <int F>
-__device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &cfg, const double (&R0)[F][9],
-                                            const double (&t0)[F][3], const double (&R)[F][9], const double (&t)[F][3],
-                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
+// one pass over the thread's points adding the entries [LO, HI) of {S packed, b, cost} (per-thread partial sums)
+template <int F, int LO, int HI>
+__device__ __forceinline__ void schur_pass(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
+                                           const double *pts, double lam, double (&acc)[Dims<F>::NV])
 {
-    constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-        acc[k] = 0.0;
+    constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL;
+    auto in = [](int idx) { return idx >= LO && idx < HI; };
     for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
         const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
         double Hpp[6], gp[3], Hcp[NC][3];
-        point_linearize<F, true>(P, R, t, p, i, Hpp, gp, Hcp, acc);
+        point_linearize<F, true, LO, HI>(P, R, t, p, i, Hpp, gp, Hcp, acc);
         const double Hd[6] = {Hpp[0] + lam, Hpp[1], Hpp[2], Hpp[3] + lam, Hpp[4], Hpp[5] + lam};
         double Pi[6];
         sym3_inverse(Hd, Pi);
@@ -407,11 +410,59 @@ __device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &c
             const double y2 = fd3(Hcp[a][0], Pi[2], Hcp[a][1], Pi[4], Hcp[a][2], Pi[5]);
 #pragma unroll
             for (int c = 0; c <= a; ++c)
-                acc[lidx(a, c)] = fma(-y2, Hcp[c][2], fma(-y1, Hcp[c][1], fma(-y0, Hcp[c][0], acc[lidx(a, c)])));
-            acc[NL + a] = fma(y2, gp[2], fma(y1, gp[1], fma(y0, gp[0], acc[NL + a])));
+                if (in(lidx(a, c)))
+                    acc[lidx(a, c)] = fma(-y2, Hcp[c][2], fma(-y1, Hcp[c][1], fma(-y0, Hcp[c][0], acc[lidx(a, c)])));
+            if (in(NL + a))
+                acc[NL + a] = fma(y2, gp[2], fma(y1, gp[1], fma(y0, gp[0], acc[NL + a])));
         }
     }
-    block_reduce<NV>(acc, red);
+}
+
+// accumulate, reduce over the workgroup and park in LDS (red[4 NV + k]) the entries [LO, HI)
+template <int F, int LO, int HI>
+__device__ __forceinline__ void schur_slice(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
+                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
+{
+    constexpr int NV = Dims<F>::NV;
+    schur_pass<F, LO, HI>(P, R, t, pts, lam, acc);
+    double part[HI - LO];
+#pragma unroll
+    for (int k = 0; k < HI - LO; ++k)
+        part[k] = acc[LO + k];
+    block_reduce<HI - LO>(part, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < HI - LO; ++k)
+            red[4 * NV + LO + k] = part[k];
+    }
+}
+
+// reduced camera system at (R, t, pts) with damping lam.  On return acc = {S packed, b, cost} on every thread.
+template <int F>
+__device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &cfg, const double (&R0)[F][9],
+                                            const double (&t0)[F][3], const double (&R)[F][9], const double (&t)[F][3],
+                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
+{
+    constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        acc[k] = 0.0;
+    // several passes over the thread's points, each owning a slice of the accumulator vector (same per-point operations,
+    // same point order per entry, same reduction tree: the sums have the same bits as a single pass); the totals of a
+    // finished slice wait in LDS.  Two frames: rows 0..6 of S | rows 7..9 | rows 10..11, b, cost.
+    if constexpr (F == 2) {
+        schur_slice<F, 0, lidx(7, 0)>(P, R, t, pts, lam, acc, red);
+        schur_slice<F, lidx(7, 0), lidx(10, 0)>(P, R, t, pts, lam, acc, red);
+        schur_slice<F, lidx(10, 0), NV>(P, R, t, pts, lam, acc, red);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            acc[k] = red[4 * NV + k];
+        __syncthreads();   // the next user of `red` must not overtake the reads above
+    } else {
+        schur_pass<F, 0, NV>(P, R, t, pts, lam, acc);
+        block_reduce<NV>(acc, red);
+    }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         double e[6], Jw[9], Jv[9];
@@ -447,7 +498,7 @@ template <int F>
 __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
 {
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
-    __shared__ double red[4 * NV];
+    __shared__ double red[5 * NV];   // 4 wavefront partials + the parked totals of build_schur's first pass
     __shared__ double Sinv[NC * NC];
     const int g = blockIdx.x;
     const RefineCfg &cfg = d.cfg;
