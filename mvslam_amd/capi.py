@@ -370,15 +370,19 @@ class Context:
         return dict(ok=st == MVS_OK, R=R, t=t, inliers=idx[:ni.value].copy(), best_hyp=bh.value)
 
     # VisualFeature::extract(image) for a stack of equally sized grayscale images [B, H, W]
-    def extract(self, images, params=None):
+    def extract(self, images, params=None, out=None):
         images = np.ascontiguousarray(images, dtype=np.uint8)
         if images.ndim == 2:
             images = images[None]
         B, H, W = images.shape
         params = params or default_orb_params()
-        kp = np.zeros((B, params.nfeatures), dtype=KEYPOINT_DTYPE)
-        desc = np.zeros((B, params.nfeatures, 32), dtype=np.uint8)
-        n = np.zeros(B, dtype=np.int32)
+        if out is None:
+            kp = np.zeros((B, params.nfeatures), dtype=KEYPOINT_DTYPE)
+            desc = np.zeros((B, params.nfeatures, 32), dtype=np.uint8)
+            n = np.zeros(B, dtype=np.int32)
+        else:   # caller-owned outputs (e.g. pinned_empty() arrays: the copies become DMA transfers)
+            kp, desc, n = out["kp"], out["desc"], out["n"]
+            assert kp.shape == (B, params.nfeatures) and desc.shape == (B, params.nfeatures, 32) and n.shape == (B,)
         st = lib().mvs_extract(self._h, _ptr(images, C.c_uint8), C.c_int(B), C.c_int(W), C.c_int(H), C.byref(params),
                                kp.ctypes.data_as(C.c_void_p), _ptr(desc, C.c_uint8), _ptr(n, C.c_int32))
         self._check(st, "mvs_extract")
