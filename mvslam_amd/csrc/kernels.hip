@@ -1524,7 +1524,11 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     const int bw = 64 * ppl;
     const size_t lds_cnt = (size_t)((b.max_kp + bw - 1) / bw) * bw * 4 * sizeof(double);
     const size_t lds_sel = (size_t)b.max_kp * 4 * sizeof(double);
-    static bool attr_set = false;
+    // the opt-in to more than 64 KB of dynamic LDS is a per-device function attribute: once per device of this process
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool &attr_set = attr_done[dev & 63];
     if (!attr_set) {
         const void *fns[] = {reinterpret_cast<const void *>(ransac_count_kernel<512, 1>),
                              reinterpret_cast<const void *>(ransac_count_kernel<1024, 1>),
