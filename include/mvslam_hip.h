@@ -163,8 +163,8 @@ typedef struct mvs_pnp_params {
     int32_t min_inliers;    /* 4: the model points of the RANSAC kernel */
     int32_t refit;          /* 0 (default): return the best P3P hypothesis.  1: then minimise the reprojection error over
                                ALL inliers (pose only, points fixed), the refit cv::solvePnPRansac ends with
-                               (pnp-solve.cpp:53-64); the inlier set stays the RANSAC one.  mvs_pnp_solve only: the
-                               batched tracks of a sequence are refined by the caller (mvs_pnp_refine) */
+                               (pnp-solve.cpp:53-64); the inlier set stays the RANSAC one.  Honoured by mvs_pnp_solve and,
+                               batched over all tracks on the device, by mvs_seq_run */
 } mvs_pnp_params;
 mvs_status mvs_pnp_params_default(mvs_pnp_params *p);
 mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *image_uv, int n, const double K[9],

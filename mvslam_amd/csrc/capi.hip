@@ -62,6 +62,8 @@ struct mvs_seq {
     SeqJoinDev join{};
     PnpDev pnp{};
     SeqChainDev chain{};
+    RefineDev refit{};          // pnp_solve's refit over the inliers of every track (mvs_pnp_params.refit), allocated on demand
+    bool refit_ready = false, refit_on = false;
     std::vector<void *> allocs;
 };
 
@@ -125,6 +127,10 @@ static mvs_status up_async(mvs_ctx *ctx, void *dst, const void *src, size_t byte
     HIP_TRY(ctx, hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, ctx->stream));
     return MVS_OK;
 }
+
+// pnp_solve's refit (pnp-solve.cpp:53-64) as a refinement problem: points fixed (sigma 1e-9), no prior on the pose
+constexpr double kRefitPointSigma = 1e-9, kRefitPoseSigma = 1e6;
+static RefineCfg to_cfg(const mvs_refine_params &p, int n_frames);
 
 static RunParams to_run(const mvs_params &p)
 {
@@ -1440,6 +1446,44 @@ static mvs_status seq_prepare(mvs_seq *q, const mvs_params *tv, const mvs_pnp_pa
     q->pnp.min_inliers = pp->min_inliers;
     q->pnp.seed = pp->seed;
     q->pnp.thr2 = pp->reproj_error * pp->reproj_error;
+    q->refit_on = pp->refit != 0;
+    if (q->refit_on && !q->refit_ready) {
+        const size_t T = q->n_tracks, S = q->stride;
+        double *obs0, *oi0, *p0, *pi, *pts, *tmp, *pose;
+        int32_t *m;
+        mvs_refine_result *out;
+        if ((st = seq_alloc(q, &obs0, T * S * 2)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &oi0, T * S * 3)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &p0, T * S * 3)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &pi, T * S * 6)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &pts, T * S * 3)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &tmp, T * S * 3)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &pose, T * 12)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &m, T)) != MVS_OK) return st;
+        if ((st = seq_alloc(q, &out, T)) != MVS_OK) return st;
+        RefineDev &d = q->refit;
+        d = RefineDev{};
+        d.n_problems = (int)T;
+        d.stride = (int)S;
+        d.n_frames = 1;
+        d.m = m;
+        d.K = q->pnp.K;
+        d.pose0 = pose;
+        d.obs[0] = obs0;
+        d.oinfo[0] = oi0;
+        d.pts0 = p0;
+        d.pinfo = pi;
+        d.pts = pts;
+        d.pts_tmp = tmp;
+        d.out = out;
+        q->refit_ready = true;
+    }
+    if (q->refit_on) {
+        mvs_refine_params rp;
+        mvs_refine_params_default(&rp);
+        rp.pose_sigma[0] = rp.pose_sigma[1] = kRefitPoseSigma;
+        q->refit.cfg = to_cfg(rp, 1);
+    }
     return MVS_OK;
 }
 
@@ -1450,6 +1494,8 @@ static mvs_status seq_enqueue(mvs_seq *q, const RunParams &rp)
         return st;
     launch_seq_join(q->join, q->ctx->stream);
     launch_pnp(q->pnp, q->ctx->stream);
+    if (q->refit_on)
+        launch_pnp_refit(q->pnp, q->refit, kRefitPointSigma, q->ctx->stream);
     q->chain.n_corr = q->pnp.n;
     launch_seq_chain(q->chain, q->ctx->stream);
     HIP_TRY(q->ctx, hipGetLastError());
@@ -1518,6 +1564,8 @@ mvs_status mvs_seq_time_stages(mvs_seq *q, const mvs_params *two_view, const mvs
         launch_seq_join(q->join, s);
         HIP_TRY(q->ctx, hipEventRecord(ev[2], s));
         launch_pnp(q->pnp, s);
+        if (q->refit_on)
+            launch_pnp_refit(q->pnp, q->refit, kRefitPointSigma, s);
         HIP_TRY(q->ctx, hipEventRecord(ev[3], s));
         q->chain.n_corr = q->pnp.n;
         launch_seq_chain(q->chain, s);
@@ -1694,11 +1742,11 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
         for (size_t i = 0; i < m; ++i) {
             std::memcpy(&X[3 * i], world_xyz + 3 * (size_t)tmp[i], 3 * sizeof(double));
             std::memcpy(&uv[2 * i], image_uv + 2 * (size_t)tmp[i], 2 * sizeof(double));
-            XC[9 * i] = XC[9 * i + 4] = XC[9 * i + 8] = 1e-18;
+            XC[9 * i] = XC[9 * i + 4] = XC[9 * i + 8] = kRefitPointSigma * kRefitPointSigma;
         }
         mvs_refine_params rp;
         mvs_refine_params_default(&rp);
-        rp.pose_sigma[0] = rp.pose_sigma[1] = 1e6;
+        rp.pose_sigma[0] = rp.pose_sigma[1] = kRefitPoseSigma;
         mvs_refine_result rr;
         if (mvs_pnp_refine(ctx, X.data(), XC.data(), uv.data(), nullptr, (int)m, K, out.R, out.t, &rp, &rr) == MVS_OK && rr.ok) {
             std::memcpy(out.R, rr.R, sizeof(out.R));

@@ -204,6 +204,9 @@ void launch_refine_prep(const RefineDev &d, const double *cov2_0, const double *
                         double *oinfo0, double *oinfo1, double *pinfo, const uint8_t *valid0, const uint8_t *valid1,
                         hipStream_t stream);
 void launch_refine(const RefineDev &d, hipStream_t stream);
+// pnp_solve's refit over the inliers for a batch of PnP problems (the tracks of a sequence): gather -> refine_kernel<1>
+// -> poses written back into p.out.  d: a one-frame RefineDev over the same problems with its own buffers.
+void launch_pnp_refit(const PnpDev &p, const RefineDev &d, double point_sigma, hipStream_t stream);
 // batch glue: build the two-view refinement problems of every pair from the batch's own results
 void launch_refine_gather(const BatchDev &b, int n_active, double sigma_px, double point_sigma, int stride, int32_t *m,
                           double *pose0, double *obs0, double *obs1, double *oinfo0, double *oinfo1, double *pts0,

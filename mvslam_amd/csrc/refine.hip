@@ -852,7 +852,72 @@ __global__ void refine_gather_kernel(BatchDev b, double w_obs, double w_pt, int 
     pinfo[6 * s + 1] = pinfo[6 * s + 2] = pinfo[6 * s + 4] = 0.0;
 }
 
+// pnp_solve's refit over the inliers (cv::solvePnPRansac ends with one, pnp-solve.cpp:53-64), batched over the tracks of a
+// sequence: problem q = the inliers of track q in inlier order, world points held by a stiff prior (information w_pt),
+// unweighted pixels, guess = the RANSAC pose.  Same inputs in the same order as mvs_pnp_solve(refit = 1) stages on the host.
+__global__ void pnp_refit_gather_kernel(PnpDev p, double w_pt, int32_t *m, double *pose0, double *obs0, double *oinfo0,
+                                        double *pts0, double *pinfo)
+{
+    const int q = blockIdx.y;
+    const PnpOut &o = p.out[q];
+    const int n = (o.ok && o.n_inliers >= 4) ? o.n_inliers : 0;
+    if (blockIdx.x == 0 && threadIdx.x < 12)
+        pose0[12 * (size_t)q + threadIdx.x] = threadIdx.x < 9 ? o.R[threadIdx.x] : o.t[threadIdx.x - 9];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        m[q] = n;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const size_t base = (size_t)q * p.stride, s = base + j;
+    const size_t src = base + p.inliers[s];
+    obs0[2 * s] = p.uv[2 * src];
+    obs0[2 * s + 1] = p.uv[2 * src + 1];
+    oinfo0[3 * s] = 1.0, oinfo0[3 * s + 1] = 0.0, oinfo0[3 * s + 2] = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        pts0[3 * s + k] = p.X[3 * src + k];
+    pinfo[6 * s] = pinfo[6 * s + 3] = pinfo[6 * s + 5] = w_pt;
+    pinfo[6 * s + 1] = pinfo[6 * s + 2] = pinfo[6 * s + 4] = 0.0;
+}
+
+// a converged refit replaces the track's pose (camera in world, and its inverse world -> camera)
+__global__ void pnp_refit_apply_kernel(PnpDev p, const mvs_refine_result *rr)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.n_problems)
+        return;
+    PnpOut &o = p.out[q];
+    const mvs_refine_result &r = rr[q];
+    if (!o.ok || o.n_inliers < 4 || !r.ok)
+        return;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        o.R[k] = r.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        o.t[k] = r.t[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.Rw2c[3 * i + j] = r.R[3 * j + i];
+        o.tw2c[i] = -((r.R[i] * r.t[0] + r.R[3 + i] * r.t[1]) + r.R[6 + i] * r.t[2]);
+    }
+}
+
 }  // namespace
+
+void launch_pnp_refit(const PnpDev &p, const RefineDev &d, double point_sigma, hipStream_t stream)
+{
+    if (p.n_problems <= 0)
+        return;
+    dim3 grid((p.stride + 255) / 256, p.n_problems);
+    hipLaunchKernelGGL(pnp_refit_gather_kernel, grid, dim3(256), 0, stream, p, 1.0 / (point_sigma * point_sigma),
+                       const_cast<int32_t *>(d.m), const_cast<double *>(d.pose0), const_cast<double *>(d.obs[0]),
+                       const_cast<double *>(d.oinfo[0]), const_cast<double *>(d.pts0), const_cast<double *>(d.pinfo));
+    launch_refine(d, stream);
+    hipLaunchKernelGGL(pnp_refit_apply_kernel, dim3((p.n_problems + 255) / 256), dim3(256), 0, stream, p, d.out);
+}
 
 void launch_refine_prep(const RefineDev &d, const double *cov2_0, const double *cov2_1, const double *cov3, double iso3,
                         double *oinfo0, double *oinfo1, double *pinfo, const uint8_t *valid0, const uint8_t *valid1,

@@ -194,3 +194,40 @@ def test_gpu_sequence_trajectory_with_failed_tracks(ctx):
         assert tr[k].tobytes() == want[k].tobytes(), k
     assert np.all(tr["track_scale"][2:5] == 1.0)
     assert np.array_equal(tr["R"][5], tr["R"][4]) and np.array_equal(tr["t"][5], tr["t"][4])   # pair 4 invalid: identity step
+
+
+@pytest.mark.gpu
+def test_gpu_sequence_refit_is_the_single_shot_refit_and_tightens_the_scale(ctx):
+    """mvs_pnp_params.refit = 1 inside mvs_seq_run: the refit cv::solvePnPRansac ends with (pnp-solve.cpp:53-64), batched
+    over all tracks on the device.  Every track's pose equals mvs_pnp_solve(refit = 1) on the joined correspondences
+    (same kernel, same inputs in the same order), the inlier sets are the RANSAC ones, the fold is the oracle's, and the
+    per-step scale ratios of a constant-speed sequence get closer to 1 than with the 3-point poses (median error)."""
+    from mvslam_amd import capi
+
+    F, N = 10, 800
+    seq = synth.make_sequence(F, n_kp=N, n_map=9000, noise_px=0.3, step=0.08)
+    prm = capi.default_params(num_hypotheses=4096, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=2e-3)
+    out = {}
+    for refit in (0, 1):
+        s = capi.Sequence(ctx, F, N, 32)
+        s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+        s.run(prm, capi.default_pnp_params(num_hypotheses=256, seed=2, reproj_error=1.5, refit=refit))
+        out[refit] = (s.download_pairs(), s.download_tracks(), s.download_trajectory())
+        s.close()
+    (gp0, gt0, tr0), (gp1, gt1, tr1) = out[0], out[1]
+    assert gp0["results"].tobytes() == gp1["results"].tobytes()              # the pairs do not depend on the refit
+    t0, t1 = gt0["tracks"], gt1["tracks"]
+    assert np.all(t1["ok"] == 1) and np.array_equal(t0["n_inliers"], t1["n_inliers"]) and np.array_equal(t0["best_hyp"], t1["best_hyp"])
+    assert np.array_equal(gt0["inlier_idx"], gt1["inlier_idx"])
+    for q in range(F - 2):
+        nc = int(t1[q]["n_corr"])
+        one = ctx.pnp_solve(gt1["corr_xyz"][q][:nc], gt1["corr_uv"][q][:nc], seq["K"],
+                            capi.default_pnp_params(num_hypotheses=256, seed=2 + q, reproj_error=1.5, refit=1))
+        assert one["ok"] and one["best_hyp"] == t1[q]["best_hyp"]
+        assert one["R"].tobytes() == t1[q]["R"].tobytes() and one["t"].tobytes() == t1[q]["t"].tobytes()
+        assert np.abs(t1[q]["R"] @ t1[q]["R"].T - np.eye(3)).max() < 1e-12
+    want = o.seq_chain(gp1["results"]["R"], gp1["results"]["t"], gp1["results"]["valid"], t1["R"], t1["t"], t1["ok"])
+    for k in ("R", "t", "pair_scale", "track_scale"):
+        assert tr1[k].tobytes() == want[k].tobytes(), k
+    e0, e1 = np.abs(tr0["track_scale"] - 1.0), np.abs(tr1["track_scale"] - 1.0)
+    assert np.median(e1) < np.median(e0), (e0, e1)    # what remains is the two-view triangulation noise of the map points

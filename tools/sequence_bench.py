@@ -13,6 +13,7 @@ ap.add_argument("--kp", type=int, default=2000)
 ap.add_argument("--hyp", type=int, default=50000)
 ap.add_argument("--pnp-hyp", type=int, default=100)      # the reference's iterationsCount (pnp-solve.cpp:47)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--refit", type=int, default=0, help="1: refit every track's pose on its inliers (mvs_pnp_params.refit)")
 ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the same sequence timed through the CPU oracle (0 = skip)")
 args = ap.parse_args()
 
@@ -23,7 +24,7 @@ ctx = capi.Context(0)
 s = capi.Sequence(ctx, args.frames, args.kp, 32)
 s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
 prm = capi.default_params(num_hypotheses=args.hyp, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
-pprm = capi.default_pnp_params(num_hypotheses=args.pnp_hyp, seed=7, reproj_error=2.0)
+pprm = capi.default_pnp_params(num_hypotheses=args.pnp_hyp, seed=7, reproj_error=2.0, refit=args.refit)
 ms = s.time(prm, pprm, steps=args.steps, warmup=1) / args.steps
 stage_ms = s.time_stages(prm, pprm, steps=args.steps)
 s.run(prm, pprm)
@@ -58,7 +59,7 @@ if args.cpu_frames >= 3:
 print(json.dumps({
     "metric": "frames/sec, 1000-frame synthetic sequence (match + two-view + PnP + triangulate per frame, no BA)",
     "value": round(args.frames / (ms * 1e-3), 1), "unit": "frames/s", "ms_per_sequence": round(ms, 2),
-    "frames": args.frames, "keypoints": args.kp, "hypotheses": args.hyp, "pnp_hypotheses": args.pnp_hyp,
+    "frames": args.frames, "keypoints": args.kp, "hypotheses": args.hyp, "pnp_hypotheses": args.pnp_hyp, "pnp_refit": args.refit,
     "valid_pairs": int(res["valid"].sum()), "avg_matches": round(float(res["n_matches"].mean()), 1),
     "avg_points": round(float(res["n_points"].mean()), 1), "tracks_ok": int(tr["ok"].sum()),
     "avg_corr": round(float(tr["n_corr"].mean()), 1), "avg_pnp_inliers": round(float(tr["n_inliers"].mean()), 1),
