@@ -181,29 +181,44 @@ static mvs_status seq_alloc(mvs_seq *q, T **ptr, size_t count)
     return MVS_OK;
 }
 
+// release one block of a batch early (superseded by a larger one); the stream must be idle
+static void dev_release(mvs_batch *b, void *p)
+{
+    if (!p)
+        return;
+    for (size_t i = 0; i < b->allocs.size(); ++i)
+        if (b->allocs[i] == p) {
+            b->allocs.erase(b->allocs.begin() + i);
+            (void)hipFree(p);
+            return;
+        }
+}
+
+// per-hypothesis buffers of the RANSAC stage, sized for the largest hypothesis count seen so far.  All new blocks are
+// allocated before any pointer is switched (a failed allocation leaves the batch as it was, its partial blocks owned by
+// allocs until destroy); the superseded blocks are freed at once: 77 B x hypotheses x pairs is 2 GB at the bench size.
 static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
 {
     const int G = (num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
     if (G <= b->d.max_groups)
         return MVS_OK;
     HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    const size_t P = (size_t)b->d.n_pairs, Hp = (size_t)G * kHypPerBlock;
     WgBest *p = nullptr;
-    mvs_status st = dev_alloc(b, &p, (size_t)b->d.n_pairs * G);
-    if (st != MVS_OK)
-        return st;
-    b->d.wgbest = p;  // the smaller old block stays owned by allocs until destroy
-    // per-hypothesis F for the split solve / score variant of the RANSAC stage: 72 B x hypotheses x pairs
-    double *hf = nullptr;
+    double *hf = nullptr;   // F of every hypothesis (solve -> scoring hand-over): 72 B x hypotheses x pairs
     uint8_t *ho = nullptr;
-    if ((st = dev_alloc(b, &hf, (size_t)b->d.n_pairs * 9 * G * kHypPerBlock)) != MVS_OK)
-        return st;
-    if ((st = dev_alloc(b, &ho, (size_t)b->d.n_pairs * G * kHypPerBlock)) != MVS_OK)
-        return st;
     int32_t *hc = nullptr;
-    if ((st = dev_alloc(b, &hc, (size_t)b->d.n_pairs * G * kHypPerBlock)) != MVS_OK)
-        return st;
-    if (!b->d.bound && (st = dev_alloc(b, &b->d.bound, (size_t)b->d.n_pairs)) != MVS_OK)
-        return st;
+    mvs_status st;
+    if ((st = dev_alloc(b, &p, P * G)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &hf, P * 9 * Hp)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &ho, P * Hp)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &hc, P * Hp)) != MVS_OK) return st;
+    if (!b->d.bound && (st = dev_alloc(b, &b->d.bound, P)) != MVS_OK) return st;
+    dev_release(b, b->d.wgbest);
+    dev_release(b, b->d.hyp_F);
+    dev_release(b, b->d.hyp_okf);
+    dev_release(b, b->d.hyp_cnt);
+    b->d.wgbest = p;
     b->d.hyp_F = hf;
     b->d.hyp_okf = ho;
     b->d.hyp_cnt = hc;

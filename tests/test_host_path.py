@@ -110,3 +110,25 @@ def test_async_pinned_transfers_match_the_synchronous_path_and_tails_are_zero(ct
     b.close()
     for a in list(pin.values()) + [pin_n, pin_K, o_res, o_mt, o_mk, o_pt, o_ix]:
         capi.pinned_free(a)
+
+
+def test_batch_reused_with_growing_and_shrinking_hypothesis_counts(ctx):
+    """one batch object, three runs with different hypothesis counts: the per-hypothesis buffers are re-sized (and the
+    superseded blocks released) in between; every run agrees with the oracle"""
+    from mvslam_amd import capi
+
+    P, N = 4, 400
+    data = synth.make_batch(300, P, n_kp=N)
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
+    for H in (300, 2100, 64):
+        prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=3, max_error_sq=1e-2)
+        b.run(prm)
+        out = b.download()
+        for i in range(P):
+            ref = o.image_pair(data["desc1"][i], data["kp1"][i], data["desc2"][i], data["kp2"][i], data["K"][i].reshape(3, 3),
+                               o.make_params(H, o.SAMPLER_PHILOX, 3 + int(data["global_index"][i]), 1e-2), 0.7, 10.0)
+            r = out["results"][i]
+            assert bool(r["valid"]) == ref["ok"] and r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"]
+            assert np.array_equal(out["mask"][i][:ref["n_matches"]], ref["mask"])
+    b.close()
