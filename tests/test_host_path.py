@@ -132,3 +132,48 @@ def test_batch_reused_with_growing_and_shrinking_hypothesis_counts(ctx):
             assert bool(r["valid"]) == ref["ok"] and r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"]
             assert np.array_equal(out["mask"][i][:ref["n_matches"]], ref["mask"])
     b.close()
+
+
+def test_two_host_threads_with_their_own_contexts_run_concurrently(ctx):
+    """the threading contract (include/mvslam_hip.h: one mvs_ctx per (thread, GPU), calls on one ctx serialised by the
+    caller): two host threads, each with its own context, stream and batch, run different workloads at the same time
+    (ctypes releases the GIL inside the C ABI); each gets the bytes the same work gives when run alone"""
+    import threading
+
+    from mvslam_amd import capi
+
+    jobs = [dict(first=40, P=6, N=500, H=1500, seed=11), dict(first=90, P=3, N=800, H=2600, seed=12)]
+
+    def run(c, j, reps):
+        data = synth.make_batch(j["first"], j["P"], n_kp=j["N"])
+        prm = capi.default_params(num_hypotheses=j["H"], sampler=capi.SAMPLER_PHILOX, seed=j["seed"], max_error_sq=1e-2)
+        b = capi.Batch(c, j["P"], j["N"], 32)
+        outs = []
+        for _ in range(reps):
+            b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+                     data["global_index"])
+            b.run(prm)
+            out = b.download()
+            outs.append(b"".join(out[k].tobytes() for k in ("results", "matches", "mask", "points", "point_idx")))
+        b.close()
+        return outs
+
+    alone = [run(ctx, j, 1)[0] for j in jobs]
+    got, err = [None, None], []
+
+    def work(k):
+        try:
+            c = capi.Context(0)
+            try:
+                got[k] = run(c, jobs[k], 6)
+            finally:
+                c.close()
+        except Exception as e:
+            err.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not err, err
+    for k in range(2):
+        assert all(x == alone[k] for x in got[k]), "job %d differs when another context runs beside it" % k

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle soak over every entry point (more cases than the test-suite keeps).  Integer / index outputs
 must agree bit for bit, floating point within the tolerances of the tests.  Prints one JSON summary line; exit code 1
-on any mismatch.  usage: python tools/soak.py [--cases 200]"""
+on any mismatch.  usage: python tools/soak.py [--cases 200] [--seed 2026]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,8 +16,10 @@ import test_orb as TO
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=200)
+ap.add_argument("--seed", type=int, default=2026, help="another seed = another universe of cases")
 args = ap.parse_args()
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(args.seed)
+PAIR0 = 10_000 + (args.seed - 2026) * 1000   # synthetic pair ids of part 1
 ctx = capi.Context(0)
 bad = []
 cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0)
@@ -30,7 +32,7 @@ N = int(sizes.max())
 b = capi.Batch(ctx, n_pairs, N)
 data = []
 for i in range(n_pairs):
-    p = synth.make_pair(10_000 + i, n_kp=int(sizes[i]), noise_px=float(rng.choice([0.0, 0.3, 1.0])),
+    p = synth.make_pair(PAIR0 + i, n_kp=int(sizes[i]), noise_px=float(rng.choice([0.0, 0.3, 1.0])),
                         outlier_frac=float(rng.choice([0.0, 0.3, 0.6])))
     data.append(p)
 pad = lambda a, w: np.concatenate([a, np.zeros((N - len(a),) + a.shape[1:], a.dtype)])
@@ -157,6 +159,6 @@ for i in range(args.cases // 8):
             and np.array_equal(got["desc"][0][:n], want["desc"])):
         bad.append(("extract", i, h, w, kw))
 ctx.close()
-print(json.dumps({"cases": cnt, "mismatches": len(bad), "first_mismatches": [list(map(str, x)) for x in bad[:8]],
+print(json.dumps({"seed": args.seed, "cases": cnt, "mismatches": len(bad), "first_mismatches": [list(map(str, x)) for x in bad[:8]],
                   "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if bad else 0)
