@@ -243,7 +243,7 @@ def main():
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world},
             "roofline": {
                 "bound": "valu_fp64",
-                "kernel": "ransac_solve_kernel<240> + ransac_count_kernel<1024, 2> + ransac_select_kernel (the RANSAC stage; launch_ms is their sum)",
+                "kernel": "ransac_solve_kernel<1264> + ransac_count_kernel<1024, 2> + ransac_select_kernel (the RANSAC stage; launch_ms is their sum)",
                 "bound_detail": "fp64 vector FMA rate: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (no MFMA is "
                                 "issued: v_mfma_f64 shares the double-precision pipe, profiles/r02_mfma_coissue_microbench.txt)",
                 "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

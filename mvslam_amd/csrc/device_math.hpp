@@ -603,8 +603,11 @@ MVS_DEV uint32_t cvrng_next(uint64_t &state)
 
 // Full 3x3 SVD: A = U diag(w) Vt, exactly cv::SVDecomp(A, w, u, vt, MODIFY_A | FULL_UV).
 // U[i][j] row-major (columns are the left vectors), Vt rows are the right vectors.
+// FAST / CHEAP: the pair step of the 9x9 solve (same guards, same proofs: they do not depend on the size); a violated
+// guard raises `bad` and the caller recomputes with the full sequences.
+template <bool INPLACE = false, bool FAST = false, bool CHEAP = false>
 MVS_DEV void svd3_full(const double (&A)[3][3], double (&w)[3], double (&U)[3][3], double (&Vt)[3][3], unsigned &rot,
-                       unsigned &pairs)
+                       unsigned &pairs, bool &bad3)
 {
     double At[3][3], W[3];
 #pragma unroll
@@ -612,8 +615,7 @@ MVS_DEV void svd3_full(const double (&A)[3][3], double (&w)[3], double (&U)[3][3
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             At[i][k] = A[k][i];
-    bool bad3 = false;
-    jacobi_svd_core<3, 3>(At, Vt, W, rot, pairs, bad3);
+    jacobi_svd_core<3, 3, INPLACE, FAST, true, CHEAP>(At, Vt, W, rot, pairs, bad3);
     // selection sort with physical row swaps (N = 3: cheap)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -694,6 +696,12 @@ MVS_DEV void svd3_full(const double (&A)[3][3], double (&w)[3], double (&U)[3][3
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             U[i][j] = At[j][i];
+}
+MVS_DEV void svd3_full(const double (&A)[3][3], double (&w)[3], double (&U)[3][3], double (&Vt)[3][3], unsigned &rot,
+                       unsigned &pairs)
+{
+    bool bad3 = false;
+    svd3_full<false, false, false>(A, w, U, Vt, rot, pairs, bad3);
 }
 
 // ---------------------------------------------------------------------------------
@@ -831,14 +839,17 @@ MVS_DEV bool eight_point_front(const double (&x1)[8], const double (&y1)[8], con
 }
 
 // back half: rank-2 enforcement (:127-136) and de-normalisation (:245) of the null vector f
-MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double (&F)[9])
+// VAR bit 1024 (with 32 and 128): the 3x3 SVD with the unscaled sequences too
+template <int VAR = 0>
+MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double (&F)[9], bool &bad)
 {
     double Fn[3][3];
     {
         double Fp[3][3] = {{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}};
         double w[3], U[3][3], Vt[3][3];
         unsigned r3 = 0, p3 = 0;
-        svd3_full(Fp, w, U, Vt, r3, p3);
+        constexpr bool F3 = (VAR & (32 | 128 | 1024)) == (32 | 128 | 1024);
+        svd3_full<F3 && (VAR & 16) != 0, F3, F3>(Fp, w, U, Vt, r3, p3, bad);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double a = U[i][0] * w[0], b = U[i][1] * w[1];
@@ -879,7 +890,7 @@ MVS_DEV bool eight_point(const double (&x1)[8], const double (&y1)[8], const dou
         ok = eight_point_front(x1, y1, x2, y2, At, nm);
         svd9_last_vt_row<(VAR & 16) != 0, (VAR & 32) != 0, (VAR & 256) == 0, (VAR & 128) != 0>(At, f, rot9, pairs9, bad);
     }
-    eight_point_back(f, nm, F);
+    eight_point_back<VAR>(f, nm, F, bad);
     return ok;
 }
 

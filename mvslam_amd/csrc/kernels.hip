@@ -611,7 +611,8 @@ __global__ __launch_bounds__(512, 1) void ransac_solve_av_kernel(BatchDev b, Run
 #pragma unroll
         for (int k = 0; k < 9; ++k)
             f[k] = ch.f[k][lane];
-        eight_point_back(f, nm, F);
+        bool bad3 = false;
+        eight_point_back<0>(f, nm, F, bad3);
     }
     if (__builtin_expect(__any(bad) || !alive, 0)) {
         // a fast-math guard was violated (never for Hartley-normalised samples) or the partner was lost: this wavefront
@@ -1052,7 +1053,9 @@ __global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, co
     }
     unsigned rot = 0, pairs = 0;
     bool bad = false;
-    bool ok = eight_point<48>(x1, y1, x2, y2, F, rot, pairs, bad);
+    // the pair step of the RANSAC solve (unscaled sequences, sqrt-free test, 9x9 and 3x3), so that the bitwise F
+    // tests of this entry point cover exactly the arithmetic the hot kernel runs
+    bool ok = eight_point<16 + 32 + 128 + 1024>(x1, y1, x2, y2, F, rot, pairs, bad);
     if (bad)
         ok = eight_point<16>(x1, y1, x2, y2, F, rot, pairs, bad);
 #pragma unroll
@@ -1490,7 +1493,8 @@ void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2,
 }
 
 // 120 fused; 632 = solve + hypothesis-per-lane scoring as two launches (round 1); 1784 = solve (with the sqrt-free
-// convergence test, bit 128) + pruned point-per-lane scoring (bit 1024): ransac_count + ransac_select
+// convergence test, bit 128 of the kernel's VAR, for the 9x9 and -- kernel bit 1024 -- the 3x3 SVD) + pruned
+// point-per-lane scoring (bit 1024 of the launch variant): ransac_count + ransac_select
 static int g_ransac_variant = 1784;
 void set_ransac_variant(int v) { g_ransac_variant = v; }
 int get_ransac_variant() { return g_ransac_variant; }
@@ -1586,18 +1590,26 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
             launch_pruned_scoring(b, rp, n_active, stream);
         }
         break;
+    case 5880:  // experiment: 1784 with the 3x3 SVD on the unscaled sequences too
+        if (!split_ok || b.hyp_count) {
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+        } else {
+            hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), grid, block, 0, stream, b, rp);
+            launch_pruned_scoring(b, rp, n_active, stream);
+        }
+        break;
     case 1656:  // 632 + pruned scoring
     case 1784:  // 760 + pruned scoring
         if (!split_ok) {
             // one or two pairs, per-hypothesis tables: the fused kernel (with the same sqrt-free pair step for 1784);
             // the instrumented replay stays on variant 120, whose counters the flop model was derived with
             if (g_ransac_variant == 1784 && !stats)
-                launch_ransac_var<248>(b, rp, grid, block, false, stream);
+                launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream);
             else
                 launch_ransac_var<120>(b, rp, grid, block, stats, stream);
         } else {
             if (g_ransac_variant == 1784)
-                hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
+                hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), grid, block, 0, stream, b, rp);
             else
                 hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
             if (b.hyp_count)

@@ -15,7 +15,8 @@ from mvslam_amd import capi, synth  # noqa: E402
 NAMES = {0: "round-1 first version", 120: "fused: LDS point stream + in-place rotation + mask-fma + unscaled sqrt/div",
          632: "120 split into a solve and a scoring launch (round-1 default)", 376: "timing only: 120 without V rotations",
          760: "632 + sqrt-free convergence test in the solve", 1656: "632 + pruned point-per-lane scoring",
-         1784: "760 + pruned point-per-lane scoring (default)", 3832: "1784 with the solve as A / V wavefront pairs"}
+         1784: "760 + pruned point-per-lane scoring (default)", 3832: "1784 with the solve as A / V wavefront pairs",
+         5880: "1784 before the 3x3 SVD of the solve moved to the unscaled sequences"}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=128)
