@@ -584,14 +584,21 @@ MVS_DEV void svd9_last_vt_row(double (&At)[9][9], double (&f)[9], unsigned &rot,
 }
 
 // Last row of vt of cv::SVDecomp(A) for a 4x4 A given as At = A^T.
-MVS_DEV void svd4_last_vt_row(double (&At)[4][4], double (&x)[4], unsigned &rot, unsigned &pairs)
+// GUARDED: the pair step of the RANSAC solve (unscaled sequences, sqrt-free test); a violated guard raises `bad` and
+// the caller recomputes with GUARDED = false (the guards and their proofs do not depend on the matrix size).
+template <bool GUARDED = false>
+MVS_DEV void svd4_last_vt_row(double (&At)[4][4], double (&x)[4], unsigned &rot, unsigned &pairs, bool &bad)
 {
     double Vt[4][4], W[4];
     int tag[4];
-    bool bad = false;
-    jacobi_svd_core<4, 4>(At, Vt, W, rot, pairs, bad);
+    jacobi_svd_core<4, 4, GUARDED, GUARDED, true, GUARDED>(At, Vt, W, rot, pairs, bad);
     sort_tags_desc<4>(W, tag);
     select_row<4>(Vt, tag[3], x);
+}
+MVS_DEV void svd4_last_vt_row(double (&At)[4][4], double (&x)[4], unsigned &rot, unsigned &pairs)
+{
+    bool bad = false;
+    svd4_last_vt_row<false>(At, x, rot, pairs, bad);
 }
 
 // OpenCV's multiply-with-carry generator, used only when a singular value is <= DBL_MIN.

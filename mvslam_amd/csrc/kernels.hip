@@ -1345,13 +1345,21 @@ __global__ __launch_bounds__(256) void triangulate_kernel(BatchDev b)
     const double t0 = flip ? -fm->T[0] : fm->T[0], t1 = flip ? -fm->T[1] : fm->T[1], t2 = flip ? -fm->T[2] : fm->T[2];
     const double4 p = *reinterpret_cast<const double4 *>(b.pts + (base + i) * 4);
     double At[4][4];  // At[col][row] of A
-    At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
-    At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
-    At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
-    At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
+    auto design = [&]() {
+        At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
+        At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
+        At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
+        At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
+    };
     double X[4];
     unsigned rot = 0, prs = 0;
-    svd4_last_vt_row(At, X, rot, prs);
+    bool bad = false;
+    design();
+    svd4_last_vt_row<true>(At, X, rot, prs, bad);
+    if (__builtin_expect(__any(bad), 0)) {   // a range guard of the unscaled sequences was violated: full sequences
+        design();
+        svd4_last_vt_row<false>(At, X, rot, prs, bad);
+    }
     bool okp = !(dabs(X[3]) < kTol);
     const double scale = 1.0 / X[3];
     const double px = X[0] * scale, py = X[1] * scale, pz = X[2] * scale;
