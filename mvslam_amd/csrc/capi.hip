@@ -585,7 +585,7 @@ mvs_status mvs_host_alloc(size_t bytes, void **out)
     if (!out || bytes == 0)
         return MVS_ERR_INVALID_ARG;
     *out = nullptr;
-    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? MVS_OK : MVS_ERR_HIP;
+    return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? MVS_OK : MVS_ERR_HIP;
 }
 
 void mvs_host_free(void *p)
