@@ -202,6 +202,135 @@ struct Prob {
     const double *pinfo;
 };
 
+// ---- per-point inputs through a per-wavefront LDS prefetch ring ------------------------------------------------------
+// The kernel runs at one wavefront per SIMD (510 registers), so nothing hides a global load: with the point data read
+// straight from memory the wavefronts sat in s_waitcnt for 47 % of their cycles (profiles/r02_refine_pmc_*.json).
+// Every loop over a thread's points now goes through for_points(): the inputs of the wavefront's NEXT 64 points travel
+// global -> LDS by LDS-DMA (global_load_lds: no destination registers) while the current 64 are processed; two buffers
+// per wavefront, private to it (no barrier), retired with a counted s_waitcnt vmcnt(N).  The DMA instructions are inline
+// asm: hipcc would otherwise drain them with vmcnt(0) in front of the first LDS read (cdna_hip_programming.md section 5).
+// Loads return in order, so "at most N operations outstanding" after issuing N newer ones means the older batch has
+// landed, whatever stores the loop body issued in between.
+template <int F>
+struct PtIn {
+    double L[6];       // point prior information (packed symmetric)
+    double p0[3];      // point prior mean
+    double ob[F][2];   // observations
+    double W[F][3];    // observation information (packed symmetric 2x2)
+    double p[3];       // current estimate
+};
+
+template <int F>
+struct PtStage {   // one wavefront, one point per lane; an LDS-DMA instruction writes 16 bytes per lane, contiguously --
+                   // dwordx3 too: three dwords and an untouched fourth (tools/glds_layout.hip)
+    static constexpr int N16 = 3 + F;           // pinfo (48 B) + F observations (16 B)
+    static constexpr int N12 = 2 * (2 + F);     // pts0, pts, F x oinfo: 24-byte records as two 12-byte halves
+    uint32_t c16[N16][64][4];
+    uint32_t c12[N12][64][4];
+};
+
+__device__ __forceinline__ unsigned lds_offset(const void *p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+// M0 carries the LDS destination of an LDS-DMA and is compiler-reserved: saved and restored inside the statement
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds12(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int F>
+__device__ __forceinline__ void stage_issue(const Prob<F> &P, const double *pts, int i, PtStage<F> *st)
+{
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(st));
+    const unsigned o16 = base + offsetof(PtStage<F>, c16), o12 = base + offsetof(PtStage<F>, c12);
+    const char *pi = reinterpret_cast<const char *>(P.pinfo + 6 * (size_t)i);
+    glds16(pi, o16);
+    glds16(pi + 16, o16 + 1024);
+    glds16(pi + 32, o16 + 2048);
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+        glds16(P.obs[f] + 2 * (size_t)i, o16 + (3 + f) * 1024);
+    const char *r0 = reinterpret_cast<const char *>(P.pts0 + 3 * (size_t)i);
+    const char *r1 = reinterpret_cast<const char *>(pts + 3 * (size_t)i);
+    glds12(r0, o12);
+    glds12(r0 + 12, o12 + 1024);
+    glds12(r1, o12 + 2 * 1024);
+    glds12(r1 + 12, o12 + 3 * 1024);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const char *w = reinterpret_cast<const char *>(P.oinfo[f] + 3 * (size_t)i);
+        glds12(w, o12 + (4 + 2 * f) * 1024);
+        glds12(w + 12, o12 + (5 + 2 * f) * 1024);
+    }
+}
+template <int F>
+constexpr int stage_ops() { return (3 + F) + 2 * (2 + F); }
+
+__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+// a 24-byte record of three doubles from its two 12-byte halves
+__device__ __forceinline__ void read_rec3(const uint32_t (&a)[4], const uint32_t (&b)[4], double (&o)[3])
+{
+    o[0] = mk_double(a[0], a[1]);
+    o[1] = mk_double(a[2], b[0]);
+    o[2] = mk_double(b[1], b[2]);
+}
+template <int F>
+__device__ __forceinline__ void stage_read(const PtStage<F> *st, int lane, PtIn<F> &q)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        q.L[2 * c] = mk_double(st->c16[c][lane][0], st->c16[c][lane][1]);
+        q.L[2 * c + 1] = mk_double(st->c16[c][lane][2], st->c16[c][lane][3]);
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        q.ob[f][0] = mk_double(st->c16[3 + f][lane][0], st->c16[3 + f][lane][1]);
+        q.ob[f][1] = mk_double(st->c16[3 + f][lane][2], st->c16[3 + f][lane][3]);
+    }
+    read_rec3(st->c12[0][lane], st->c12[1][lane], q.p0);
+    read_rec3(st->c12[2][lane], st->c12[3][lane], q.p);
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+        read_rec3(st->c12[4 + 2 * f][lane], st->c12[5 + 2 * f][lane], q.W[f]);
+}
+
+// body(i, q) for every point i of this thread (i = tid, tid + 256, ...), inputs q through the wavefront's ring `ring[2]`
+template <int F, typename Body>
+__device__ __forceinline__ void for_points(const Prob<F> &P, const double *pts, PtStage<F> *ring, Body body)
+{
+    const int lane = threadIdx.x & 63;
+    const int n_it = (P.m + kRefineThreads - 1) / kRefineThreads;   // workgroup-uniform
+    constexpr int kOps = stage_ops<F>();
+    static_assert(kOps == 13 || kOps == 10, "the counted waits below are written for these");
+    stage_issue<F>(P, pts, min((int)threadIdx.x, P.m - 1), ring);
+    for (int k = 0; k < n_it; ++k) {
+        const int i = threadIdx.x + k * kRefineThreads;
+        if (k + 1 < n_it) {
+            stage_issue<F>(P, pts, min(i + kRefineThreads, P.m - 1), ring + ((k + 1) & 1));
+            if (kOps == 13)
+                asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PtIn<F> q;
+        stage_read<F>(ring + (k & 1), lane, q);
+        asm volatile("" ::: "memory");   // the reads above stay above the next iteration's DMA into the other buffer
+        if (i < P.m)
+            body(i, q);
+    }
+}
+
 // linearise point i at (R, t, p): Hpp (+ prior), gp, Hcp; when ACC, the frames' own Hcc / gc blocks and the cost go
 // straight into the thread's accumulators
 // [LO, HI): the slice of the accumulator vector {S packed, b, cost} this call adds to (build_schur accumulates the
@@ -209,17 +338,13 @@ struct Prob {
 // linearisation temporaries and went to scratch memory)
 template <int F, bool ACC, int LO = 0, int HI = Dims<F>::NV>
 __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
-                                                const double (&p)[3], int i, double (&Hpp)[6], double (&gp)[3],
+                                                const double (&p)[3], const PtIn<F> &q, double (&Hpp)[6], double (&gp)[3],
                                                 double (&Hcp)[6 * F][3], double (&acc)[Dims<F>::NV])
 {
     constexpr int NL = Dims<F>::NL, NC = Dims<F>::NC;
     auto in = [](int idx) { return idx >= LO && idx < HI; };
-    double L[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-        L[k] = P.pinfo[6 * (size_t)i + k];
-    const double d0 = p[0] - P.pts0[3 * (size_t)i], d1 = p[1] - P.pts0[3 * (size_t)i + 1],
-                 d2 = p[2] - P.pts0[3 * (size_t)i + 2];
+    const double (&L)[6] = q.L;
+    const double d0 = p[0] - q.p0[0], d1 = p[1] - q.p0[1], d2 = p[2] - q.p0[2];
     const double Ld0 = fd3(L[0], d0, L[1], d1, L[2], d2), Ld1 = fd3(L[1], d0, L[3], d1, L[4], d2),
                  Ld2 = fd3(L[2], d0, L[4], d1, L[5], d2);
 #pragma unroll
@@ -230,8 +355,8 @@ __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         double r[2], Jc[12], Jp[6];
-        project_lin<true>(P.cam, R[f], t[f], p, P.obs[f][2 * (size_t)i], P.obs[f][2 * (size_t)i + 1], r, Jc, Jp);
-        const double W0 = P.oinfo[f][3 * (size_t)i], W1 = P.oinfo[f][3 * (size_t)i + 1], W2 = P.oinfo[f][3 * (size_t)i + 2];
+        project_lin<true>(P.cam, R[f], t[f], p, q.ob[f][0], q.ob[f][1], r, Jc, Jp);
+        const double W0 = q.W[f][0], W1 = q.W[f][1], W2 = q.W[f][2];
         const double wr0 = fd2(W0, r[0], W1, r[1]), wr1 = fd2(W1, r[0], W2, r[1]);
         cost = fma(r[1], wr1, fma(r[0], wr0, cost));
         double WJc[12], WJp[6];
@@ -276,26 +401,49 @@ __device__ __forceinline__ void point_linearize(const Prob<F> &P, const double (
 
 template <int F>
 __device__ __forceinline__ double point_cost(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
-                                             const double (&p)[3], int i)
+                                             const double (&p)[3], const PtIn<F> &q)
 {
-    double L[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-        L[k] = P.pinfo[6 * (size_t)i + k];
-    const double d0 = p[0] - P.pts0[3 * (size_t)i], d1 = p[1] - P.pts0[3 * (size_t)i + 1],
-                 d2 = p[2] - P.pts0[3 * (size_t)i + 2];
+    const double (&L)[6] = q.L;
+    const double d0 = p[0] - q.p0[0], d1 = p[1] - q.p0[1], d2 = p[2] - q.p0[2];
     const double Ld0 = fd3(L[0], d0, L[1], d1, L[2], d2), Ld1 = fd3(L[1], d0, L[3], d1, L[4], d2),
                  Ld2 = fd3(L[2], d0, L[4], d1, L[5], d2);
     double c = fd3(d0, Ld0, d1, Ld1, d2, Ld2);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         double r[2], Jc[12], Jp[6];
-        project_lin<false>(P.cam, R[f], t[f], p, P.obs[f][2 * (size_t)i], P.obs[f][2 * (size_t)i + 1], r, Jc, Jp);
-        const double W0 = P.oinfo[f][3 * (size_t)i], W1 = P.oinfo[f][3 * (size_t)i + 1], W2 = P.oinfo[f][3 * (size_t)i + 2];
+        project_lin<false>(P.cam, R[f], t[f], p, q.ob[f][0], q.ob[f][1], r, Jc, Jp);
+        const double W0 = q.W[f][0], W1 = q.W[f][1], W2 = q.W[f][2];
         const double wr0 = fd2(W0, r[0], W1, r[1]), wr1 = fd2(W1, r[0], W2, r[1]);
         c = fma(r[1], wr1, fma(r[0], wr0, c));
     }
     return c;
+}
+
+// x of the lane a DPP control selects (two 32-bit moves; no LDS round trip, unlike ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// sum over the wavefront, the xor butterfly's tree ((x0 + x1) + (x2 + x3)) + ... in every lane: steps 1 and 2 are quad
+// permutes; after them a quad is uniform, so the lane a half-row mirror (i -> 7 - i) selects holds what lane i ^ 4 holds,
+// likewise the row mirror for i ^ 8; rows are then uniform and steps 16 / 32 are (r0 + r1) + (r2 + r3) of the four row
+// values.  Bit-identical to x = x + __shfl_xor(x, s) for s = 1 .. 32, which cost 12 ds_bpermute round trips per value
+// (the kernel spent 47 % of its cycles waiting on them at one wavefront per SIMD).
+__device__ __forceinline__ double wave_sum(double x)
+{
+    x = x + dpp_f64<0xb1>(x);    // quad_perm [1, 0, 3, 2]
+    x = x + dpp_f64<0x4e>(x);    // quad_perm [2, 3, 0, 1]
+    x = x + dpp_f64<0x141>(x);   // row_half_mirror
+    x = x + dpp_f64<0x140>(x);   // row_mirror
+    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 // fixed-order sum over the workgroup; every thread returns with the same totals
@@ -305,10 +453,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double *red)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int s = 1; s < 64; s *= 2)
-            x = x + __shfl_xor(x, s, 64);
+        const double x = wave_sum(v[k]);
         if (lane == 0)
             red[wave * NV + k] = x;
     }
@@ -342,7 +487,8 @@ __device__ __forceinline__ double prior_cost(const RefineCfg &cfg, const double 
     return c;
 }
 
-// in-place Cholesky of the packed lower triangle; false if not positive definite
+// in-place Cholesky of the packed lower triangle; false if not positive definite.  The diagonal holds 1 / l_jj (one
+// division per column; the other 78 divisions of a factorisation + solve are multiplications by it, as in the oracle)
 template <int N>
 __device__ __forceinline__ bool chol_packed(double (&S)[N * (N + 1) / 2])
 {
@@ -354,15 +500,15 @@ __device__ __forceinline__ bool chol_packed(double (&S)[N * (N + 1) / 2])
         for (int k = 0; k < j; ++k)
             d = fma(-S[lidx(j, k)], S[lidx(j, k)], d);
         ok = ok && (d > 0.0) && (d < __builtin_inf());
-        const double l = sqrt(d);
-        S[lidx(j, j)] = l;
+        const double inv = 1.0 / sqrt(d);
+        S[lidx(j, j)] = inv;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             double v = S[lidx(i, j)];
 #pragma unroll
             for (int k = 0; k < j; ++k)
                 v = fma(-S[lidx(i, k)], S[lidx(j, k)], v);
-            S[lidx(i, j)] = v / l;
+            S[lidx(i, j)] = v * inv;
         }
     }
     return ok;
@@ -377,7 +523,7 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[N * (N + 1) / 2], 
 #pragma unroll
         for (int k = 0; k < i; ++k)
             v = fma(-Lc[lidx(i, k)], b[k], v);
-        b[i] = v / Lc[lidx(i, i)];
+        b[i] = v * Lc[lidx(i, i)];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
@@ -385,21 +531,21 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[N * (N + 1) / 2], 
 #pragma unroll
         for (int k = i + 1; k < N; ++k)
             v = fma(-Lc[lidx(k, i)], b[k], v);
-        b[i] = v / Lc[lidx(i, i)];
+        b[i] = v * Lc[lidx(i, i)];
     }
 }
 
 // one pass over the thread's points adding the entries [LO, HI) of {S packed, b, cost} (per-thread partial sums)
 template <int F, int LO, int HI>
 __device__ __forceinline__ void schur_pass(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
-                                           const double *pts, double lam, double (&acc)[Dims<F>::NV])
+                                           const double *pts, double lam, double (&acc)[Dims<F>::NV], PtStage<F> *ring)
 {
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL;
     auto in = [](int idx) { return idx >= LO && idx < HI; };
-    for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
-        const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    for_points<F>(P, pts, ring, [&](int, const PtIn<F> &q) {
+        const double (&p)[3] = q.p;
         double Hpp[6], gp[3], Hcp[NC][3];
-        point_linearize<F, true, LO, HI>(P, R, t, p, i, Hpp, gp, Hcp, acc);
+        point_linearize<F, true, LO, HI>(P, R, t, p, q, Hpp, gp, Hcp, acc);
         const double Hd[6] = {Hpp[0] + lam, Hpp[1], Hpp[2], Hpp[3] + lam, Hpp[4], Hpp[5] + lam};
         double Pi[6];
         sym3_inverse(Hd, Pi);
@@ -415,16 +561,17 @@ __device__ __forceinline__ void schur_pass(const Prob<F> &P, const double (&R)[F
             if (in(NL + a))
                 acc[NL + a] = fma(y2, gp[2], fma(y1, gp[1], fma(y0, gp[0], acc[NL + a])));
         }
-    }
+    });
 }
 
 // accumulate, reduce over the workgroup and park in LDS (red[4 NV + k]) the entries [LO, HI)
 template <int F, int LO, int HI>
 __device__ __forceinline__ void schur_slice(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
-                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
+                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red,
+                                            PtStage<F> *ring)
 {
     constexpr int NV = Dims<F>::NV;
-    schur_pass<F, LO, HI>(P, R, t, pts, lam, acc);
+    schur_pass<F, LO, HI>(P, R, t, pts, lam, acc, ring);
     double part[HI - LO];
 #pragma unroll
     for (int k = 0; k < HI - LO; ++k)
@@ -441,7 +588,8 @@ __device__ __forceinline__ void schur_slice(const Prob<F> &P, const double (&R)[
 template <int F>
 __device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &cfg, const double (&R0)[F][9],
                                             const double (&t0)[F][3], const double (&R)[F][9], const double (&t)[F][3],
-                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
+                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red,
+                                            PtStage<F> *ring)
 {
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
 #pragma unroll
@@ -451,16 +599,16 @@ __device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &c
     // same point order per entry, same reduction tree: the sums have the same bits as a single pass); the totals of a
     // finished slice wait in LDS.  Two frames: rows 0..6 of S | rows 7..9 | rows 10..11, b, cost.
     if constexpr (F == 2) {
-        schur_slice<F, 0, lidx(7, 0)>(P, R, t, pts, lam, acc, red);
-        schur_slice<F, lidx(7, 0), lidx(10, 0)>(P, R, t, pts, lam, acc, red);
-        schur_slice<F, lidx(10, 0), NV>(P, R, t, pts, lam, acc, red);
+        schur_slice<F, 0, lidx(7, 0)>(P, R, t, pts, lam, acc, red, ring);
+        schur_slice<F, lidx(7, 0), lidx(10, 0)>(P, R, t, pts, lam, acc, red, ring);
+        schur_slice<F, lidx(10, 0), NV>(P, R, t, pts, lam, acc, red, ring);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             acc[k] = red[4 * NV + k];
         __syncthreads();   // the next user of `red` must not overtake the reads above
     } else {
-        schur_pass<F, 0, NV>(P, R, t, pts, lam, acc);
+        schur_pass<F, 0, NV>(P, R, t, pts, lam, acc, ring);
         block_reduce<NV>(acc, red);
     }
 #pragma unroll
@@ -500,6 +648,8 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
     __shared__ double red[5 * NV];   // 4 wavefront partials + the parked totals of build_schur's first pass
     __shared__ double Sinv[NC * NC];
+    __shared__ __attribute__((aligned(16))) PtStage<F> stage[kRefineThreads / 64][2];   // per-wavefront prefetch rings
+    PtStage<F> *ring = stage[threadIdx.x >> 6];
     const int g = blockIdx.x;
     const RefineCfg &cfg = d.cfg;
     Prob<F> P;
@@ -571,10 +721,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     double cur;
     {
         double c = 0.0;
-        for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
-            const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
-            c = c + point_cost<F>(P, R, t, p, i);
-        }
+        for_points<F>(P, pts, ring, [&](int, const PtIn<F> &q) { c = c + point_cost<F>(P, R, t, q.p, q); });
         cur = block_reduce1(c, red) + prior_cost<F>(cfg, R0, t0, R, t);
     }
     double lam = cfg.lambda_initial;
@@ -582,7 +729,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     const bool ok0 = cur < __builtin_inf() && cur == cur;
     while (ok0 && it < cfg.max_iterations) {
         double acc[NV];
-        build_schur<F>(P, cfg, R0, t0, R, t, pts, lam, acc, red);
+        build_schur<F>(P, cfg, R0, t0, R, t, pts, lam, acc, red, ring);
         double S[NL], b[NC];
 #pragma unroll
         for (int k = 0; k < NL; ++k)
@@ -611,10 +758,10 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
                 }
             }
             double c = 0.0;
-            for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
-                const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+            for_points<F>(P, pts, ring, [&](int i, const PtIn<F> &q) {
+                const double (&p)[3] = q.p;
                 double Hpp[6], gp[3], Hcp[NC][3], dummy[NV];
-                point_linearize<F, false>(P, R, t, p, i, Hpp, gp, Hcp, dummy);
+                point_linearize<F, false>(P, R, t, p, q, Hpp, gp, Hcp, dummy);
                 const double Hd[6] = {Hpp[0] + lam, Hpp[1], Hpp[2], Hpp[3] + lam, Hpp[4], Hpp[5] + lam};
                 double Pi[6];
                 sym3_inverse(Hd, Pi);
@@ -631,8 +778,8 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     pts_new[3 * (size_t)i + k] = pn[k];
-                c = c + point_cost<F>(P, Rn, tn, pn, i);
-            }
+                c = c + point_cost<F>(P, Rn, tn, pn, q);
+            });
             cand = block_reduce1(c, red) + prior_cost<F>(cfg, R0, t0, Rn, tn);
             accepted = cand <= cur;
         }
@@ -671,7 +818,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     bool ok = ok0;
     if (ok) {
         double acc[NV];
-        build_schur<F>(P, cfg, R0, t0, R, t, pts, 0.0, acc, red);
+        build_schur<F>(P, cfg, R0, t0, R, t, pts, 0.0, acc, red, ring);
         double S[NL];
 #pragma unroll
         for (int k = 0; k < NL; ++k)
@@ -691,10 +838,10 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
             __syncthreads();
             if (d.point_cov) {
                 double *pc = d.point_cov + 9 * base;
-                for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
-                    const double p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+                for_points<F>(P, pts, ring, [&](int i, const PtIn<F> &q) {
+                    const double (&p)[3] = q.p;
                     double Hpp[6], gp[3], Hcp[NC][3], dummy[NV];
-                    point_linearize<F, false>(P, R, t, p, i, Hpp, gp, Hcp, dummy);
+                    point_linearize<F, false>(P, R, t, p, q, Hpp, gp, Hcp, dummy);
                     double Pi[6];
                     sym3_inverse(Hpp, Pi);
                     const double Pf[9] = {Pi[0], Pi[1], Pi[2], Pi[1], Pi[3], Pi[4], Pi[2], Pi[4], Pi[5]};
@@ -728,7 +875,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
 #pragma unroll
                     for (int k = 0; k < 9; ++k)
                         pc[9 * (size_t)i + k] = Pf[k] + C[k];
-                }
+                });
             }
         }
     }
