@@ -202,15 +202,12 @@ struct Prob {
     const double *pinfo;
 };
 
-// ---- per-point inputs through a per-wavefront LDS prefetch ring ------------------------------------------------------
-// The kernel runs at one wavefront per SIMD (510 registers), so nothing hides a global load: with the point data read
-// straight from memory the wavefronts sat in s_waitcnt for 47 % of their cycles (profiles/r02_refine_pmc_*.json).
-// Every loop over a thread's points now goes through for_points(): the inputs of the wavefront's NEXT 64 points travel
-// global -> LDS by LDS-DMA (global_load_lds: no destination registers) while the current 64 are processed; two buffers
-// per wavefront, private to it (no barrier), retired with a counted s_waitcnt vmcnt(N).  The DMA instructions are inline
-// asm: hipcc would otherwise drain them with vmcnt(0) in front of the first LDS read (cdna_hip_programming.md section 5).
-// Loads return in order, so "at most N operations outstanding" after issuing N newer ones means the older batch has
-// landed, whatever stores the loop body issued in between.
+// ---- per-point inputs -------------------------------------------------------------------------------------------------
+// Every loop over a thread's points goes through for_points(), which loads the point's inputs once into PtIn.
+// (Tried in round 2 and dropped: the inputs of the wavefront's next 64 points prefetched global -> LDS by LDS-DMA into a
+// two-buffer ring per wavefront, retired with a counted s_waitcnt -- same results, 0.636 vs 0.596 ms per 512 pairs: the
+// 13 DMA statements per point with their M0 set-up, the LDS reads and 36 B of scratch cost more than the exposed load
+// latency they hide; the kernel's waits were the ds_bpermute chains of the reductions, see wave_sum.)
 template <int F>
 struct PtIn {
     double L[6];       // point prior information (packed symmetric)
@@ -220,114 +217,29 @@ struct PtIn {
     double p[3];       // current estimate
 };
 
-template <int F>
-struct PtStage {   // one wavefront, one point per lane; an LDS-DMA instruction writes 16 bytes per lane, contiguously --
-                   // dwordx3 too: three dwords and an untouched fourth (tools/glds_layout.hip)
-    static constexpr int N16 = 3 + F;           // pinfo (48 B) + F observations (16 B)
-    static constexpr int N12 = 2 * (2 + F);     // pts0, pts, F x oinfo: 24-byte records as two 12-byte halves
-    uint32_t c16[N16][64][4];
-    uint32_t c12[N12][64][4];
-};
-
-__device__ __forceinline__ unsigned lds_offset(const void *p)
-{
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
-}
-// M0 carries the LDS destination of an LDS-DMA and is compiler-reserved: saved and restored inside the statement
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds12(const void *gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-template <int F>
-__device__ __forceinline__ void stage_issue(const Prob<F> &P, const double *pts, int i, PtStage<F> *st)
-{
-    const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(st));
-    const unsigned o16 = base + offsetof(PtStage<F>, c16), o12 = base + offsetof(PtStage<F>, c12);
-    const char *pi = reinterpret_cast<const char *>(P.pinfo + 6 * (size_t)i);
-    glds16(pi, o16);
-    glds16(pi + 16, o16 + 1024);
-    glds16(pi + 32, o16 + 2048);
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-        glds16(P.obs[f] + 2 * (size_t)i, o16 + (3 + f) * 1024);
-    const char *r0 = reinterpret_cast<const char *>(P.pts0 + 3 * (size_t)i);
-    const char *r1 = reinterpret_cast<const char *>(pts + 3 * (size_t)i);
-    glds12(r0, o12);
-    glds12(r0 + 12, o12 + 1024);
-    glds12(r1, o12 + 2 * 1024);
-    glds12(r1 + 12, o12 + 3 * 1024);
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const char *w = reinterpret_cast<const char *>(P.oinfo[f] + 3 * (size_t)i);
-        glds12(w, o12 + (4 + 2 * f) * 1024);
-        glds12(w + 12, o12 + (5 + 2 * f) * 1024);
-    }
-}
-template <int F>
-constexpr int stage_ops() { return (3 + F) + 2 * (2 + F); }
-
-__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
-// a 24-byte record of three doubles from its two 12-byte halves
-__device__ __forceinline__ void read_rec3(const uint32_t (&a)[4], const uint32_t (&b)[4], double (&o)[3])
-{
-    o[0] = mk_double(a[0], a[1]);
-    o[1] = mk_double(a[2], b[0]);
-    o[2] = mk_double(b[1], b[2]);
-}
-template <int F>
-__device__ __forceinline__ void stage_read(const PtStage<F> *st, int lane, PtIn<F> &q)
-{
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        q.L[2 * c] = mk_double(st->c16[c][lane][0], st->c16[c][lane][1]);
-        q.L[2 * c + 1] = mk_double(st->c16[c][lane][2], st->c16[c][lane][3]);
-    }
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        q.ob[f][0] = mk_double(st->c16[3 + f][lane][0], st->c16[3 + f][lane][1]);
-        q.ob[f][1] = mk_double(st->c16[3 + f][lane][2], st->c16[3 + f][lane][3]);
-    }
-    read_rec3(st->c12[0][lane], st->c12[1][lane], q.p0);
-    read_rec3(st->c12[2][lane], st->c12[3][lane], q.p);
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-        read_rec3(st->c12[4 + 2 * f][lane], st->c12[5 + 2 * f][lane], q.W[f]);
-}
-
-// body(i, q) for every point i of this thread (i = tid, tid + 256, ...), inputs q through the wavefront's ring `ring[2]`
+// body(i, q) for every point i of this thread (i = tid, tid + 256, ...)
 template <int F, typename Body>
-__device__ __forceinline__ void for_points(const Prob<F> &P, const double *pts, PtStage<F> *ring, Body body)
+__device__ __forceinline__ void for_points(const Prob<F> &P, const double *pts, Body body)
 {
-    const int lane = threadIdx.x & 63;
-    const int n_it = (P.m + kRefineThreads - 1) / kRefineThreads;   // workgroup-uniform
-    constexpr int kOps = stage_ops<F>();
-    static_assert(kOps == 13 || kOps == 10, "the counted waits below are written for these");
-    stage_issue<F>(P, pts, min((int)threadIdx.x, P.m - 1), ring);
-    for (int k = 0; k < n_it; ++k) {
-        const int i = threadIdx.x + k * kRefineThreads;
-        if (k + 1 < n_it) {
-            stage_issue<F>(P, pts, min(i + kRefineThreads, P.m - 1), ring + ((k + 1) & 1));
-            if (kOps == 13)
-                asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
         PtIn<F> q;
-        stage_read<F>(ring + (k & 1), lane, q);
-        asm volatile("" ::: "memory");   // the reads above stay above the next iteration's DMA into the other buffer
-        if (i < P.m)
-            body(i, q);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            q.L[k] = P.pinfo[6 * (size_t)i + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            q.p0[k] = P.pts0[3 * (size_t)i + k];
+            q.p[k] = pts[3 * (size_t)i + k];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            q.ob[f][0] = P.obs[f][2 * (size_t)i];
+            q.ob[f][1] = P.obs[f][2 * (size_t)i + 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                q.W[f][k] = P.oinfo[f][3 * (size_t)i + k];
+        }
+        body(i, q);
     }
 }
 
@@ -446,6 +358,13 @@ __device__ __forceinline__ double wave_sum(double x)
     return (r0 + r1) + (r2 + r3);
 }
 
+// a value every lane holds with the same bits, moved to scalar registers (the pose is wave-uniform: 24 doubles per frame
+// pair that would otherwise occupy vector registers in every lane of a kernel that has none to spare)
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
 // fixed-order sum over the workgroup; every thread returns with the same totals
 template <int NV>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], double *red)
@@ -538,11 +457,11 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[N * (N + 1) / 2], 
 // one pass over the thread's points adding the entries [LO, HI) of {S packed, b, cost} (per-thread partial sums)
 template <int F, int LO, int HI>
 __device__ __forceinline__ void schur_pass(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
-                                           const double *pts, double lam, double (&acc)[Dims<F>::NV], PtStage<F> *ring)
+                                           const double *pts, double lam, double (&acc)[Dims<F>::NV])
 {
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL;
     auto in = [](int idx) { return idx >= LO && idx < HI; };
-    for_points<F>(P, pts, ring, [&](int, const PtIn<F> &q) {
+    for_points<F>(P, pts, [&](int, const PtIn<F> &q) {
         const double (&p)[3] = q.p;
         double Hpp[6], gp[3], Hcp[NC][3];
         point_linearize<F, true, LO, HI>(P, R, t, p, q, Hpp, gp, Hcp, acc);
@@ -567,11 +486,10 @@ __device__ __forceinline__ void schur_pass(const Prob<F> &P, const double (&R)[F
 // accumulate, reduce over the workgroup and park in LDS (red[4 NV + k]) the entries [LO, HI)
 template <int F, int LO, int HI>
 __device__ __forceinline__ void schur_slice(const Prob<F> &P, const double (&R)[F][9], const double (&t)[F][3],
-                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red,
-                                            PtStage<F> *ring)
+                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
 {
     constexpr int NV = Dims<F>::NV;
-    schur_pass<F, LO, HI>(P, R, t, pts, lam, acc, ring);
+    schur_pass<F, LO, HI>(P, R, t, pts, lam, acc);
     double part[HI - LO];
 #pragma unroll
     for (int k = 0; k < HI - LO; ++k)
@@ -588,8 +506,7 @@ __device__ __forceinline__ void schur_slice(const Prob<F> &P, const double (&R)[
 template <int F>
 __device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &cfg, const double (&R0)[F][9],
                                             const double (&t0)[F][3], const double (&R)[F][9], const double (&t)[F][3],
-                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red,
-                                            PtStage<F> *ring)
+                                            const double *pts, double lam, double (&acc)[Dims<F>::NV], double *red)
 {
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
 #pragma unroll
@@ -597,18 +514,17 @@ __device__ __forceinline__ void build_schur(const Prob<F> &P, const RefineCfg &c
         acc[k] = 0.0;
     // several passes over the thread's points, each owning a slice of the accumulator vector (same per-point operations,
     // same point order per entry, same reduction tree: the sums have the same bits as a single pass); the totals of a
-    // finished slice wait in LDS.  Two frames: rows 0..6 of S | rows 7..9 | rows 10..11, b, cost.
+    // finished slice wait in LDS.  Two frames: rows 0..8 of S | rows 9..11, b, cost.
     if constexpr (F == 2) {
-        schur_slice<F, 0, lidx(7, 0)>(P, R, t, pts, lam, acc, red, ring);
-        schur_slice<F, lidx(7, 0), lidx(10, 0)>(P, R, t, pts, lam, acc, red, ring);
-        schur_slice<F, lidx(10, 0), NV>(P, R, t, pts, lam, acc, red, ring);
+        schur_slice<F, 0, lidx(9, 0)>(P, R, t, pts, lam, acc, red);
+        schur_slice<F, lidx(9, 0), NV>(P, R, t, pts, lam, acc, red);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             acc[k] = red[4 * NV + k];
         __syncthreads();   // the next user of `red` must not overtake the reads above
     } else {
-        schur_pass<F, 0, NV>(P, R, t, pts, lam, acc, ring);
+        schur_pass<F, 0, NV>(P, R, t, pts, lam, acc);
         block_reduce<NV>(acc, red);
     }
 #pragma unroll
@@ -648,8 +564,6 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
     __shared__ double red[5 * NV];   // 4 wavefront partials + the parked totals of build_schur's first pass
     __shared__ double Sinv[NC * NC];
-    __shared__ __attribute__((aligned(16))) PtStage<F> stage[kRefineThreads / 64][2];   // per-wavefront prefetch rings
-    PtStage<F> *ring = stage[threadIdx.x >> 6];
     const int g = blockIdx.x;
     const RefineCfg &cfg = d.cfg;
     Prob<F> P;
@@ -684,17 +598,17 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
         if (d.pose0_all) {   // general two-frame problem: every frame has its own guess (= prior mean)
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                R0[f][k] = d.pose0_all[12 * ((size_t)g * F + f) + k];
+                R0[f][k] = uniform_f64(d.pose0_all[12 * ((size_t)g * F + f) + k]);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                t0[f][k] = d.pose0_all[12 * ((size_t)g * F + f) + 9 + k];
+                t0[f][k] = uniform_f64(d.pose0_all[12 * ((size_t)g * F + f) + 9 + k]);
         } else if (f == F - 1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                R0[f][k] = d.pose0[12 * (size_t)g + k];
+                R0[f][k] = uniform_f64(d.pose0[12 * (size_t)g + k]);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                t0[f][k] = d.pose0[12 * (size_t)g + 9 + k];
+                t0[f][k] = uniform_f64(d.pose0[12 * (size_t)g + 9 + k]);
         } else {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
@@ -721,7 +635,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     double cur;
     {
         double c = 0.0;
-        for_points<F>(P, pts, ring, [&](int, const PtIn<F> &q) { c = c + point_cost<F>(P, R, t, q.p, q); });
+        for_points<F>(P, pts, [&](int, const PtIn<F> &q) { c = c + point_cost<F>(P, R, t, q.p, q); });
         cur = block_reduce1(c, red) + prior_cost<F>(cfg, R0, t0, R, t);
     }
     double lam = cfg.lambda_initial;
@@ -729,7 +643,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     const bool ok0 = cur < __builtin_inf() && cur == cur;
     while (ok0 && it < cfg.max_iterations) {
         double acc[NV];
-        build_schur<F>(P, cfg, R0, t0, R, t, pts, lam, acc, red, ring);
+        build_schur<F>(P, cfg, R0, t0, R, t, pts, lam, acc, red);
         double S[NL], b[NC];
 #pragma unroll
         for (int k = 0; k < NL; ++k)
@@ -758,7 +672,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
                 }
             }
             double c = 0.0;
-            for_points<F>(P, pts, ring, [&](int i, const PtIn<F> &q) {
+            for_points<F>(P, pts, [&](int i, const PtIn<F> &q) {
                 const double (&p)[3] = q.p;
                 double Hpp[6], gp[3], Hcp[NC][3], dummy[NV];
                 point_linearize<F, false>(P, R, t, p, q, Hpp, gp, Hcp, dummy);
@@ -789,10 +703,10 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
             for (int f = 0; f < F; ++f) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
-                    R[f][k] = Rn[f][k];
+                    R[f][k] = uniform_f64(Rn[f][k]);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    t[f][k] = tn[f][k];
+                    t[f][k] = uniform_f64(tn[f][k]);
             }
             double *sw = pts;
             pts = pts_new;
@@ -818,7 +732,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     bool ok = ok0;
     if (ok) {
         double acc[NV];
-        build_schur<F>(P, cfg, R0, t0, R, t, pts, 0.0, acc, red, ring);
+        build_schur<F>(P, cfg, R0, t0, R, t, pts, 0.0, acc, red);
         double S[NL];
 #pragma unroll
         for (int k = 0; k < NL; ++k)
@@ -838,7 +752,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
             __syncthreads();
             if (d.point_cov) {
                 double *pc = d.point_cov + 9 * base;
-                for_points<F>(P, pts, ring, [&](int i, const PtIn<F> &q) {
+                for_points<F>(P, pts, [&](int i, const PtIn<F> &q) {
                     const double (&p)[3] = q.p;
                     double Hpp[6], gp[3], Hcp[NC][3], dummy[NV];
                     point_linearize<F, false>(P, R, t, p, q, Hpp, gp, Hcp, dummy);
