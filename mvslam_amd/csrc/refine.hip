@@ -200,6 +200,22 @@ struct Prob {
     const double *oinfo[F];
     const double *pts0;
     const double *pinfo;
+    // LDS-resident copy of the inputs of points [0, n_res): constants [NCONST][CAP] and the current / trial estimate
+    // [2][3][CAP] (slot `cur` is current)
+    double *res_c, *res_p;
+    int n_res, cur;
+};
+
+// How many points keep their inputs in LDS.  The kernel runs at one wavefront per SIMD, so nothing hides a global load:
+// every visit of a point exposed one full load latency (~2 k clocks, a third of the kernel's cycles after the
+// reductions stopped waiting on ds_bpermute).  A point's inputs are read in every pass (two accumulation passes, the
+// update pass and the cost, per linear solve) but written only here and by the point's own thread, so they live in the
+// 160 KB of LDS the workgroup has to itself: 25 (F = 2) or 20 (F = 1) doubles per point.  Points beyond the capacity
+// keep the global path (a wave-uniform branch: the capacity is a multiple of 64).
+template <int F>
+struct Res {
+    static constexpr int NCONST = 6 + 3 + 2 * F + 3 * F;
+    static constexpr int CAP = F == 2 ? 768 : 960;
 };
 
 // ---- per-point inputs -------------------------------------------------------------------------------------------------
@@ -221,23 +237,44 @@ struct PtIn {
 template <int F, typename Body>
 __device__ __forceinline__ void for_points(const Prob<F> &P, const double *pts, Body body)
 {
+    constexpr int CAP = Res<F>::CAP;
     for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
         PtIn<F> q;
+        if (i < P.n_res) {   // wave-uniform
+            const double *c = P.res_c + i, *pc = P.res_p + (size_t)P.cur * 3 * CAP + i;
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
-            q.L[k] = P.pinfo[6 * (size_t)i + k];
+            for (int k = 0; k < 6; ++k)
+                q.L[k] = c[k * CAP];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            q.p0[k] = P.pts0[3 * (size_t)i + k];
-            q.p[k] = pts[3 * (size_t)i + k];
-        }
+            for (int k = 0; k < 3; ++k) {
+                q.p0[k] = c[(6 + k) * CAP];
+                q.p[k] = pc[k * CAP];
+            }
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-            q.ob[f][0] = P.obs[f][2 * (size_t)i];
-            q.ob[f][1] = P.obs[f][2 * (size_t)i + 1];
+            for (int f = 0; f < F; ++f) {
+                q.ob[f][0] = c[(9 + 5 * f) * CAP];
+                q.ob[f][1] = c[(10 + 5 * f) * CAP];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                q.W[f][k] = P.oinfo[f][3 * (size_t)i + k];
+                for (int k = 0; k < 3; ++k)
+                    q.W[f][k] = c[(11 + 5 * f + k) * CAP];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                q.L[k] = P.pinfo[6 * (size_t)i + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                q.p0[k] = P.pts0[3 * (size_t)i + k];
+                q.p[k] = pts[3 * (size_t)i + k];
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                q.ob[f][0] = P.obs[f][2 * (size_t)i];
+                q.ob[f][1] = P.obs[f][2 * (size_t)i + 1];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    q.W[f][k] = P.oinfo[f][3 * (size_t)i + k];
+            }
         }
         body(i, q);
     }
@@ -564,6 +601,8 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
     constexpr int NC = Dims<F>::NC, NL = Dims<F>::NL, NV = Dims<F>::NV;
     __shared__ double red[5 * NV];   // 4 wavefront partials + the parked totals of build_schur's first pass
     __shared__ double Sinv[NC * NC];
+    __shared__ double res_c[Res<F>::NCONST * Res<F>::CAP];
+    __shared__ double res_p[2 * 3 * Res<F>::CAP];
     const int g = blockIdx.x;
     const RefineCfg &cfg = d.cfg;
     Prob<F> P;
@@ -624,10 +663,36 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
         for (int k = 0; k < 3; ++k)
             t[f][k] = t0[f][k];
     }
+    P.res_c = res_c;
+    P.res_p = res_p;
+    P.n_res = min(P.m, Res<F>::CAP);
+    P.cur = 0;
     for (int i = threadIdx.x; i < P.m; i += kRefineThreads) {
+        double p0[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            pts[3 * (size_t)i + k] = P.pts0[3 * (size_t)i + k];
+        for (int k = 0; k < 3; ++k) {
+            p0[k] = P.pts0[3 * (size_t)i + k];
+            pts[3 * (size_t)i + k] = p0[k];
+        }
+        if (i < P.n_res) {   // the thread that owns point i is the only one that ever touches its LDS entries
+            constexpr int CAP = Res<F>::CAP;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                res_c[k * CAP + i] = P.pinfo[6 * (size_t)i + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                res_c[(6 + k) * CAP + i] = p0[k];
+                res_p[k * CAP + i] = p0[k];
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                res_c[(9 + 5 * f) * CAP + i] = P.obs[f][2 * (size_t)i];
+                res_c[(10 + 5 * f) * CAP + i] = P.obs[f][2 * (size_t)i + 1];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    res_c[(11 + 5 * f + k) * CAP + i] = P.oinfo[f][3 * (size_t)i + k];
+            }
+        }
     }
     __syncthreads();
 
@@ -692,6 +757,11 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     pts_new[3 * (size_t)i + k] = pn[k];
+                if (i < P.n_res) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        res_p[((P.cur ^ 1) * 3 + k) * Res<F>::CAP + i] = pn[k];
+                }
                 c = c + point_cost<F>(P, Rn, tn, pn, q);
             });
             cand = block_reduce1(c, red) + prior_cost<F>(cfg, R0, t0, Rn, tn);
@@ -711,6 +781,7 @@ __global__ __launch_bounds__(kRefineThreads) void refine_kernel(RefineDev d)
             double *sw = pts;
             pts = pts_new;
             pts_new = sw;
+            P.cur ^= 1;
             const double dec = 0.5 * (cur - cand);
             const bool done = dec <= cfg.abs_tol || dec <= cfg.rel_tol * (0.5 * cur);
             cur = cand;
