@@ -427,12 +427,12 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
 template <int VAR>
 __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp)
 {
-    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int pair = blockIdx.y, tid = threadIdx.x;
     const int M = b.M[pair];
     if (M < 8)
         return;
     const int H = rp.num_hypotheses;
-    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
+    const uint32_t h = blockIdx.x * blockDim.x + tid;   // any block size that divides 256 (the launch picks it)
     const uint32_t hh = h < (uint32_t)H ? h : (uint32_t)(H - 1);
     const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
     const double *P = b.pts + (size_t)pair * b.max_kp * 4;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunPar
     for (int k = 0; k < 9; ++k)
         Fo[k] = F[k];
     b.hyp_okf[(size_t)pair * Hp + h] = ok ? 1 : 0;
-    if (g == 0 && tid == 0)
+    if (h == 0)
         b.bound[pair] = 0;   // pruning bound of the scoring launch that follows on the stream
 }
 
@@ -735,25 +735,24 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
         for (int k = 0; k < kCntSlots; ++k)
             alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        double2 pa_n[PPL], pb_n[PPL];
+        // two register sets for the block's points, used alternately: the next block's points are requested before this
+        // block's arithmetic (the uniform branches keep the compiler from hoisting the loads) and the LDS round trip hides
+        // under the four slots; with one set plus a "next" set the loop carried eight v_mov_b64 per block, a fifth of
+        // its vector instructions once two of the four slots have died
+        double2 pa0[PPL], pb0[PPL], pa1[PPL], pb1[PPL];
+        auto load = [&](double2 (&pa)[PPL], double2 (&pb)[PPL], int blk) {
+            const int nb = min(blk, nblk - 1) * BW;
 #pragma unroll
-        for (int u = 0; u < PPL; ++u) {
-            pa_n[u] = L1[u * 64];
-            pb_n[u] = L2[u * 64];
-        }
-        for (int blk = 0; blk < nblk && alive; ++blk) {
+            for (int u = 0; u < PPL; ++u) {
+                pa[u] = L1[nb + u * 64];
+                pb[u] = L2[nb + u * 64];
+            }
+        };
+        auto process = [&](const double2 (&pa)[PPL], const double2 (&pb)[PPL], int blk) {
             double4 p[PPL];
 #pragma unroll
             for (int u = 0; u < PPL; ++u)
-                p[u] = make_double4(pa_n[u].x, pa_n[u].y, pb_n[u].x, pb_n[u].y);
-            // the next block's points are requested before this block's arithmetic (the uniform branches below keep
-            // the compiler from hoisting the loads): the LDS round trip hides under the four slots
-            const int nb = min(blk + 1, nblk - 1) * BW;
-#pragma unroll
-            for (int u = 0; u < PPL; ++u) {
-                pa_n[u] = L1[nb + u * 64];
-                pb_n[u] = L2[nb + u * 64];
-            }
+                p[u] = make_double4(pa[u].x, pa[u].y, pb[u].x, pb[u].y);
             const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
             if (alive & 1u) {
 #pragma unroll
@@ -779,6 +778,15 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
                     c3 += count_block(F3, p[u], thr);
                 if (c3 < need) alive &= ~8u;
             }
+        };
+        load(pa0, pb0, 0);
+        for (int blk = 0; blk < nblk && alive; blk += 2) {
+            load(pa1, pb1, blk + 1);
+            process(pa0, pb0, blk);
+            if (!(blk + 1 < nblk && alive))
+                break;
+            load(pa0, pb0, blk + 2);
+            process(pa1, pb1, blk + 1);
         }
         // a slot that is still alive has seen every point: its count is final
         const int v0 = (alive & 1u) ? c0 : -1, v1 = (alive & 2u) ? c1 : -1;
@@ -1616,8 +1624,15 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
             else
                 launch_ransac_var<120>(b, rp, grid, block, stats, stream);
         } else {
-            if (g_ransac_variant == 1784)
-                hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), grid, block, 0, stream, b, rp);
+            if (g_ransac_variant == 1784) {
+                // one wavefront per workgroup: the kernel runs at one wavefront per SIMD, and a 256-thread workgroup holds
+                // its four SIMDs until its slowest wavefront (one more Jacobi sweep than the others) has finished;
+                // single-wavefront workgroups refill every SIMD on its own: 45.4 -> 44.5 ms per 512 pairs, same bits
+                static const int sb = env_int("MVS_SOLVE_BLOCK", 64);   // experiment knob: 64, 128 or 256
+                const int bs = (sb == 128 || sb == 256) ? sb : 64;
+                hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / bs), n_active), dim3(bs), 0,
+                                   stream, b, rp);
+            }
             else
                 hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
             if (b.hyp_count)
