@@ -31,20 +31,21 @@ namespace mvs {
 // lane's query, running top-2 per lane.  The 16 partial lists are merged through LDS in (distance, train index)
 // order, which reproduces the strict-'<' insertion of a sequential scan (OpenCV brute-force k-NN).
 // ---------------------------------------------------------------------------------------------
-struct Top2 {
-    int d0, i0, d1, i1;
-};
-// insert (d, i) into a (distance, train index)-ordered top-2 list; `use` = false leaves it unchanged
-__device__ __forceinline__ Top2 top2_insert(Top2 t, int d, int i, bool use)
+// The running top-2 of a lane is kept as two KEYS (distance << 16 | train index), k0 <= k1: keys are unique per train
+// row and their order is the (distance, train index) order, i.e. the strict-'<' insertion of a scan in index order.
+// Inserting k is k0' = min(k0, k), k1' = min(k1, max(k0, k)) -- three instructions instead of a divergent compare / shift chain
+// (the kernel is bound by its vector instruction count: 16 for the xor + popcount of 256 bits, 10 for the old insertion).
+constexpr uint32_t kKeyNone = 0xffffffffu;
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
 {
-    const bool b0 = use && ((d < t.d0) || (d == t.d0 && i < t.i0));
-    const bool b1 = use && !b0 && ((d < t.d1) || (d == t.d1 && i < t.i1));
-    Top2 r;
-    r.d1 = b0 ? t.d0 : (b1 ? d : t.d1);
-    r.i1 = b0 ? t.i0 : (b1 ? i : t.i1);
-    r.d0 = b0 ? d : t.d0;
-    r.i0 = b0 ? i : t.i0;
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
     return r;
+}
+__device__ __forceinline__ void key_insert(uint32_t &k0, uint32_t &k1, uint32_t k)
+{
+    k1 = min(k1, max(k0, k));   // = med3(k0, k1, k) given k0 <= k1
+    k0 = min(k0, k);
 }
 
 constexpr int kTopkWaves = 16;
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(1024) void match_topk_kernel(BatchDev b, double rat
 {
     constexpr int kTileRows = kTopkTileBytes / (DW * 4);
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[kTopkTileBytes / 4];
-    __shared__ int s_d0[kTopkWaves][64], s_i0[kTopkWaves][64], s_d1[kTopkWaves][64], s_i1[kTopkWaves][64];
+    __shared__ uint32_t s_k0[kTopkWaves][64], s_k1[kTopkWaves][64];
+    static_assert(DW * 32 < 0xffff && kMaxKp <= 0x10000, "distance and train index share a 32-bit key");
     const int pair = blockIdx.y;
     const int n1 = min(b.n1[pair], b.max_kp), n2 = min(b.n2[pair], b.max_kp);
     const int q0 = blockIdx.x * 64;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(1024) void match_topk_kernel(BatchDev b, double rat
     }
     const uint4 *tr4 = reinterpret_cast<const uint4 *>(b.desc1 + base * DW);
 
-    int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1, i1 = -1;
+    uint32_t k0 = kKeyNone, k1 = kKeyNone;
     for (int tile0 = 0; tile0 < n1; tile0 += kTileRows) {
         const int rows = min(kTileRows, n1 - tile0);
         __syncthreads();  // previous tile fully consumed
@@ -87,39 +89,42 @@ __global__ __launch_bounds__(1024) void match_topk_kernel(BatchDev b, double rat
         const int chunk = (rows + kTopkWaves - 1) / kTopkWaves;
         const int r0 = __builtin_amdgcn_readfirstlane(w * chunk);
         const int r1 = min(rows, r0 + chunk);
-#pragma unroll 4
-        for (int r = r0; r < r1; ++r) {
+        auto row = [&](int r) {
             const uint4 *td = reinterpret_cast<const uint4 *>(s_tile + r * DW);  // wave-uniform -> LDS broadcast
-            int d = 0;
+            uint32_t d = 0;
 #pragma unroll
             for (int k = 0; k < DW; k += 4) {
                 const uint4 v = td[k / 4];
-                d += __popc(qv[k] ^ v.x) + __popc(qv[k + 1] ^ v.y) + __popc(qv[k + 2] ^ v.z) + __popc(qv[k + 3] ^ v.w);
+                d = bcnt_acc(qv[k] ^ v.x, d);       // v_bcnt_u32_b32 adds its second operand: one instruction per
+                d = bcnt_acc(qv[k + 1] ^ v.y, d);   // dword (hipcc otherwise counts into fresh registers and adds
+                d = bcnt_acc(qv[k + 2] ^ v.z, d);   // them up with v_add3: 11 instead of 8 per row)
+                d = bcnt_acc(qv[k + 3] ^ v.w, d);
             }
-            const int t = tile0 + r;
-            // strict '<' insertion: equal distances keep the smaller train index first
-            if (d < d1) {
-                if (d < d0) {
-                    d1 = d0; i1 = i0;
-                    d0 = d;  i0 = t;
-                } else {
-                    d1 = d; i1 = t;
-                }
-            }
+            key_insert(k0, k1, (d << 16) | (uint32_t)(tile0 + r));
+        };
+        int r = r0;   // unrolled by hand: hipcc does not unroll a loop with inline asm in it
+        for (; r + 4 <= r1; r += 4) {
+            row(r);
+            row(r + 1);
+            row(r + 2);
+            row(r + 3);
         }
+        for (; r < r1; ++r)
+            row(r);
     }
 
-    s_d0[w][lane] = d0; s_i0[w][lane] = i0; s_d1[w][lane] = d1; s_i1[w][lane] = i1;
+    s_k0[w][lane] = k0;
+    s_k1[w][lane] = k1;
     __syncthreads();
     if (w == 0 && live) {
-        Top2 t{0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        uint32_t m0 = kKeyNone, m1 = kKeyNone;
 #pragma unroll
         for (int c = 0; c < kTopkWaves; ++c) {
-            const int a0 = s_d0[c][lane], j0 = s_i0[c][lane], a1 = s_d1[c][lane], j1 = s_i1[c][lane];
-            t = top2_insert(t, a0, j0, j0 >= 0);
-            t = top2_insert(t, a1, j1, j1 >= 0);
+            key_insert(m0, m1, s_k0[c][lane]);
+            key_insert(m0, m1, s_k1[c][lane]);
         }
-        const int D0 = t.d0, D1 = t.d1, I0 = t.i0;
+        const int D0 = m0 == kKeyNone ? 0x7fffffff : (int)(m0 >> 16), D1 = m1 == kKeyNone ? 0x7fffffff : (int)(m1 >> 16);
+        const int I0 = m0 == kKeyNone ? -1 : (int)(m0 & 0xffffu);
         // Lowe ratio in double on float distances (visual-feature.cpp:67-68)
         const float f0 = (float)D0, f1 = (float)D1;
         const bool check1 = (double)f0 < ratio * (double)f1;
