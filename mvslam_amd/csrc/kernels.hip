@@ -33,7 +33,7 @@ namespace mvs {
 // ---------------------------------------------------------------------------------------------
 // The running top-2 of a lane is kept as two KEYS (distance << 16 | train index), k0 <= k1: keys are unique per train
 // row and their order is the (distance, train index) order, i.e. the strict-'<' insertion of a scan in index order.
-// Inserting k is k0' = min(k0, k), k1' = min(k1, max(k0, k)) -- three instructions instead of a divergent compare / shift chain
+// Inserting k is k0' = min(k0, k), k1' = med3(k0, k1, k) -- two instructions instead of a divergent compare / shift chain
 // (the kernel is bound by its vector instruction count: 16 for the xor + popcount of 256 bits, 10 for the old insertion).
 constexpr uint32_t kKeyNone = 0xffffffffu;
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
@@ -44,7 +44,9 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
 }
 __device__ __forceinline__ void key_insert(uint32_t &k0, uint32_t &k1, uint32_t k)
 {
-    k1 = min(k1, max(k0, k));   // = med3(k0, k1, k) given k0 <= k1
+    uint32_t m;   // min(k1, max(k0, k)) = the median of the three, given k0 <= k1
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k0), "v"(k1), "v"(k));
+    k1 = m;
     k0 = min(k0, k);
 }
 
