@@ -766,17 +766,32 @@ void orc_sample8(uint64_t seed, uint32_t hyp, int M, int sampler, int idx[8])
 /* estimator-RANSAC.cpp:100-129.  r = |p2^T F p1| (homogeneous 1), fused form:
  *   u_j = fma(x2, F0j, fma(y2, F1j, F2j));  r = |fma(u0, x1, fma(u1, y1, u2))|
  * inlier iff r < max_error_sq (strict); residual += r in index order. */
+/* Study switch (tests/contract_sensitivity.py), 0 everywhere else: 1 = the residual as the reference's own expression
+ * evaluates it -- `p2.transpose() * F * p1` (estimator-RANSAC.cpp:114) is (p2^T F) p1 with Eigen's coefficient-wise
+ * left-to-right sums and no fused multiply-add (x86-64 build without -mfma, SConstruct:86 EIGEN_DONT_VECTORIZE).  It
+ * measures how far the contract's fused form can move an inlier decision or a winner away from the reference's. */
+static int g_residual_form = 0;
+void orc_set_residual_form(int form) { g_residual_form = form; }
+
 int orc_count_inliers(const double *p1, const double *p2, int M, const double F[9], double max_error_sq,
                       uint8_t *mask, double *residual)
 {
     int count = 0;
     double res = 0.0;
+    const int unfused = g_residual_form == 1;
     for (int i = 0; i < M; ++i) {
         double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        double r;
+        if (unfused) {
+            const double v0 = (x2 * F[0] + y2 * F[3]) + F[6], v1 = (x2 * F[1] + y2 * F[4]) + F[7],
+                         v2 = (x2 * F[2] + y2 * F[5]) + F[8];
+            r = fabs((v0 * x1 + v1 * y1) + v2);
+        } else {
         double u0 = fma(x2, F[0], fma(y2, F[3], F[6]));
         double u1 = fma(x2, F[1], fma(y2, F[4], F[7]));
         double u2 = fma(x2, F[2], fma(y2, F[5], F[8]));
-        double r = fabs(fma(u0, x1, fma(u1, y1, u2)));
+        r = fabs(fma(u0, x1, fma(u1, y1, u2)));
+        }
         if (r < max_error_sq) {
             ++count;
             res += r;

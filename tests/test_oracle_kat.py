@@ -331,3 +331,29 @@ def test_golden_rig():
     r = o.sfm_solve(g["L_uv1"], g["L_uv2"], np.eye(3), o.make_params(1, o.SAMPLER_IDENTITY))
     assert r["R"].tobytes() == g["L_R"].tobytes() and r["points"].tobytes() == g["L_points"].tobytes()
     assert np.abs(r["points"] - g["L_X"]).max() < 1e-3
+
+
+# ---------------------------------------------------------------- the contract's fused residual vs the reference's form
+def test_unfused_reference_residual_is_a_different_rounding_but_the_same_decisions():
+    """tests/contract_sensitivity.py's switch: the reference's `p2^T F p1` (estimator-RANSAC.cpp:114, separate mul / add)
+    differs from the contract's fused residual in the last bits, and on a synthetic pair decides every match the same way
+    (the full-size study: profiles/r02_contract_sensitivity.json)."""
+    import contract_sensitivity as cs
+    from mvslam_amd import synth
+
+    p = synth.make_pair(3, n_kp=400)
+    ref = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(300, o.SAMPLER_PHILOX, 9, 1e-2), 0.7, 10.0)
+    Kinv = np.linalg.inv(p["K"])
+    mt = ref["matches"]
+    x1 = (Kinv @ np.c_[p["kp1"][mt["trainIdx"]].astype(float), np.ones(len(mt))].T).T[:, :2]
+    x2 = (Kinv @ np.c_[p["kp2"][mt["queryIdx"]].astype(float), np.ones(len(mt))].T).T[:, :2]
+    try:
+        n0, r0, m0 = o.count_inliers(x1, x2, ref["F"], 1e-2)
+        o.lib().orc_set_residual_form(1)
+        n1, r1, m1 = o.count_inliers(x1, x2, ref["F"], 1e-2)
+    finally:
+        o.lib().orc_set_residual_form(0)
+    assert n0 == n1 and np.array_equal(m0, m1)
+    assert r0 != r1 and abs(r0 - r1) <= 1e-12 * abs(r0)      # another rounding of the same sum
+    out = cs.run(2, 400, 1e-2, n_kp=300, threads=2)
+    assert out["winners_changed"] == 0 and out["mask_bits_flipped"] == 0
