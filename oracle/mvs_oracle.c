@@ -292,6 +292,12 @@ void orc_debug_set_jacobi_trace(uint64_t *buf, size_t cap)
 }
 size_t orc_debug_jacobi_trace_len(void) { return g_trace_len; }
 
+/* Study switch (tests/contract_sensitivity.py), 0 everywhere else: 1 = the Jacobi inner loops in OpenCV's literal forms
+ * (lapack.cpp JacobiSVDImpl_: p += Ai[k]*Aj[k]; gamma = hypot(p, beta); t0 = c*Ai[k] + s*Aj[k]; t1 = -s*Ai[k] + c*Aj[k];
+ * a += t0*t0) compiled without contraction, instead of the contract's fused ones. */
+static int g_jacobi_form = 0;
+void orc_set_jacobi_form(int form) { g_jacobi_form = form; }
+
 static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n1, int which)
 {
     const double eps = DBL_EPSILON * 10.0;
@@ -304,7 +310,7 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
         double sd = 0.0;
         for (int k = 0; k < m; ++k) {
             double t = At[i * m + k];
-            sd = fma(t, t, sd);
+            sd = g_jacobi_form ? sd + t * t : fma(t, t, sd);
         }
         W[i] = sd;
         if (Vt) {
@@ -325,12 +331,12 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
                 ++pairs;
                 ++pair_idx;
                 for (int k = 0; k < m; ++k)
-                    p = fma(Ai[k], Aj[k], p);
+                    p = g_jacobi_form ? p + Ai[k] * Aj[k] : fma(Ai[k], Aj[k], p);
                 if (fabs(p) <= eps * sqrt(a * b))
                     continue;
                 p *= 2.0;
                 double beta = a - b;
-                double gamma = sqrt(fma(p, p, beta * beta));
+                double gamma = g_jacobi_form ? hypot(p, beta) : sqrt(fma(p, p, beta * beta));
                 double c, s;
                 if (beta < 0.0) {
                     double delta = (gamma - beta) * 0.5;
@@ -343,12 +349,12 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
                 a = 0.0;
                 b = 0.0;
                 for (int k = 0; k < m; ++k) {
-                    double t0 = fma(c, Ai[k], s * Aj[k]);
-                    double t1 = fma(c, Aj[k], -(s * Ai[k]));
+                    double t0 = g_jacobi_form ? c * Ai[k] + s * Aj[k] : fma(c, Ai[k], s * Aj[k]);
+                    double t1 = g_jacobi_form ? -s * Ai[k] + c * Aj[k] : fma(c, Aj[k], -(s * Ai[k]));
                     Ai[k] = t0;
                     Aj[k] = t1;
-                    a = fma(t0, t0, a);
-                    b = fma(t1, t1, b);
+                    a = g_jacobi_form ? a + t0 * t0 : fma(t0, t0, a);
+                    b = g_jacobi_form ? b + t1 * t1 : fma(t1, t1, b);
                 }
                 W[i] = a;
                 W[j] = b;
@@ -358,8 +364,8 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
                 if (Vt) {
                     double *Vi = Vt + i * n, *Vj = Vt + j * n;
                     for (int k = 0; k < n; ++k) {
-                        double t0 = fma(c, Vi[k], s * Vj[k]);
-                        double t1 = fma(c, Vj[k], -(s * Vi[k]));
+                        double t0 = g_jacobi_form ? c * Vi[k] + s * Vj[k] : fma(c, Vi[k], s * Vj[k]);
+                        double t1 = g_jacobi_form ? -s * Vi[k] + c * Vj[k] : fma(c, Vj[k], -(s * Vi[k]));
                         Vi[k] = t0;
                         Vj[k] = t1;
                     }
@@ -380,7 +386,7 @@ static void jacobi_svd(double *At, int m, int n, double *Wout, double *Vt, int n
         double sd = 0.0;
         for (int k = 0; k < m; ++k) {
             double t = At[i * m + k];
-            sd = fma(t, t, sd);
+            sd = g_jacobi_form ? sd + t * t : fma(t, t, sd);
         }
         W[i] = sqrt(sd);
     }

@@ -104,6 +104,7 @@ int orc_ransac_fundamental(const double *p1, const double *p2, int M, double max
                            double *best_residual, int32_t *per_hyp_count, double *per_hyp_residual);
 /* study switch, see mvs_oracle.c; 0 = the contract's fused residual (default) */
 void orc_set_residual_form(int form);
+void orc_set_jacobi_form(int form);
 int orc_count_inliers(const double *p1, const double *p2, int M, const double F[9], double max_error_sq,
                       uint8_t *mask, double *residual); /* estimator-RANSAC.cpp:100-129 */
 

@@ -356,4 +356,4 @@ def test_unfused_reference_residual_is_a_different_rounding_but_the_same_decisio
     assert n0 == n1 and np.array_equal(m0, m1)
     assert r0 != r1 and abs(r0 - r1) <= 1e-12 * abs(r0)      # another rounding of the same sum
     out = cs.run(2, 400, 1e-2, n_kp=300, threads=2)
-    assert out["winners_changed"] == 0 and out["mask_bits_flipped"] == 0
+    assert out["winners_changed"] == 0 and out["mask_bits_flipped"] == 0 and out["pairs_with_another_pose"] == 0
