@@ -259,6 +259,34 @@ int mvs_debug_fastmath_check(mvs_ctx *ctx, const double *x, const double *y, int
     return MVS_OK;
 }
 
+// diagnostics only: one guarded Jacobi pair step per row pair against the IEEE one (pairstep_check_kernel).
+// rows: n x 6 doubles.  counts[3] = {steps that differ, steps compared, decisions that differ}
+int mvs_debug_pairstep_check(mvs_ctx *ctx, const double *rows, int n, unsigned long long counts[3])
+{
+    if (!ctx || n < 1)
+        return MVS_ERR_INVALID_ARG;
+    double *dr = nullptr;
+    unsigned long long *dc = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc((void **)&dr, (size_t)n * 48));
+    if (hipMalloc((void **)&dc, 32) != hipSuccess) {
+        (void)hipFree(dr);
+        return MVS_ERR_HIP;
+    }
+    hipError_t e = hipMemcpyAsync(dr, rows, (size_t)n * 48, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dc, 0, 32, ctx->stream);
+    if (e == hipSuccess) {
+        launch_pairstep_check(dr, n, dc, ctx->stream);
+        e = hipMemcpyAsync(counts, dc, 24, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dr);
+    (void)hipFree(dc);
+    return e == hipSuccess ? MVS_OK : MVS_ERR_HIP;
+}
+
 // diagnostics only (not in the public header): pick a co-compiled ransac_kernel variant for A/B timing
 int mvs_debug_set_ransac_variant(int v)
 {

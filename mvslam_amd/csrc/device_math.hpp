@@ -88,6 +88,36 @@ MVS_DEV double sqrt_fast_nz(double x)
     g = dfma(d, h, g);
     return g;
 }
+// sqrt_fast_nz that also hands out its by-product h ~ 1 / (2 sqrt(x)): the refined half reciprocal root of the
+// sequence (relative error ~2^-50 after the one quadratic refinement of the 2^-26 v_rsq_f64 seed)
+MVS_DEV double sqrt_fast_nz_h(double x, double &h_out)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = dfma(-h, g, 0.5);
+    g = dfma(g, r, g);
+    h = dfma(h, r, h);
+    double d = dfma(-g, g, x);
+    g = dfma(d, h, g);
+    d = dfma(-g, g, x);
+    g = dfma(d, h, g);
+    h_out = h;
+    return g;
+}
+// n / d from a reciprocal estimate r0 ~ 1 / d good to ~2^-45 or better: ONE Newton step brings it to the last bit (what
+// div_fast's two steps do from v_rcp_f64's 2^-26), then the same quotient / remainder / correction as div_fast.
+// v_rcp_f64 and v_rsq_f64 cost three v_fma_f64 each (profiles/r02_trans_issue_microbench.txt): a rotation's two divisions
+// take their estimates from the two square roots' by-products instead (jacobi_pair) -- no v_rcp_f64, one Newton step less.
+// The whole pair step is compared bit for bit with the IEEE one on 2^25 row pairs (test_rotation_parameters_are_ieee_exact).
+MVS_DEV double div_seeded(double n, double d, double r0)
+{
+    const double e = dfma(-d, r0, 1.0);
+    const double r = dfma(r0, e, r0);
+    const double q = n * r;
+    const double rem = dfma(-d, q, n);
+    return dfma(rem, r, q);
+}
 MVS_DEV double div_fast(double n, double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -178,6 +208,20 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
             }
             // CHEAP: g2 >= 2^-400 and num / den in [1/2, 1] are guarded (a violated guard recomputes the wavefront with
             // the full sequences), so neither root needs sqrt_fast's zero / infinity select
+#ifndef MVS_NO_SEEDED_DIV
+            if (CHEAP) {
+                // ((gamma - beta) / 2) / gamma for beta < 0 and (gamma + beta) / (2 gamma) otherwise are the SAME real
+                // number (t / 2) / gamma, t = gamma + |beta| (the halvings / doublings are exact inside the guard, so
+                // they commute with the roundings): no candidates, no selects.  Both divisions take their reciprocal
+                // estimates from the by-products of the two square roots (div_seeded).
+                double hg, hx;
+                const double gamma = sqrt_fast_nz_h(g2, hg);           // hg ~ 1 / (2 gamma)
+                const double t = gamma + dabs(beta);
+                x = sqrt_fast_nz_h(div_seeded(t * 0.5, gamma, hg + hg), hx);   // hx ~ 1 / (2 x)
+                y = div_seeded(p, gamma * x * 2.0, (hg * hx) * 2.0);
+            } else
+#endif
+            {
             const double gamma = CHEAP ? sqrt_fast_nz(g2) : sqrt_fast(g2);
             if (CHEAP) {
                 // gamma - beta == gamma + |beta| for beta < 0, and the halving / doubling are exact inside the guard:
@@ -191,6 +235,7 @@ MVS_DEV void jacobi_pair(double (&Ai)[M], double (&Aj)[M], double (&Vi)[N], doub
             }
             x = CHEAP ? sqrt_fast_nz(div_fast(num, den)) : sqrt_fast(div_fast(num, den));
             y = div_fast(p, gamma * x * 2.0);
+            }
         } else {
             const double gamma = dsqrt(g2);
             const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);

@@ -1659,6 +1659,58 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
     hipLaunchKernelGGL(finalize_select_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b);
 }
 
+// diagnostics: one Jacobi pair step on two rows of three elements, guarded (unscaled sequences, seeded divisions) against
+// the compiler's IEEE sqrt / division, bit for bit.  rows: n x 6 doubles (row i, row j).  out[0] = steps whose rotated
+// rows or norms differ, out[1] = steps compared (both rotate, guards hold), out[2] = steps where the decision differs
+__global__ __launch_bounds__(256) void pairstep_check_kernel(const double *rows, int n, unsigned long long *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    double A[2][2][3], V[2][2][3], W[2][2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double sd = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                A[v][r][k] = rows[(size_t)i * 6 + r * 3 + k];
+                V[v][r][k] = r == k ? 1.0 : 0.0;
+                sd = dfma(A[v][r][k], A[v][r][k], sd);
+            }
+            W[v][r] = sd;
+        }
+    }
+    bool ch0 = false, ch1 = false, bad0 = false, bad1 = false;
+    unsigned r0 = 0, r1 = 0;
+    double q0 = 0x1p1000, q1 = 0x1p1000;
+    jacobi_pair<3, 3, true, true, true, true>(A[0][0], A[0][1], V[0][0], V[0][1], W[0][0], W[0][1], ch0, r0, bad0, q0);
+    jacobi_pair<3, 3, true, false, false, false>(A[1][0], A[1][1], V[1][0], V[1][1], W[1][0], W[1][1], ch1, r1, bad1, q1);
+    if (ch0 != ch1) {
+        atomicAdd(&out[2], 1ull);
+        return;
+    }
+    if (!ch0 || !(q0 >= kGuardQMin) || !(W[1][0] + W[1][1] <= kGuardWSumMax))
+        return;
+    atomicAdd(&out[1], 1ull);
+    bool same = __double_as_longlong(W[0][0]) == __double_as_longlong(W[1][0]) &&
+                __double_as_longlong(W[0][1]) == __double_as_longlong(W[1][1]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            same = same && __double_as_longlong(A[0][r][k]) == __double_as_longlong(A[1][r][k]) &&
+                   __double_as_longlong(V[0][r][k]) == __double_as_longlong(V[1][r][k]);
+    if (!same)
+        atomicAdd(&out[0], 1ull);
+}
+
+void launch_pairstep_check(const double *rows, int n, unsigned long long *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pairstep_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rows, n, out);
+}
+
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(fastmath_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, out);

@@ -257,6 +257,7 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
 void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)
 int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);
+void launch_pairstep_check(const double *rows, int n, unsigned long long *out, hipStream_t stream);
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream);
 
 }  // namespace mvs

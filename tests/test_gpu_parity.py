@@ -100,6 +100,51 @@ def test_unscaled_sqrt_div_are_ieee_exact(ctx):
     assert counts[1] == 0, "div_fast differs from IEEE division on %d operand pairs" % counts[1]
 
 
+def test_rotation_parameters_are_ieee_exact(ctx):
+    """The guarded pair step (unscaled sqrt sequences, divisions seeded from the square roots' by-products instead of
+    v_rcp_f64, one Newton step) against the same step with the compiler's IEEE sqrt and division: rotated rows, V rows and
+    norms bit for bit, on 2^25 row pairs in the regimes the solve visits -- generic, nearly orthogonal (late sweeps),
+    very different norms (the null direction), equal norms, scaled by 2^-60 .. 2^60."""
+    import ctypes as C
+
+    dbg = C.CDLL(capi.DBG_LIB_PATH)
+    h = C.c_void_p()
+    assert dbg.mvs_ctx_create(C.c_int(0), C.byref(h)) == 0
+    dbg.mvs_ctx_destroy.argtypes = [C.c_void_p]
+    dbg.mvs_debug_pairstep_check.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_ulonglong)]
+    rng = np.random.default_rng(2026)
+    n = 1 << 22
+    total = 0
+    try:
+        for regime in range(8):
+            a = rng.normal(size=(n, 3))
+            b = rng.normal(size=(n, 3))
+            if regime in (1, 5):      # nearly orthogonal: the dot product is 1e-3 .. 1e-13 of the norms
+                b -= (np.einsum("ij,ij->i", a, b) / np.einsum("ij,ij->i", a, a))[:, None] * a
+                b += a * (10.0 ** rng.uniform(-13, -3, size=(n, 1))) * rng.choice([-1.0, 1.0], size=(n, 1))
+            if regime in (2, 6):      # one row tiny
+                b *= 10.0 ** rng.uniform(-17, -2, size=(n, 1))
+            if regime == 3:           # equal norms: beta ~ 0, either sign
+                b *= (np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1))[:, None] * (1 + rng.normal(scale=1e-15, size=(n, 1)))
+            if regime in (4, 5, 6):   # common scale
+                sc = np.ldexp(1.0, rng.integers(-60, 60, size=(n, 1)))
+                a *= sc
+                b *= sc
+            if regime == 7:           # swapped roles (beta < 0 with a tiny first row)
+                a, b = b * 10.0 ** rng.uniform(-12, 0, size=(n, 1)), a
+            rows = np.ascontiguousarray(np.concatenate([a, b], axis=1))
+            counts = (C.c_ulonglong * 3)()
+            st = dbg.mvs_debug_pairstep_check(h, rows.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(n), counts)
+            assert st == 0
+            assert counts[2] == 0, "regime %d: %d rotate / skip decisions differ" % (regime, counts[2])
+            assert counts[0] == 0, "regime %d: %d of %d pair steps differ from the IEEE one" % (regime, counts[0], counts[1])
+            assert counts[1] > n // 2, "regime %d compared only %d steps" % (regime, counts[1])
+            total += counts[1]
+    finally:
+        dbg.mvs_ctx_destroy(h)
+    print("pair steps compared bit for bit:", total)
+
+
 # ----------------------------------------------------------------------------- 8-point
 def test_find_fundamental_bitwise(ctx):
     """The whole solve chain (normalise, A^T A, 9x9 + 3x3 Jacobi SVD, sqrt / div / fma) bit for bit."""
