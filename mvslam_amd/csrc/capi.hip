@@ -260,8 +260,9 @@ int mvs_debug_fastmath_check(mvs_ctx *ctx, const double *x, const double *y, int
 }
 
 // diagnostics only: one guarded Jacobi pair step per row pair against the IEEE one (pairstep_check_kernel).
-// rows: n x 6 doubles.  counts[3] = {steps that differ, steps compared, decisions that differ}
-int mvs_debug_pairstep_check(mvs_ctx *ctx, const double *rows, int n, unsigned long long counts[3])
+// rows: n x 6 doubles.  counts[4] = {steps that differ, steps compared, decisions that differ, bits of the largest
+// |1 - gamma * 2 h| seen (accuracy of the reciprocal estimate the seeded divisions start from)}
+int mvs_debug_pairstep_check(mvs_ctx *ctx, const double *rows, int n, unsigned long long counts[4])
 {
     if (!ctx || n < 1)
         return MVS_ERR_INVALID_ARG;
@@ -278,7 +279,7 @@ int mvs_debug_pairstep_check(mvs_ctx *ctx, const double *rows, int n, unsigned l
         e = hipMemsetAsync(dc, 0, 32, ctx->stream);
     if (e == hipSuccess) {
         launch_pairstep_check(dr, n, dc, ctx->stream);
-        e = hipMemcpyAsync(counts, dc, 24, hipMemcpyDeviceToHost, ctx->stream);
+        e = hipMemcpyAsync(counts, dc, 32, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);

@@ -1682,6 +1682,13 @@ __global__ __launch_bounds__(256) void pairstep_check_kernel(const double *rows,
             W[v][r] = sd;
         }
     }
+    {   // accuracy of the reciprocal estimate the divisions start from: max |1 - gamma * 2 h| as double bits in out[3]
+        const double g2 = dfma(W[0][0], W[0][0], W[0][1] * W[0][1]) + 0x1p-300;
+        double h;
+        const double gamma = sqrt_fast_nz_h(g2, h);
+        const double e = dabs(dfma(-gamma, h + h, 1.0));
+        atomicMax(&out[3], (unsigned long long)__double_as_longlong(e));
+    }
     bool ch0 = false, ch1 = false, bad0 = false, bad1 = false;
     unsigned r0 = 0, r1 = 0;
     double q0 = 0x1p1000, q1 = 0x1p1000;

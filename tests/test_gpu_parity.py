@@ -114,7 +114,7 @@ def test_rotation_parameters_are_ieee_exact(ctx):
     dbg.mvs_debug_pairstep_check.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_ulonglong)]
     rng = np.random.default_rng(2026)
     n = 1 << 22
-    total = 0
+    total, seed_err = 0, 0.0
     try:
         for regime in range(8):
             a = rng.normal(size=(n, 3))
@@ -133,16 +133,18 @@ def test_rotation_parameters_are_ieee_exact(ctx):
             if regime == 7:           # swapped roles (beta < 0 with a tiny first row)
                 a, b = b * 10.0 ** rng.uniform(-12, 0, size=(n, 1)), a
             rows = np.ascontiguousarray(np.concatenate([a, b], axis=1))
-            counts = (C.c_ulonglong * 3)()
+            counts = (C.c_ulonglong * 4)()
             st = dbg.mvs_debug_pairstep_check(h, rows.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(n), counts)
             assert st == 0
             assert counts[2] == 0, "regime %d: %d rotate / skip decisions differ" % (regime, counts[2])
             assert counts[0] == 0, "regime %d: %d of %d pair steps differ from the IEEE one" % (regime, counts[0], counts[1])
             assert counts[1] > n // 2, "regime %d compared only %d steps" % (regime, counts[1])
             total += counts[1]
+            seed_err = max(seed_err, float(np.frombuffer(np.uint64(counts[3]).tobytes(), dtype=np.float64)[0]))
     finally:
         dbg.mvs_ctx_destroy(h)
-    print("pair steps compared bit for bit:", total)
+    print("pair steps compared bit for bit:", total, " largest error of the reciprocal estimate: 2^%.1f" % np.log2(seed_err))
+    assert seed_err < 2.0 ** -45       # div_seeded's one Newton step starts from this
 
 
 # ----------------------------------------------------------------------------- 8-point
