@@ -255,7 +255,7 @@ def main():
                 "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3),
                 # north_star: occupancy / LDS of the RANSAC kernel (hipcc -Rpass-analysis=kernel-resource-usage)
                 "occupancy_waves_per_simd": {"solve": 1, "count": 7, "select": 6},
-                "vgprs": {"solve": 256, "count": 70, "select": 78}, "agprs": {"solve": 148, "count": 0, "select": 0},
+                "vgprs": {"solve": 256, "count": 70, "select": 78}, "agprs": {"solve": 147, "count": 0, "select": 0},
                 "scratch_bytes": 0, "lds_bytes_per_workgroup": {"solve": 0, "count": 32 * ((args.kp + 127) // 128) * 128, "select": 32 * args.kp},
                 "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
                                    "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"},
