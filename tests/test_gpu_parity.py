@@ -104,7 +104,7 @@ def test_rotation_parameters_are_ieee_exact(ctx):
     """The guarded pair step (unscaled sqrt sequences, divisions seeded from the square roots' by-products instead of
     v_rcp_f64, one Newton step) against the same step with the compiler's IEEE sqrt and division: rotated rows, V rows and
     norms bit for bit, on 2^25 row pairs in the regimes the solve visits -- generic, nearly orthogonal (late sweeps),
-    very different norms (the null direction), equal norms, scaled by 2^-60 .. 2^60."""
+    very different norms (the null direction), equal norms, scaled by 2^-95 .. 2^95 (the whole guarded range)."""
     import ctypes as C
 
     dbg = C.CDLL(capi.DBG_LIB_PATH)
@@ -126,8 +126,8 @@ def test_rotation_parameters_are_ieee_exact(ctx):
                 b *= 10.0 ** rng.uniform(-17, -2, size=(n, 1))
             if regime == 3:           # equal norms: beta ~ 0, either sign
                 b *= (np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1))[:, None] * (1 + rng.normal(scale=1e-15, size=(n, 1)))
-            if regime in (4, 5, 6):   # common scale
-                sc = np.ldexp(1.0, rng.integers(-60, 60, size=(n, 1)))
+            if regime in (4, 5, 6):   # common scale, up to the edge of the guarded range (row norms 2^-190 .. 2^190)
+                sc = np.ldexp(1.0, rng.integers(-95, 96, size=(n, 1)) if regime == 4 else rng.integers(-60, 60, size=(n, 1)))
                 a *= sc
                 b *= sc
             if regime == 7:           # swapped roles (beta < 0 with a tiny first row)
@@ -138,7 +138,7 @@ def test_rotation_parameters_are_ieee_exact(ctx):
             assert st == 0
             assert counts[2] == 0, "regime %d: %d rotate / skip decisions differ" % (regime, counts[2])
             assert counts[0] == 0, "regime %d: %d of %d pair steps differ from the IEEE one" % (regime, counts[0], counts[1])
-            assert counts[1] > n // 2, "regime %d compared only %d steps" % (regime, counts[1])
+            assert counts[1] > n // 3, "regime %d compared only %d steps" % (regime, counts[1])
             total += counts[1]
             seed_err = max(seed_err, float(np.frombuffer(np.uint64(counts[3]).tobytes(), dtype=np.float64)[0]))
     finally:
