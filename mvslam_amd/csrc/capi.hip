@@ -2240,7 +2240,9 @@ static bool orb_layout_host(int w, int h, const mvs_orb_params &p, OrbDev &d, si
     double nd = (double)p.nfeatures * (1.0 - factor) / (1.0 - fn);
     int sum = 0;
     for (int l = 0; l < p.nlevels - 1; ++l) {
-        d.level[l].n_keep = (int)std::lrint(nd);
+        // the rounded shares can add up to more than nfeatures when nfeatures is small (cv::ORB then returns more
+        // keypoints than asked for); the outputs have room for nfeatures: a level takes at most what is left
+        d.level[l].n_keep = std::min((int)std::lrint(nd), p.nfeatures - sum);
         sum += d.level[l].n_keep;
         nd = nd * factor;
     }

@@ -80,7 +80,12 @@ int orc_orb_layout(int w, int h, const orc_orb_params *p, int *lw, int *lh, int 
     double nd = (double)p->nfeatures * (1.0 - factor) / (1.0 - fn);
     int sum = 0;
     for (int l = 0; l < p->nlevels - 1; ++l) {
+        /* cv::ORB rounds every level's share; for small nfeatures (< ~60 at 8 levels) the rounded shares can add up to
+         * MORE than nfeatures, and cv::ORB then returns more keypoints than it was asked for.  The outputs here have
+         * room for nfeatures: a level takes at most what is left (the kernel's host side clamps the same way). */
         nl[l] = (int)lrint(nd);
+        if (nl[l] > p->nfeatures - sum)
+            nl[l] = p->nfeatures - sum;
         sum += nl[l];
         nd = nd * factor;
     }

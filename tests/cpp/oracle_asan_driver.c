@@ -79,6 +79,19 @@ int main(void)
         int nk = 0;
         int oke = orc_orb_extract(im, W, H, &op, kk, dd, &nk);
         printf("orb ok=%d n=%d\n", oke, nk > 50);
+        // small feature counts: the rounded per-level shares add up to more than nfeatures (7 -> 2+1+1+1+1+1+1 = 8);
+        // outputs sized for exactly nfeatures must not be overrun
+        for (int nf = 1; nf <= 24; ++nf) {
+            orc_keypoint *k2 = (orc_keypoint *)malloc(sizeof(orc_keypoint) * nf);
+            uint8_t *d2 = (uint8_t *)malloc(32 * (size_t)nf);
+            op.nfeatures = nf;
+            op.fast_threshold = 5;
+            int n2 = 0;
+            oke &= orc_orb_extract(im, W, H, &op, k2, d2, &n2) && n2 <= nf;
+            free(k2);
+            free(d2);
+        }
+        printf("orb small ok=%d\n", oke);
     }
     free(d1); free(d2); free(k1); free(k2); free(m); free(mask); free(pts); free(idx);
     return 0;

@@ -221,6 +221,33 @@ def test_gpu_extract_bit_exact(ctx, case):
         assert got["n"].min() > 1500
 
 
+def test_small_feature_counts_never_exceed_nfeatures():
+    """cv::ORB rounds every level's share of nfeatures; for small counts the shares add up to more than nfeatures
+    (7 features over 8 levels: 2+1+1+1+1+1+1 = 8).  The outputs have room for nfeatures: a level takes what is left."""
+    img = textured(3112, 317, 204)      # the soak case that found it (seed 2309)
+    for nf in range(1, 26):
+        r = o.orb_extract(img, o.make_orb_params(nfeatures=nf, nlevels=8, fast_threshold=60, edge_threshold=19))
+        assert len(r["kp"]) <= nf
+
+
+@pytest.mark.gpu
+def test_gpu_extract_small_feature_counts(ctx):
+    """the same clamp on the device side: two images per call, so that an overrun of the first image's rows would land
+    in the second image's"""
+    from mvslam_amd import capi
+
+    imgs = np.stack([textured(3112, 317, 204), textured(3113, 317, 204)])
+    for nf in (1, 2, 3, 5, 7, 8, 11, 16, 23):
+        prm = dict(nfeatures=nf, nlevels=8, fast_threshold=60, edge_threshold=19)
+        got = ctx.extract(imgs, capi.default_orb_params(**prm))
+        for i in range(2):
+            want = o.orb_extract(imgs[i], o.make_orb_params(**prm))
+            n = int(got["n"][i])
+            assert n == len(want["kp"]) <= nf
+            assert np.array_equal(got["kp"][i][:n], want["kp"].astype(capi.KEYPOINT_DTYPE))
+            assert np.array_equal(got["desc"][i][:n], want["desc"])
+
+
 @pytest.mark.gpu
 def test_gpu_extract_against_golden_and_argument_errors(ctx):
     from mvslam_amd import capi

@@ -14,4 +14,4 @@ def test_oracle_is_clean_under_asan_ubsan(tmp_path):
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode == 0, out
-    assert "image_pair ok=1" in out and "pnp ok=1" in out and "refine ok=1 1" in out and "orb ok=1 n=1" in out and "ERROR" not in out and "runtime error" not in out
+    assert "image_pair ok=1" in out and "pnp ok=1" in out and "refine ok=1 1" in out and "orb ok=1 n=1" in out and "orb small ok=1" in out and "ERROR" not in out and "runtime error" not in out
