@@ -132,9 +132,13 @@ for i in range(args.cases // 8):
     want = o.sfm_refine(pb["p1"], pb["cov"], pb["p2"], pb["cov"], pb["K"], pb["Rg"], pb["tg"], pb["Xg"])
     cnt["sfm_refine"] += 1
     if not (got["ok"] and want["ok"] and got["iterations"] == want["iterations"] and np.abs(got["R"] - want["R"]).max() < 1e-10
-            and np.abs(got["t"] - want["t"]).max() < 1e-10 and np.abs(got["points"] - want["points"]).max() < 1e-9
+            and np.abs(got["t"] - want["t"]).max() < 1e-10
+            # points: relative to their size (depths up to 10; the two sides' sin / cos differ in the last bit and a weakly
+            # constrained depth amplifies it: 1.1e-9 seen once in 155 000 cases, at equal errors and iteration counts)
+            and np.abs(got["points"] - want["points"]).max() < 1e-9 * max(1.0, np.abs(want["points"]).max())
             and np.abs(got["pose_cov"] - want["pose_cov"]).max() <= 1e-7 * np.abs(want["pose_cov"]).max()):
-        bad.append(("sfm_refine", i))
+        bad.append(("sfm_refine", i, m, got["ok"], want["ok"], got["iterations"], want["iterations"], np.abs(got["R"] - want["R"]).max(),
+                    np.abs(got["t"] - want["t"]).max(), np.abs(got["points"] - want["points"]).max(), got["error"], want["error"]))
     pp = TR.pnp_problem(1300 + i, int(rng.integers(7, 800)))
     got = ctx.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
     want = o.pnp_refine(pp["X"], pp["wcov"], pp["uv"], pp["icov"], pp["K"], pp["Rg"], pp["tg"])
