@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle soak over every entry point (more cases than the test-suite keeps).  Integer / index outputs
+"""Randomised GPU-vs-oracle soak over every entry point, resident sequences included (more cases than the test-suite keeps).  Integer / index outputs
 must agree bit for bit, floating point within the tolerances of the tests.  Prints one JSON summary line; exit code 1
 on any mismatch.  usage: python tools/soak.py [--cases 200] [--seed 2026]"""
 import argparse, json, os, sys, time
@@ -13,6 +13,7 @@ import test_gpu_parity as TG
 import test_pnp as TP
 import test_refine as TR
 import test_orb as TO
+import test_sequence as TS
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=200)
@@ -22,7 +23,7 @@ rng = np.random.default_rng(args.seed)
 PAIR0 = 10_000 + (args.seed - 2026) * 1000   # synthetic pair ids of part 1
 ctx = capi.Context(0)
 bad = []
-cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0)
+cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0, sequence_frames=0)
 t0 = time.time()
 
 # 1. whole image pairs through the batch API: ragged keypoint counts, varying noise / outliers / hypothesis counts
@@ -162,6 +163,44 @@ for i in range(args.cases // 8):
     if not (n == len(want["kp"]) and np.array_equal(got["kp"][0][:n], want["kp"].astype(capi.KEYPOINT_DTYPE))
             and np.array_equal(got["desc"][0][:n], want["desc"])):
         bad.append(("extract", i, h, w, kw))
+# 6. resident sequences: random lengths / sizes / hypothesis counts; pair views, the join, the batched PnP and the
+# trajectory fold against the composed oracle, bit for bit
+for i in range(max(1, args.cases // 40)):
+    F, N = int(rng.integers(3, 9)), int(rng.integers(150, 450))
+    seq = synth.make_sequence(F, n_kp=N, n_map=int(rng.integers(3000, 7000)), noise_px=float(rng.choice([0.0, 0.3, 0.8])),
+                              seed=int(rng.integers(1, 1 << 30)))
+    prm = dict(H=int(rng.integers(200, 900)), seed=int(rng.integers(0, 1 << 20)), thr=1e-2)
+    pprm = dict(H=int(rng.integers(50, 300)), seed=int(rng.integers(0, 1 << 20)), err=float(rng.choice([1.0, 2.0])))
+    sq = capi.Sequence(ctx, F, N, 32)
+    sq.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    sq.run(capi.default_params(num_hypotheses=prm["H"], sampler=capi.SAMPLER_PHILOX, seed=prm["seed"], max_error_sq=prm["thr"]),
+           capi.default_pnp_params(num_hypotheses=pprm["H"], seed=pprm["seed"], reproj_error=pprm["err"]))
+    gp, gt, tr = sq.download_pairs(), sq.download_tracks(), sq.download_trajectory()
+    sq.close()
+    pairs, tracks = TS.oracle_sequence(seq, prm, pprm)
+    ok = True
+    for k, ref in enumerate(pairs):
+        r, M = gp["results"][k], ref["n_matches"]
+        ok &= r["n_matches"] == M and gp["matches"][k][:M].tobytes() == ref["matches"].tobytes()
+        ok &= bool(r["valid"]) == ref["ok"] and np.array_equal(gp["mask"][k][:M], ref["mask"])
+        if ok and ref["ok"]:
+            n = ref["n_points"]
+            ok &= np.array_equal(gp["point_idx"][k][:n], ref["point_idx"]) and gp["points"][k][:n].tobytes() == ref["points"].tobytes()
+    for q, ref in enumerate(tracks):
+        t, nc = gt["tracks"][q], len(ref["X"])
+        ok &= t["n_corr"] == nc and gt["corr_xyz"][q][:nc].tobytes() == ref["X"].tobytes() and gt["corr_uv"][q][:nc].tobytes() == ref["uv"].tobytes()
+        ok &= bool(t["ok"]) == ref["ok"] and t["best_hyp"] == ref["best_hyp"]
+        if ok and ref["ok"]:
+            ni = len(ref["inliers"])
+            ok &= t["n_inliers"] == ni and np.array_equal(gt["inlier_idx"][q][:ni], ref["inliers"])
+            ok &= t["R"].tobytes() == ref["R"].tobytes() and t["t"].tobytes() == ref["t"].tobytes()
+    res, trk = gp["results"], gt["tracks"]
+    want = o.seq_chain(res["R"], res["t"], res["valid"], trk["R"], trk["t"], trk["ok"])
+    for key in ("R", "t", "pair_scale", "track_scale"):
+        ok &= tr[key].tobytes() == want[key].tobytes()
+    cnt["sequence_frames"] += F
+    if not ok:
+        bad.append(("sequence", i, F, N, prm, pprm))
 ctx.close()
 print(json.dumps({"seed": args.seed, "cases": cnt, "mismatches": len(bad), "first_mismatches": [list(map(str, x)) for x in bad[:8]],
                   "seconds": round(time.time() - t0, 1)}))
