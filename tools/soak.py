@@ -23,7 +23,7 @@ rng = np.random.default_rng(args.seed)
 PAIR0 = 10_000 + (args.seed - 2026) * 1000   # synthetic pair ids of part 1
 ctx = capi.Context(0)
 bad = []
-cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0, sequence_frames=0)
+cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0, sequence_frames=0, single_shot=0)
 t0 = time.time()
 
 # 1. whole image pairs through the batch API: ragged keypoint counts, varying noise / outliers / hypothesis counts
@@ -201,6 +201,33 @@ for i in range(max(1, args.cases // 40)):
     cnt["sequence_frames"] += F
     if not ok:
         bad.append(("sequence", i, F, N, prm, pprm))
+# 7. the single-shot entry points (one pair per call: the fused small-launch kernel path, the pinned staging arena):
+# mvs_image_pair against the oracle's composition, and the two separate calls against the single pass
+for i in range(args.cases // 20):
+    n_kp = int(rng.integers(30, 600))
+    p = synth.make_pair(50_000 + (args.seed - 2026) * 1000 + i, n_kp=n_kp, noise_px=float(rng.choice([0.0, 0.3, 1.0])),
+                        outlier_frac=float(rng.choice([0.0, 0.3, 0.6])))
+    Hs, sd = int(rng.integers(1, 700)), int(rng.integers(0, 1 << 20))
+    thr = float(rng.choice([1e-2, 0.0]))
+    prm1 = capi.default_params(num_hypotheses=Hs, sampler=capi.SAMPLER_PHILOX, seed=sd, max_error_sq=thr)
+    got = ctx.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], prm1)
+    ref = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(Hs, o.SAMPLER_PHILOX, sd, thr), 0.7, 10.0)
+    M = ref["n_matches"]
+    ok = got["ok"] == ref["ok"] and got["n_matches"] == M and got["matches"].tobytes() == ref["matches"].tobytes()
+    ok = ok and got["best_hyp"] == ref["best_hyp"] and got["best_count"] == ref["best_count"] and np.array_equal(got["mask"], ref["mask"])
+    if ok and ref["ok"]:
+        ok = np.array_equal(got["point_idx"], ref["point_idx"]) and np.abs(got["R"] - ref["R"]).max() <= 1e-12 and \
+            np.abs(got["t"] - ref["t"]).max() <= 1e-12 and \
+            np.abs(got["points"] - ref["points"]).max() <= 1e-12 * max(1.0, np.abs(ref["points"]).max())
+    if ok and M >= 8:
+        mt = ctx.match_hamming(p["desc1"], p["desc2"], 0.7, 10.0)
+        two = ctx.two_view(p["kp1"][mt["trainIdx"]].astype(np.float64), p["kp2"][mt["queryIdx"]].astype(np.float64), p["K"], prm1)
+        ok = mt.tobytes() == got["matches"].tobytes() and two["ok"] == got["ok"] and two["best_hyp"] == got["best_hyp"]
+        if ok and got["ok"]:
+            ok = two["R"].tobytes() == got["R"].tobytes() and two["points"].tobytes() == got["points"].tobytes()
+    cnt["single_shot"] += 1
+    if not ok:
+        bad.append(("single_shot", i, n_kp, Hs, sd, thr))
 ctx.close()
 print(json.dumps({"seed": args.seed, "cases": cnt, "mismatches": len(bad), "first_mismatches": [list(map(str, x)) for x in bad[:8]],
                   "seconds": round(time.time() - t0, 1)}))
