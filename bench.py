@@ -243,7 +243,7 @@ def main():
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world},
             "roofline": {
                 "bound": "valu_fp64",
-                "kernel": "ransac_solve_kernel<1264> + ransac_count_kernel<1024, 2> + ransac_select_kernel (the RANSAC stage; launch_ms is their sum)",
+                "kernel": "ransac_solve_kernel<1264> + ransac_count_kernel<768, 2> + ransac_select_kernel (the RANSAC stage; launch_ms is their sum)",
                 "bound_detail": "fp64 vector FMA rate: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (no MFMA is "
                                 "issued: v_mfma_f64 shares the double-precision pipe, profiles/r02_mfma_coissue_microbench.txt)",
                 "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -254,7 +254,7 @@ def main():
                                 % int((m_avg * 32 + 88 * ((args.hyp + 255) // 256)) * n_local),
                 "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3),
                 # north_star: occupancy / LDS of the RANSAC kernel (hipcc -Rpass-analysis=kernel-resource-usage)
-                "occupancy_waves_per_simd": {"solve": 1, "count": 7, "select": 6},
+                "occupancy_waves_per_simd": {"solve": 1, "count": 6, "select": 6},
                 "vgprs": {"solve": 256, "count": 70, "select": 78}, "agprs": {"solve": 147, "count": 0, "select": 0},
                 "scratch_bytes": 0, "lds_bytes_per_workgroup": {"solve": 0, "count": 32 * ((args.kp + 127) // 128) * 128, "select": 32 * args.kp},
                 "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "

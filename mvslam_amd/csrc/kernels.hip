@@ -1541,7 +1541,11 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
 {
     // enough workgroups to fill the chip for a small launch, few enough that every wavefront works through many
     // groups of four hypotheses (the bound only helps once the first groups have finished)
-    static const int threads = env_int("MVS_CNT_THREADS", 1024) == 512 ? 512 : 1024;   // experiment knobs
+    // 768 threads = 12 wavefronts: two workgroups fit a CU (2 x 64 KB of LDS, 6 of the 7 wavefronts per SIMD the 70
+    // registers allow), against one workgroup of 1024 (4 wavefronts per SIMD): more wavefronts to cover the scalar loads
+    // of a group of four hypotheses, 42.7 -> 42.3 ms per 512 pairs (896 = 7 per SIMD on paper, uneven over the SIMDs: 43.1)
+    static const int threads_env = env_int("MVS_CNT_THREADS", 768);   // experiment knobs
+    static const int threads = threads_env == 512 ? 512 : threads_env == 1024 ? 1024 : threads_env == 896 ? 896 : 768;
     static const int ppl = env_int("MVS_CNT_PPL", 2) == 1 ? 1 : 2;
     const int n_groups4 = (rp.num_hypotheses + kCntSlots - 1) / kCntSlots;
     const int wpw = threads / 64;
@@ -1561,13 +1565,19 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
                              reinterpret_cast<const void *>(ransac_count_kernel<1024, 1>),
                              reinterpret_cast<const void *>(ransac_count_kernel<512, 2>),
                              reinterpret_cast<const void *>(ransac_count_kernel<1024, 2>),
+                             reinterpret_cast<const void *>(ransac_count_kernel<768, 2>),
+                             reinterpret_cast<const void *>(ransac_count_kernel<896, 2>),
                              reinterpret_cast<const void *>(ransac_select_kernel)};
         for (const void *f : fns)
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
         attr_set = true;
     }
     const dim3 grid(wg, n_active);
-    if (threads == 512 && ppl == 1)
+    if (threads == 768)
+        hipLaunchKernelGGL((ransac_count_kernel<768, 2>), grid, dim3(768), lds_cnt, stream, b, rp, wg);
+    else if (threads == 896)
+        hipLaunchKernelGGL((ransac_count_kernel<896, 2>), grid, dim3(896), lds_cnt, stream, b, rp, wg);
+    else if (threads == 512 && ppl == 1)
         hipLaunchKernelGGL((ransac_count_kernel<512, 1>), grid, dim3(512), lds_cnt, stream, b, rp, wg);
     else if (threads == 512)
         hipLaunchKernelGGL((ransac_count_kernel<512, 2>), grid, dim3(512), lds_cnt, stream, b, rp, wg);
