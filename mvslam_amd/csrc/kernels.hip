@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_model_kernel(BatchDev b,
 
 // triangulation: grid (ceil(4 * max_kp / 256), P); item = (candidate c, inlier j); 4x4 DLT + SVD per lane
 // (sfm-solve.cpp:134-227)
-__global__ __launch_bounds__(256) void triangulate_kernel(BatchDev b)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void triangulate_kernel(BatchDev b)
 {
     const int pair = blockIdx.y;
     const FinModel *fm = b.fin + pair;
