@@ -17,10 +17,10 @@ import oracle_lib as o
 from mvslam_amd import synth
 
 
-def run(n_pairs, H, thr, n_kp=2000, threads=8, jacobi=False):
+def run(n_pairs, H, thr, n_kp=2000, threads=8, jacobi=False, first=0):
     """jacobi=False: only the epipolar residual changes form; True: the Jacobi SVD inner loops too (OpenCV's literal
     p += a*b, hypot, c*x + s*y, a += t*t without contraction) -- every place the contract fuses or rewrites."""
-    data = synth.make_batch(0, n_pairs, n_kp=n_kp)
+    data = synth.make_batch(first, n_pairs, n_kp=n_kp)
     out = {}
     for form in (0, 1):
         o.lib().orc_set_residual_form(form)   # process-global: set before the worker threads start
@@ -73,7 +73,8 @@ if __name__ == "__main__":
     ap.add_argument("--pairs", type=int, default=32)
     ap.add_argument("--hyp", type=int, default=50000)
     ap.add_argument("--kp", type=int, default=2000)
+    ap.add_argument("--first", type=int, default=0, help="index of the first synthetic pair")
     ap.add_argument("--max-error-sq", type=float, default=1e-2, help="0 = the reference's 5e-2 / K00 / K11")
     ap.add_argument("--jacobi", action="store_true", help="also switch the Jacobi SVD inner loops to OpenCV's literal forms")
     a = ap.parse_args()
-    print(json.dumps(run(a.pairs, a.hyp, a.max_error_sq, a.kp, jacobi=a.jacobi)))
+    print(json.dumps(dict(first_pair=a.first, **run(a.pairs, a.hyp, a.max_error_sq, a.kp, jacobi=a.jacobi, first=a.first))))
