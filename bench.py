@@ -7,17 +7,23 @@ each = BASELINE.json configs[2] per GPU; configs[3] is the same workload on 8 GP
 uploaded to HBM before the timed region.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 8                       # spawns its own 8 rank processes (no launcher needed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Besides the contract's fields the line carries (rank 0, N = 1): `roofline.per_kernel` (executed work per kernel,
+registers / LDS / occupancy as the runtime reports them), `reference_threshold` (the SURVEY 8(d) threshold
+5e-2/K00/K11 in its own wall-clock loop with its own roofline), and the rows either side of the path:
+`sequence` (BASELINE configs[4]), `refine`, `extract`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,15 +33,75 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X fp64: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop 
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def flop_model(stats):
-    """Algorithmic fp64 flops of the RANSAC launch (fma = 2; mul/add/sub/div/sqrt/compare = 1).  DESIGN.md
-    'RANSAC kernel: work model' derives the constants from the arithmetic contract."""
-    per_hyp = 184 + 32 + 720 + 162 + 171 + 800 + 73   # normalise x2, A, A^T A, W init, W final, 3x3 SVD+rank-2, denorm
-    per_pair9 = 21        # dot (9 fma) + threshold test
-    per_rot9 = 172        # rotation angle (14) + 9 x (A rows 10 + V rows 6)
-    per_eval = 18         # 8 fma + compare + conditional add
-    return (stats["hypotheses"] * per_hyp + stats["pairs9"] * per_pair9 + stats["rotations9"] * per_rot9
-            + stats["score_evals"] * per_eval)
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun.  The parent NEVER imports torch or touches HIP: it only starts
+# one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), waits, and exits with the first
+# non-zero child code (the other children are then terminated by their exact PIDs).
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MVS_BENCH_LAUNCHED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    return env
+
+
+def launch_ranks(world, argv, child_cmd=None, timeout_s=None, poll_s=0.05):
+    """Start `world` rank processes of this script (or of `child_cmd`, for the tests) and wait for them.  Returns the
+    exit code: 0 when every rank exited 0, else the first non-zero code seen (124 on timeout)."""
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    port = free_port()
+    procs = []
+    for r in range(world):
+        # rank 0 owns stdout (the JSON line); the other ranks print nothing there
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen(cmd + list(argv), env=rank_env(r, world, port), stdout=out))
+    t0 = time.time()
+    code = 0
+    live = set(range(world))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 128 - rc
+        if code == 0 and timeout_s is not None and time.time() - t0 > timeout_s:
+            code = 124
+        if code != 0:
+            break
+        if live:
+            time.sleep(poll_s)
+    for r in sorted(live):   # a rank failed (or the time limit passed): stop the others, by PID
+        procs[r].terminate()
+    for r in sorted(live):
+        try:
+            procs[r].wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    return code
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# work models (DESIGN.md "work model"): algorithmic fp64 flops, fma = 2, everything else 1
+# ---------------------------------------------------------------------------------------------------------------------
+PER_HYP = 184 + 32 + 720 + 162 + 171 + 800 + 73   # normalise x2, A, A^T A, W init, W final, 3x3 SVD+rank-2, denorm
+PER_PAIR9 = 21        # dot (9 fma) + threshold test
+PER_ROT9 = 172        # rotation angle (14) + 9 x (A rows 10 + V rows 6)
+PER_EVAL = 18         # 8 fma + compare + conditional add
+
+
+def solve_flops(stats):
+    return stats["hypotheses"] * PER_HYP + stats["pairs9"] * PER_PAIR9 + stats["rotations9"] * PER_ROT9
 
 
 def algorithmic_bytes(n_kp, m, m_inl, n_pts, desc_bytes=32):
@@ -43,15 +109,20 @@ def algorithmic_bytes(n_kp, m, m_inl, n_pts, desc_bytes=32):
     return 2 * n_kp * desc_bytes + m * 16 + m * 32 + 72 + m + 96 + n_pts * 32
 
 
+def host_threads():
+    # the GPU box exposes all host threads but grants a 16-thread share per GPU: never oversubscribe it
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
 def cpu_baseline(data, params_kw, n_pairs_total, budget_s=25.0):
     """The CPU oracle (same algorithm, plain C, -O2) on a bounded sample of the same workload, one pair per
-    host thread.  This is the ONLY place bench.py touches oracle/ (as the baseline being timed)."""
+    host thread.  This (and the three small *_cpu legs below) is the ONLY place bench.py touches oracle/ -- as the
+    baseline being timed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
 
     o.build()
-    # the GPU box exposes all host threads but grants a 16-thread share per GPU: never oversubscribe it
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    cores = host_threads()
     # calibrate one pair at full H on one thread, then size the sample to the budget
     prm0 = o.make_params(params_kw["num_hypotheses"], o.SAMPLER_PHILOX, params_kw["seed"] + int(data["global_index"][0]),
                          params_kw["max_error_sq"])
@@ -83,6 +154,220 @@ def cpu_baseline(data, params_kw, n_pairs_total, budget_s=25.0):
                       "single-thread latency %.2f s/pair" % (n_sample, params_kw["num_hypotheses"], t_one)}
 
 
+def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
+    """Per-kernel view of one pipeline pass: measured ms of every launch (HIP events on the launches' stream), EXECUTED
+    fp64 work where a model exists, and the kernel's registers / LDS / occupancy as the runtime reports them for the
+    loaded code object (+ the build's VGPR / AGPR split).  Nothing here is typed in."""
+    info = ctx.kernel_info(batch.max_kp, batch.desc_bytes)
+    table = {}
+    for name, ms in batch.time_kernels(prm, steps=steps):
+        e = table.setdefault(name, {"ms": 0.0, "launches": 0})
+        e["ms"] += ms
+        e["launches"] += 1
+    for name, e in table.items():
+        ki = info.get(name, {})
+        e["ms"] = round(e["ms"], 4)
+        e["threads_per_block"] = ki.get("threads_per_block")
+        e["registers_runtime"] = ki.get("num_regs")
+        e["lds_bytes_per_workgroup"] = (ki.get("static_lds_bytes") or 0) + (ki.get("dynamic_lds_bytes") or 0)
+        e["scratch_bytes_per_lane"] = ki.get("scratch_bytes_per_lane")
+        e["workgroups_per_cu"] = ki.get("blocks_per_cu")
+        e["occupancy_waves_per_simd"] = ki.get("waves_per_simd")
+        if "build" in ki:
+            e["vgprs"], e["agprs"], e["sgprs"] = ki["build"].get("vgprs"), ki["build"].get("agprs"), ki["build"].get("sgprs")
+    for name, e in table.items():
+        fl_exec = fl_alg = None
+        if name.startswith("ransac_solve_kernel"):
+            fl_exec = fl_alg = solve_flops(stats)
+        elif name.startswith("ransac_count_kernel"):
+            fl_alg = stats["score_evals"] * PER_EVAL
+            fl_exec = stats["score_evals_executed"] * PER_EVAL
+            e["evals_executed_frac"] = round(stats["score_evals_executed"] / max(stats["score_evals"], 1), 4)
+        elif name.startswith("ransac_kernel"):   # fused: solve + every evaluation
+            fl_exec = fl_alg = solve_flops(stats) + stats["score_evals"] * PER_EVAL
+        if fl_exec is not None and e["ms"] > 0:
+            e["flops_executed"] = int(fl_exec)
+            e["flops_algorithmic"] = int(fl_alg)
+            e["tflops_executed"] = round(fl_exec / (e["ms"] * 1e-3) / 1e12, 3)
+            e["frac_executed"] = round(fl_exec / (e["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)
+    return table
+
+
+def roofline_object(table, stats, traffic, traffic_src):
+    """roofline of the DOMINANT kernel (executed work / its measured launch time) + the RANSAC stage as a whole."""
+    ransac = {k: v for k, v in table.items() if k.startswith("ransac_")}
+    dom_name = max(ransac, key=lambda k: ransac[k]["ms"]) if ransac else max(table, key=lambda k: table[k]["ms"])
+    dom = table[dom_name]
+    stage_ms = sum(v["ms"] for v in ransac.values())
+    stage_exec = sum(v.get("flops_executed", 0) for v in ransac.values())
+    stage_alg = sum(v.get("flops_algorithmic", 0) for v in ransac.values())
+    achieved = dom.get("tflops_executed", 0.0)
+    return {
+        "bound": "valu_fp64", "kernel": dom_name,
+        "bound_detail": "fp64 vector FMA rate: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (no MFMA is "
+                        "issued: v_mfma_f64 shares the double-precision pipe, profiles/r02_mfma_coissue_microbench.txt)",
+        "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
+        "frac_definition": "EXECUTED algorithmic flops of the dominant kernel / its launch time (HIP events) / peak",
+        "launch_ms": dom["ms"], "flops_per_launch": dom.get("flops_executed"),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "stage": {"kernels": sorted(ransac), "ms": round(stage_ms, 3), "flops_executed": int(stage_exec),
+                  "frac_executed": round(stage_exec / max(stage_ms, 1e-9) / 1e9 / FP64_PEAK_TFLOPS, 4),
+                  "frac_algorithmic_equivalent": round(stage_alg / max(stage_ms, 1e-9) / 1e9 / FP64_PEAK_TFLOPS, 4),
+                  "note": "frac_algorithmic_equivalent also credits the (hypothesis, point) evaluations the pruned "
+                          "counting kernel provably skips; frac_executed does not"},
+        "per_kernel": table,
+        "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
+                           "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the rows either side of the path (SURVEY 8(f)), one bounded leg each
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_sequence(capi, synth, np, dev, args):
+    """BASELINE configs[4]: 1000-frame synthetic sequence, per frame match + two-view + PnP + triangulate, no BA."""
+    frames, kp, hyp, pnp_hyp = args.seq_frames, args.kp, args.hyp, 100   # 100 = the reference's iterationsCount
+    seq = synth.make_sequence(frames, n_kp=kp)
+    ctx = capi.Context(dev)
+    s = capi.Sequence(ctx, frames, kp, 32)
+    s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    prm = capi.default_params(num_hypotheses=hyp, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
+    pprm = capi.default_pnp_params(num_hypotheses=pnp_hyp, seed=7, reproj_error=2.0, refit=0)
+    steps = 3
+    ms = s.time(prm, pprm, steps=steps, warmup=1) / steps
+    stage_ms = s.time_stages(prm, pprm, steps=steps)
+    s.run(prm, pprm)
+    gp, gt = s.download_pairs(), s.download_tracks()
+    res, tr = gp["results"], gt["tracks"]
+    s.close()
+    ctx.close()
+    pnp_flops = int(sum(pnp_hyp * (1900 + 28 * int(n)) for n in tr["n_corr"]))
+    out = {"metric": "frames/sec, %d-frame synthetic sequence (match + two-view + PnP + triangulate per frame, no BA)" % frames,
+           "value": round(frames / (ms * 1e-3), 1), "unit": "frames/s", "ms_per_sequence": round(ms, 2), "frames": frames,
+           "keypoints": kp, "hypotheses": hyp, "pnp_hypotheses": pnp_hyp, "valid_pairs": int(res["valid"].sum()),
+           "tracks_ok": int(tr["ok"].sum()), "avg_corr": round(float(tr["n_corr"].mean()), 1),
+           "avg_pnp_inliers": round(float(tr["n_inliers"].mean()), 1),
+           "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+           "pnp_roofline": {"bound": "latency (one 100-lane workgroup per track: the reference's iterationsCount)",
+                            "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "flops_per_launch": pnp_flops,
+                            "launch_ms": round(stage_ms["pnp"], 4),
+                            "achieved": round(pnp_flops / (stage_ms["pnp"] * 1e-3) / 1e12, 4),
+                            "frac": round(pnp_flops / (stage_ms["pnp"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)}}
+    if not args.no_cpu_baseline and args.seq_cpu_frames >= 3:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_sequence import oracle_sequence
+        nthr = host_threads()
+        chunk = max(3, args.seq_cpu_frames // nthr + 2)   # frames per thread: chunk - 1 pairs and chunk - 2 tracks
+
+        def work(k0):
+            sub = dict(desc=seq["desc"][k0:k0 + chunk], kp=seq["kp"][k0:k0 + chunk], n_kp=seq["n_kp"][k0:k0 + chunk], K=seq["K"])
+            oracle_sequence(sub, dict(H=hyp, seed=synth.SEED_BASE + k0, thr=1e-2), dict(H=pnp_hyp, seed=7, err=2.0))
+
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=work, args=(i * chunk,)) for i in range(nthr) if (i + 1) * chunk <= frames]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        done = len(ths) * (chunk - 1)
+        out["cpu_baseline"] = {"value": round(done / dt, 2), "unit": "frames/s", "cores": len(ths), "kind": "port",
+                               "sample": "%d threads x %d consecutive frames of the same sequence (%d frame steps, full "
+                                         "hypothesis counts)" % (len(ths), chunk, done)}
+    return out
+
+
+def bench_refine(capi, np, batch, data, dl, args, steps=10):
+    """Row f4: ImagePair::refine of the resident batch (the main leg's results), wall clock around `steps` asynchronous
+    refinement passes + one sync (inputs and results stay in HBM)."""
+    rp = capi.default_refine_params()
+    batch.refine(rp, 0.5)
+    batch.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.refine(rp, 0.5)
+    batch.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    res = dl["results"]
+    ref = batch.download_refined(points=False)
+    rr = ref["refined"]
+    ok = rr["ok"] == 1
+    npts = res["n_points"][ok].astype(np.int64)
+    its = rr["iterations"][ok].astype(np.int64)
+    # algorithmic work (DESIGN.md 4.7): per linear solve every point is linearised twice and its candidate cost evaluated
+    # once, + one covariance pass
+    LIN, SCHUR, STEP, COST, COV = 524, 760, 90, 90, 1100
+    flops = float(np.sum(npts * (its * (2 * LIN + SCHUR + STEP + COST) + (LIN + SCHUR + COV))))
+    out = {"metric": "refined image-pairs/sec (ImagePair::refine = sfm_refine, batched on device)",
+           "value": round(batch.n_pairs / (ms * 1e-3), 1), "unit": "pairs/s", "ms_per_batch": round(ms, 4),
+           "pairs": int(batch.n_pairs), "refined_ok": int(ok.sum()),
+           "mean_points": round(float(npts.mean()), 1) if len(npts) else 0.0,
+           "mean_linear_solves": round(float(its.mean()), 3) if len(its) else 0.0,
+           "roofline": {"bound": "valu_fp64", "kernel": "refine_kernel<2>", "flops_per_launch": int(flops),
+                        "launch_ms": round(ms, 4), "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as o
+        full = batch.download(0, min(batch.n_pairs, 16))
+        idx = [p for p in range(len(full["results"])) if ok[p]][:16]
+        t0 = time.perf_counter()
+        for p in idx:
+            n = int(res["n_points"][p])
+            mt = full["matches"][p][full["point_idx"][p][:n]]
+            p1 = data["kp1"][p][mt["trainIdx"]].astype(np.float64)
+            p2 = data["kp2"][p][mt["queryIdx"]].astype(np.float64)
+            cov = np.tile((np.eye(2) * 0.25).reshape(4), (n, 1))
+            o.sfm_refine(p1, cov, p2, cov, data["K"][p].reshape(3, 3), res["R"][p], res["t"][p], full["points"][p][:n])
+        dt = time.perf_counter() - t0
+        if idx:
+            out["cpu_baseline"] = {"value": round(len(idx) / dt, 2), "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": "%d pairs of the same batch, single thread" % len(idx)}
+    return out
+
+
+def bench_extract(capi, np, dev, args, images=64, width=640, height=480):
+    """Row f3: VisualFeature::extract for a batch of 640x480 frames at the keypoint count the matching configs assume."""
+    def textured(seed, h, w):
+        rng = np.random.default_rng(seed)
+        base = rng.integers(0, 256, size=(h // 6 + 2, w // 6 + 2)).astype(np.uint8)
+        img = np.kron(base, np.ones((6, 6), dtype=np.uint8))[:h, :w].astype(np.int32)
+        img += rng.integers(-6, 7, size=img.shape)
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+    imgs = np.stack([textured(100 + i, height, width) for i in range(images)])
+    ctx = capi.Context(dev)
+    prm = capi.default_orb_params(nfeatures=args.kp)
+    out_k = ctx.extract(imgs, prm)
+    kernel_ms = ctx.extract_time(steps=10)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.extract(imgs, prm)
+    host_ms = (time.perf_counter() - t0) * 1e3 / 3
+    ctx.close()
+    pyr = sum(round(width / 1.2 ** l) * round(height / 1.2 ** l) for l in range(8))
+    alg_bytes = 9.0 * pyr * images   # u8 pixels, ~9 passes over the 3.16 x pyramid (DESIGN.md 4.8)
+    out = {"metric": "extracted images/sec (VisualFeature::extract, %dx%d, %d features)" % (width, height, args.kp),
+           "value": round(images / (kernel_ms * 1e-3), 1), "unit": "images/s", "kernel_ms_per_batch": round(kernel_ms, 4),
+           "images": images, "mean_keypoints": float(out_k["n"].mean()),
+           "host_buffers_ms_per_batch": round(host_ms, 3), "host_buffers_images_per_s": round(images / (host_ms * 1e-3), 1),
+           "roofline": {"bound": "hbm", "kernel": "resize + fast_nms + select + blur + describe (one extraction)",
+                        "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "bytes_per_launch": int(alg_bytes), "traffic": None}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as o
+        ncpu = 4
+        t0 = time.perf_counter()
+        same = True
+        for i in range(ncpu):
+            w = o.orb_extract(imgs[i], o.make_orb_params(nfeatures=args.kp))
+            n = int(out_k["n"][i])
+            same &= n == len(w["kp"]) and np.array_equal(out_k["desc"][i][:n], w["desc"])
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(ncpu / dt, 2), "unit": "images/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the same frames, single thread" % ncpu, "bit_exact_vs_gpu": bool(same)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,20 +387,30 @@ def main():
                     "buffers over PCIe); reported as pcie_inclusive_pairs_per_s, never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
-    ap.add_argument("--no-ref-threshold", action="store_true", help="skip the extra reference-threshold timing (profiling "
-                    "runs: keeps every launch of a kernel on the same workload)")
+    ap.add_argument("--no-ref-threshold", action="store_true", help="skip the reference-threshold leg (profiling runs: "
+                    "keeps every launch of a kernel on the same workload)")
+    ap.add_argument("--ref-steps", type=int, default=10, help="wall-clock steps of the reference-threshold leg")
+    ap.add_argument("--sections", default="main,sequence,refine,extract",
+                    help="legs to run on rank 0 at N = 1 (main is always timed; the others add their sub-objects)")
+    ap.add_argument("--seq-frames", type=int, default=1000)
+    ap.add_argument("--seq-cpu-frames", type=int, default=48)
+    ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before a self-launched run is abandoned")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above this line has touched torch or HIP.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.launch_timeout))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -125,6 +420,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
     dev = 0 if os.environ.get("MVS_BENCH_ONE_DEVICE") == "1" else local_rank
     torch.cuda.set_device(dev)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":  # RCCL over xGMI
@@ -132,6 +428,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    sections = set(x for x in args.sections.split(",") if x)
     n_local = args.pairs
     first = rank * n_local  # contiguous block per rank, weak scaling
     data = synth.make_batch(first, n_local, n_kp=args.kp, noise_px=args.noise_px)
@@ -183,11 +480,21 @@ def main():
         gathered = step(timed=True)
     batch.sync()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    rank_ms = [elapsed_local / args.steps * 1e3]
+    ranks_seen = [0]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # every rank's own step time and rank id, as the communicator delivers them
+        mine = torch.tensor([float(rank), elapsed_local / args.steps * 1e3], dtype=torch.float64, device=coll_dev)
+        allr = torch.empty(2 * world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().reshape(world, 2)
+        ranks_seen = sorted(int(x) for x in allr[:, 0].tolist())
+        rank_ms = [float(x) for x in allr[:, 1].tolist()]
 
     gather_us = None
     if world > 1 and gather_ev:   # communication reported separately from compute; max over ranks
@@ -195,7 +502,7 @@ def main():
             g_us = float(np.mean([a.elapsed_time(b2) for a, b2 in gather_ev])) * 1e3
         else:
             g_us = float(np.mean(gather_ev)) * 1e6
-        tg = torch.tensor([g_us], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tg = torch.tensor([g_us], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_us = round(float(tg.item()), 1)
 
@@ -203,34 +510,28 @@ def main():
     total_pairs = n_local * world
     value = total_pairs * args.steps / elapsed
 
-    out = None
     if rank == 0:
         # ---- per-kernel HIP-event timing on the kernels' own stream + work statistics (outside the timed region)
         _, kern_ms = batch.time(prm, steps=min(args.steps, 5), warmup=0)
         ksteps = min(args.steps, 5)
         kern_ms = {k: v / ksteps for k, v in kern_ms.items()}
         stats = batch.stats(prm)
-        res = batch.download(matches=False, mask=False, points=False)["results"]
-        flops = flop_model(stats)
-        ransac_s = kern_ms["ransac"] * 1e-3
-        achieved = flops / ransac_s / 1e12
+        table = kernel_table(capi, ctx, batch, prm, stats, n_local)
+        dl = batch.download(matches=False, mask=False, points=False)
+        res = dl["results"]
         m_avg = float(res["n_matches"].mean())
         bytes_pair = algorithmic_bytes(args.kp, m_avg, float(res["n_inliers"].mean()), float(res["n_points"].mean()))
         # HBM bytes of the RANSAC launches: a RECORDED value (PMC counters cannot be read inside this process): the
         # rocprofv3 --pmc pass of this same workload committed under profiles/ ((2*FETCH_SIZE + WRITE_SIZE) KB per
         # MI355X_MICROARCH.md, its own pass); only quoted for the default workload, null otherwise
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_ransac_hbm_traffic.json")
-        if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000 and args.max_error_sq == 1e-2:
-            traffic = int(json.load(open(tpath))["hbm_bytes_per_pair"] * n_local)
-        # the reference-threshold regime (5e-2 / K00 / K11, sfm-solve.cpp:311: ~5 inliers, ties decided by the residual
-        # sum, nothing to prune) with the same kernels, in the same line
-        ref_thr = None
-        if args.max_error_sq > 0 and not args.no_ref_threshold:
-            prm_ref = capi.default_params(sampler=capi.SAMPLER_PHILOX, min_inliers=8, **dict(params_kw, max_error_sq=0.0))
-            tot_ref, k_ref = batch.time(prm_ref, steps=3, warmup=1)
-            ref_thr = {"pairs_per_s": round(n_local * 3 / (tot_ref * 1e-3), 1), "ransac_ms": round(k_ref["ransac"] / 3, 3),
-                       "max_error_sq": "5e-2/K00/K11 = %.3e" % (5e-2 / 525.0 / 525.0)}
+        traffic, traffic_src = None, None
+        for tname in ("r03_ransac_hbm_traffic.json", "r02_ransac_hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000 and args.max_error_sq == 1e-2:
+                traffic = int(json.load(open(tpath))["hbm_bytes_per_pair"] * n_local)
+                traffic_src = "recorded: profiles/%s (rocprofv3 --pmc pass of this workload; RANSAC stage, per launch " \
+                              "sequence)" % tname
+                break
         out = {
             "metric": "image-pairs/sec (2k kp, 50k RANSAC hyp)", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -240,25 +541,10 @@ def main():
                             "%d 8-point hypotheses per pair, full match+RANSAC+decompose+triangulate"
                             % (n_local, args.kp, args.hyp),
                 "pairs_per_gpu": n_local, "keypoints": args.kp, "hypotheses": args.hyp, "noise_px": args.noise_px,
-                "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world},
-            "roofline": {
-                "bound": "valu_fp64",
-                "kernel": "ransac_solve_kernel<1264> + ransac_count_kernel<768, 2> + ransac_select_kernel (the RANSAC stage; launch_ms is their sum)",
-                "bound_detail": "fp64 vector FMA rate: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (no MFMA is "
-                                "issued: v_mfma_f64 shares the double-precision pipe, profiles/r02_mfma_coissue_microbench.txt)",
-                "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": "recorded: profiles/r02_ransac_hbm_traffic.json (rocprofv3 --pmc pass of this workload)",
-                "traffic_note": "algorithmic: %d B for points + arg-best; the rest is the F hand-over between the solve and "
-                                "the scoring launches (72 B written + read per hypothesis, + 4 B count)"
-                                % int((m_avg * 32 + 88 * ((args.hyp + 255) // 256)) * n_local),
-                "flops_per_launch": int(flops), "launch_ms": round(kern_ms["ransac"], 3),
-                # north_star: occupancy / LDS of the RANSAC kernel (hipcc -Rpass-analysis=kernel-resource-usage)
-                "occupancy_waves_per_simd": {"solve": 1, "count": 6, "select": 6},
-                "vgprs": {"solve": 256, "count": 70, "select": 78}, "agprs": {"solve": 147, "count": 0, "select": 0},
-                "scratch_bytes": 0, "lds_bytes_per_workgroup": {"solve": 0, "count": 32 * ((args.kp + 127) // 128) * 128, "select": 32 * args.kp},
-                "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
-                                   "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"},
+                "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world,
+                "threshold_note": "headline threshold 1e-2 (a consensus set exists: ~1100 inliers per pair, every stage "
+                                  "runs); SURVEY 8(d)'s literal 5e-2/K00/K11 is timed in `reference_threshold`"},
+            "roofline": roofline_object(table, stats, traffic, traffic_src),
             "hbm_roofline": {
                 "achieved": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9 / HBM_PEAK_GBS, 6),
@@ -269,9 +555,9 @@ def main():
                      "avg_points": round(float(res["n_points"].mean()), 1), "valid_pairs": int(res["valid"].sum()),
                      "rotations9_per_hyp": round(stats["rotations9"] / max(stats["hypotheses"], 1), 2),
                      "pairs9_per_hyp": round(stats["pairs9"] / max(stats["hypotheses"], 1), 2)},
+            "ranks_seen": ranks_seen,
+            "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
         }
-        if ref_thr is not None:
-            out["reference_threshold"] = ref_thr
         if gather_us is not None:
             out["gather_us"] = gather_us
             out["gather_note"] = "all-gather of the %d-byte pose records (%d per rank), timed with its own events inside the timed steps; max over ranks" % (rec_bytes, n_local)
@@ -279,6 +565,30 @@ def main():
             allrec = mdist.records_to_numpy(gathered, capi.RESULT_DTYPE)
             out["work"]["gathered_records"] = int(len(allrec))
             out["work"]["gathered_valid"] = int(allrec["valid"].sum())
+        # ---- the SURVEY 8(d) threshold (5e-2 / K00 / K11, sfm-solve.cpp:311: ~5 inliers, ties decided by the residual sum,
+        # nothing to prune) with the same kernels: its own wall-clock loop, its own per-kernel table and roofline
+        if args.max_error_sq > 0 and not args.no_ref_threshold and world == 1:
+            prm_ref = capi.default_params(sampler=capi.SAMPLER_PHILOX, min_inliers=8, **dict(params_kw, max_error_sq=0.0))
+            for _ in range(2):
+                batch.run(prm_ref)
+            batch.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.ref_steps):
+                batch.run(prm_ref)
+            batch.sync()
+            dt = time.perf_counter() - t0
+            stats_ref = batch.stats(prm_ref)
+            table_ref = kernel_table(capi, ctx, batch, prm_ref, stats_ref, n_local)
+            res_ref = batch.download(matches=False, mask=False, points=False)["results"]
+            out["reference_threshold"] = {
+                "max_error_sq": "5e-2/K00/K11 = %.3e" % (5e-2 / 525.0 / 525.0), "steps": args.ref_steps,
+                "timing": "wall clock around %d steps + sync (same loop shape as the headline)" % args.ref_steps,
+                "pairs_per_s": round(n_local * args.ref_steps / dt, 1), "ms_per_step": round(dt / args.ref_steps * 1e3, 3),
+                "valid_pairs": int(res_ref["valid"].sum()), "avg_best_count": round(float(res_ref["best_count"].mean()), 2),
+                "roofline": roofline_object(table_ref, stats_ref, None, None)}
+            batch.run(prm)      # back to the headline results for the legs below
+            batch.sync()
+            dl = batch.download(matches=False, mask=False, points=False)
         if not args.no_single_pair:
             b1 = capi.Batch(ctx, 1, args.kp, 32)
             b1.upload(0, data["desc1"][:1], data["kp1"][:1], data["n1"][:1], data["desc2"][:1], data["kp2"][:1],
@@ -345,12 +655,20 @@ def main():
                 for a in list(lane[1].values()) + list(lane[2]):
                     capi.pinned_free(a)
             ctx2.close()
+        if world == 1 and "refine" in sections:
+            out["refine"] = bench_refine(capi, np, batch, data, dl, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, params_kw, n_local)
-        print(json.dumps(out), flush=True)
 
     batch.close()
     ctx.close()
+    if rank == 0 and world == 1:
+        if "sequence" in sections:
+            out["sequence"] = bench_sequence(capi, synth, np, dev, args)
+        if "extract" in sections:
+            out["extract"] = bench_extract(capi, np, dev, args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 1
+#define MVS_ABI_VERSION 2
 
 typedef enum mvs_status {
     MVS_OK = 0,
@@ -208,6 +208,32 @@ mvs_status mvs_batch_sync(mvs_batch *b);
 mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, int warmup, int steps,
                           float *ms_total, float *ms_kernel);
 
+/* Per-launch timing of one pipeline pass: `steps` instrumented passes with a HIP event in front of every kernel launch
+ * (on the ctx stream, where the kernels run).  kernel_id[k] / ms[k]: id (index into mvs_kernel_info_get) and mean
+ * duration of launch k of a pass, in launch order; *n_launches: launches per pass (<= cap).  Outside any timed region. */
+mvs_status mvs_batch_time_kernels(mvs_batch *b, const mvs_params *params, int n_active, int steps, int cap,
+                                  int32_t *kernel_id, float *ms, int *n_launches);
+
+/* The kernels of the two-view pipeline as they are launched for a batch of this shape: name (as rocprofv3 prints it) and
+ * what the runtime reports for the code object that is actually loaded (hipFuncGetAttributes,
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor) -- so a bench line never carries typed-in register counts.
+ * index: 0 .. n-1; returns MVS_ERR_INVALID_ARG past the end. */
+typedef struct mvs_kernel_info {
+    char name[96];
+    char symbol[160];              /* mangled name of the code object's kernel (key into lib/kernel_resources.json) */
+    int32_t kernel_id;
+    int32_t threads_per_block;     /* as launched */
+    int32_t num_regs;              /* hipFuncAttributes.numRegs (vector registers per lane, architected + accumulation) */
+    int32_t static_lds_bytes;      /* hipFuncAttributes.sharedSizeBytes */
+    int32_t dynamic_lds_bytes;     /* as launched for this batch shape */
+    int32_t scratch_bytes_per_lane;/* hipFuncAttributes.localSizeBytes */
+    int32_t max_threads_per_block;
+    int32_t blocks_per_cu;         /* hipOccupancyMaxActiveBlocksPerMultiprocessor at that block size and LDS */
+    int32_t waves_per_simd;        /* blocks_per_cu * ceil(threads / 64) / 4 SIMDs, rounded down, at least 1 if resident */
+    int32_t reserved;
+} mvs_kernel_info;
+mvs_status mvs_kernel_info_get(mvs_ctx *ctx, int index, int max_kp, int desc_bytes, mvs_kernel_info *out);
+
 /* Results (host).  Any pointer may be NULL.  results: count;  matches: count x max_kp;  mask: count x max_kp;
  * points: count x max_kp x 3;  point_idx: count x max_kp.  Valid rows of pair p: matches / mask [0, results[p].n_matches),
  * points / point_idx [0, results[p].n_points); every row past them is ZERO (the kernels clear the tails on every run, so
@@ -232,6 +258,8 @@ typedef struct mvs_work_stats {
     int64_t score_evals;
     int64_t matches; /* sum of M */
     int64_t inliers; /* sum of n_inliers */
+    int64_t score_evals_executed; /* (hypothesis, point) evaluations the pruned counting kernel actually executed (incl. the
+                                     NaN padding of a pair's last block); 0 when the batch runs on the fused kernel */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 
@@ -399,6 +427,10 @@ void mvs_orb_params_default(mvs_orb_params *p);
 mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int width, int height,
                        const mvs_orb_params *params, mvs_keypoint *keypoints, uint8_t *descriptors,
                        int32_t *n_keypoints);
+/* Kernel time of the extraction: replays the launches of the LAST mvs_extract / mvs_seq_upload_images on this context
+ * (its captured graph; the workspace still holds that call's images) `steps` times between HIP events on the ctx stream.
+ * No transfers are inside the measurement.  MVS_ERR_INVALID_ARG before the first extraction. */
+mvs_status mvs_extract_time(mvs_ctx *ctx, int steps, float *ms_total);
 /* Extraction straight into a sequence's resident frame arrays (no host round trip of descriptors): frames
  * [first, first + count) of `s` get up to max_kp keypoints each (params->nfeatures is overridden by max_kp). */
 mvs_status mvs_seq_upload_images(mvs_seq *s, int first, int count, const uint8_t *images, int width, int height,

@@ -103,7 +103,14 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 
 
 class WorkStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers")]
+    _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers",
+                                              "score_evals_executed")]
+
+
+class KernelInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("symbol", C.c_char * 160)] + [(n, C.c_int32) for n in (
+        "kernel_id", "threads_per_block", "num_regs", "static_lds_bytes", "dynamic_lds_bytes", "scratch_bytes_per_lane",
+        "max_threads_per_block", "blocks_per_cu", "waves_per_simd", "reserved")]
 
 
 EXPORTS = [
@@ -118,7 +125,8 @@ EXPORTS = [
     "mvs_orb_params_default", "mvs_extract", "mvs_seq_upload_images", "mvs_seq_refine_pairs", "mvs_seq_download_refined",
     "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
     "mvs_batch_upload_async", "mvs_batch_download_async", "mvs_host_alloc", "mvs_host_free", "mvs_image_pair",
-    "mvs_batch_gather_results", "mvs_seq_time_stages",
+    "mvs_batch_gather_results", "mvs_seq_time_stages", "mvs_batch_time_kernels", "mvs_kernel_info_get",
+    "mvs_extract_time",
 ]
 
 
@@ -256,6 +264,32 @@ class Context:
         err = lib().mvs_last_error(self._h)
         raise MvsError(st, what + (" [" + err.decode() + "]" if err else ""))
 
+    def kernel_info(self, max_kp=2000, desc_bytes=32):
+        """the kernels of the two-view pipeline as launched for this batch shape: what the RUNTIME reports for the loaded
+        code object (registers, LDS, scratch, occupancy), merged with the build's resource-usage digest
+        (lib/kernel_resources.json: the VGPR / AGPR split) when that file is present.  {name: {...}}, launch order"""
+        import json
+        build = {}
+        rpath = os.path.join(_PKG, "lib", "kernel_resources.json")
+        if os.path.exists(rpath):
+            build = json.load(open(rpath))
+        out = {}
+        i = 0
+        while True:
+            ki = KernelInfo()
+            st = lib().mvs_kernel_info_get(self._h, C.c_int(i), C.c_int(max_kp), C.c_int(desc_bytes), C.byref(ki))
+            if st == MVS_ERR_INVALID_ARG:
+                break
+            self._check(st, "mvs_kernel_info_get")
+            d = {n: getattr(ki, n) for n, _ in KernelInfo._fields_[2:] if n != "reserved"}
+            d["symbol"] = ki.symbol.decode()
+            bres = build.get(d["symbol"])
+            if bres:
+                d["build"] = bres
+            out[ki.name.decode()] = d
+            i += 1
+        return out
+
     # VisualFeature::match_visual_features(vf1 = train, vf2 = query, max_dist)
     def match_hamming(self, train_desc, query_desc, ratio=0.7, max_dist=-1.0):
         train_desc = np.ascontiguousarray(train_desc, dtype=np.uint8)
@@ -389,6 +423,12 @@ class Context:
         return dict(kp=kp, desc=desc, n=n)
 
     # sfm_refine(p1_estimates, p2_estimates, K, pose2in1_guess, pointsin1_guess, pose2in1_estimate, pointsin1_estimate, error)
+    def extract_time(self, steps=10):
+        """kernel ms of ONE replay of the last extraction's launches (HIP events on the ctx stream, no transfers)"""
+        ms = C.c_float(0)
+        self._check(lib().mvs_extract_time(self._h, C.c_int(steps), C.byref(ms)), "mvs_extract_time")
+        return ms.value / steps
+
     def sfm_refine(self, p1, cov1, p2, cov2, K, R_guess, t_guess, points_guess, params=None, point_cov=True):
         p1, p2, pg = _f64(p1).reshape(-1, 2), _f64(p2).reshape(-1, 2), _f64(points_guess).reshape(-1, 3)
         m = len(p1)
@@ -562,6 +602,19 @@ class Batch:
         self.ctx._check(st, "mvs_batch_time")
         names = ("match_topk", "match_compact", "ransac", "finalize")
         return total.value, {n: kern[i] for i, n in enumerate(names)}
+
+    def time_kernels(self, params, steps, n_active=None):
+        """mean ms of every kernel launch of one pipeline pass, in launch order: [(kernel name, ms)] (HIP events in front
+        of every launch, on the launches' own stream; an instrumented replay outside any timed region)"""
+        cap = 32
+        kid = (C.c_int32 * cap)()
+        ms = (C.c_float * cap)()
+        n = C.c_int(0)
+        st = lib().mvs_batch_time_kernels(self._h, C.byref(params), C.c_int(n_active or self.n_pairs), C.c_int(steps),
+                                          C.c_int(cap), kid, ms, C.byref(n))
+        self.ctx._check(st, "mvs_batch_time_kernels")
+        names = {v["kernel_id"]: k for k, v in self.ctx.kernel_info(self.max_kp, self.desc_bytes).items()}
+        return [(names.get(kid[k], "kernel_%d" % kid[k]), float(ms[k])) for k in range(n.value)]
 
     def stats(self, params, n_active=None):
         ws = WorkStats()

@@ -38,6 +38,8 @@ struct mvs_ctx {
     // hipMemcpyAsync on the ctx stream (no synchronous pageable copies, no sync "so that a stack temporary may die")
     char *h_pin = nullptr;
     size_t h_pin_cap = 0, h_pin_off = 0;
+    bool pin_in_flight = false;   // an asynchronous copy may still be reading / writing the arena (set by pin_get, cleared
+                                  // by whoever synchronises the stream at the end of the call)
 };
 
 struct mvs_seq;
@@ -52,7 +54,13 @@ struct mvs_batch {
     hipEvent_t ev[8]{};
     RefineDev refine{};     // allocated by the first mvs_batch_refine
     bool refine_ready = false, refine_ran = false;
-    char *h_pin = nullptr;  // pinned staging of the per-pair parameters derived on the host (K^-1, default indices)
+    // pinned staging of the per-pair parameters derived on the host (K^-1, default indices): two slot sets used in turn,
+    // each guarded by an event recorded behind its copies, so an asynchronous upload waits for the copies of the upload
+    // before last at most -- never for the kernels or downloads queued on the stream in between
+    char *h_pin = nullptr;
+    hipEvent_t pin_ev[2]{};
+    bool pin_ev_live[2] = {false, false};
+    int pin_turn = 0;
 };
 
 struct mvs_seq {
@@ -77,6 +85,14 @@ struct mvs_seq {
         }                                                                                      \
     } while (0)
 
+// every wait for the ctx stream goes through here: once it has drained nothing reads or writes the arena any more
+static hipError_t sync_stream(mvs_ctx *ctx)
+{
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        ctx->pin_in_flight = false;
+    return e;
+}
 // ---- pinned staging arena -------------------------------------------------------------------------------------------
 // pin_begin() opens a call: the arena is made large enough for everything the call will stage (growing it waits for
 // the stream first, nothing of an earlier call may still be in flight) and the cursor rewinds.  pin_put() copies a host
@@ -85,7 +101,7 @@ static mvs_status pin_begin(mvs_ctx *ctx, size_t bytes)
 {
     bytes += 4096;
     if (ctx->h_pin_cap < bytes) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, sync_stream(ctx));
         if (ctx->h_pin)
             (void)hipHostFree(ctx->h_pin);
         ctx->h_pin = nullptr;
@@ -93,6 +109,12 @@ static mvs_status pin_begin(mvs_ctx *ctx, size_t bytes)
         const size_t cap = std::max<size_t>(bytes * 2, size_t(1) << 20);
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_pin, cap, hipHostMallocDefault));
         ctx->h_pin_cap = cap;
+    }
+    if (ctx->pin_in_flight) {
+        // the previous call left through an error path after it had enqueued copies from / into the arena: wait for
+        // them before the cursor rewinds and their source bytes are overwritten
+        HIP_TRY(ctx, sync_stream(ctx));
+        ctx->pin_in_flight = false;
     }
     ctx->h_pin_off = 0;
     return MVS_OK;
@@ -103,6 +125,7 @@ static void *pin_get(mvs_ctx *ctx, size_t bytes)
     if (off + bytes > ctx->h_pin_cap)
         return nullptr;   // pin_begin() was given too small a figure: a bug, reported as MVS_ERR_HIP by the callers
     ctx->h_pin_off = off + bytes;
+    ctx->pin_in_flight = true;
     return ctx->h_pin + off;
 }
 static void *pin_put(mvs_ctx *ctx, const void *src, size_t bytes)
@@ -202,7 +225,7 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     const int G = (num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
     if (G <= b->d.max_groups)
         return MVS_OK;
-    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(b->ctx, sync_stream(b->ctx));
     const size_t P = (size_t)b->d.n_pairs, Hp = (size_t)G * kHypPerBlock;
     WgBest *p = nullptr;
     double *hf = nullptr;   // F of every hypothesis (solve -> scoring hand-over): 72 B x hypotheses x pairs
@@ -252,7 +275,7 @@ int mvs_debug_fastmath_check(mvs_ctx *ctx, const double *x, const double *y, int
     HIP_TRY(ctx, hipMemsetAsync(dc, 0, 32, ctx->stream));
     launch_fastmath_check(dx, dy, n, dc, ctx->stream);
     HIP_TRY(ctx, hipMemcpyAsync(counts, dc, 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_stream(ctx));
     (void)hipFree(dx);
     (void)hipFree(dy);
     (void)hipFree(dc);
@@ -282,7 +305,7 @@ int mvs_debug_pairstep_check(mvs_ctx *ctx, const double *rows, int n, unsigned l
         e = hipMemcpyAsync(counts, dc, 32, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
+        e = sync_stream(ctx);
     (void)hipFree(dr);
     (void)hipFree(dc);
     return e == hipSuccess ? MVS_OK : MVS_ERR_HIP;
@@ -302,7 +325,7 @@ int mvs_debug_read_hyp_F(mvs_batch *b, int pair, int n_hyp, double *F_out, unsig
     if (!b || !b->d.hyp_F || pair < 0 || pair >= b->d.n_pairs || n_hyp < 1 || n_hyp > b->d.max_groups * kHypPerBlock)
         return MVS_ERR_INVALID_ARG;
     const size_t Hp = (size_t)b->d.max_groups * kHypPerBlock;
-    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(b->ctx, sync_stream(b->ctx));
     HIP_TRY(b->ctx, hipMemcpy(F_out, b->d.hyp_F + (size_t)pair * Hp * 9, (size_t)n_hyp * 9 * sizeof(double), hipMemcpyDeviceToHost));
     if (ok_out)
         HIP_TRY(b->ctx, hipMemcpy(ok_out, b->d.hyp_okf + (size_t)pair * Hp, (size_t)n_hyp, hipMemcpyDeviceToHost));
@@ -366,6 +389,20 @@ mvs_status mvs_ctx_create_on_stream(int device_id, void *hip_stream, mvs_ctx **o
         }
         c->own_stream = true;
     }
+    {
+        // the scoring, refinement and extraction kernels are laid out for the 160 KB of LDS a gfx950 compute unit has
+        int lds = 0;
+        const hipError_t e1 = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id);
+        const hipError_t e2 = e1 == hipSuccess && lds >= 160 * 1024 ? prepare_kernels() : hipErrorInvalidDevice;
+        if (e2 != hipSuccess) {
+            std::fprintf(stderr, "mvs_ctx_create: device %d offers %d bytes of LDS per workgroup (%s); this library is built "
+                                 "for gfx950 (160 KB)\n", device_id, lds, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            if (c->own_stream)
+                (void)hipStreamDestroy(c->stream);
+            delete c;
+            return MVS_ERR_NO_DEVICE;
+        }
+    }
     if (hipMalloc((void **)&c->d_small, 64 * sizeof(double)) != hipSuccess) {
         if (c->own_stream)
             (void)hipStreamDestroy(c->stream);
@@ -383,7 +420,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_stream(ctx);
     if (ctx->scratch)
         mvs_batch_destroy(ctx->scratch);
     if (ctx->d_uv1) (void)hipFree(ctx->d_uv1);
@@ -508,7 +545,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
             mvs_batch_destroy(b);
             return MVS_ERR_HIP;
         }
-    if (hipStreamSynchronize(s) != hipSuccess) {
+    if (sync_stream(ctx) != hipSuccess) {
         ctx->err = "mvs_batch_create: hipStreamSynchronize failed";
         mvs_batch_destroy(b);
         return MVS_ERR_HIP;
@@ -522,7 +559,7 @@ void mvs_batch_destroy(mvs_batch *b)
     if (!b)
         return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)sync_stream(b->ctx);
     for (void *p : b->allocs)
         (void)hipFree(p);
     for (auto &e : b->ev)
@@ -530,6 +567,9 @@ void mvs_batch_destroy(mvs_batch *b)
             (void)hipEventDestroy(e);
     if (b->h_pin)
         (void)hipHostFree(b->h_pin);
+    for (auto &e : b->pin_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -554,22 +594,27 @@ static mvs_status batch_upload_impl(mvs_batch *b, int first, int count, const ui
                 return MVS_ERR_CAPACITY;
     // host-derived per-pair parameters live in pinned memory owned by the batch (slot = pair index), so that the
     // asynchronous form needs no temporaries that outlive the call
-    if (!b->h_pin)
-        HIP_TRY(ctx, hipHostMalloc((void **)&b->h_pin, (size_t)d.n_pairs * (9 * sizeof(double) + sizeof(int64_t)),
-                                   hipHostMallocDefault));
-    double *kinv = reinterpret_cast<double *>(b->h_pin) + (size_t)first * 9;
-    int64_t *gi = reinterpret_cast<int64_t *>(b->h_pin + (size_t)d.n_pairs * 9 * sizeof(double)) + first;
-    if (K) {
+    const size_t set_bytes = (size_t)d.n_pairs * (9 * sizeof(double) + sizeof(int64_t));
+    if (!b->h_pin) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&b->h_pin, 2 * set_bytes, hipHostMallocDefault));
+        for (auto &e : b->pin_ev)
+            HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (K)
         for (int i = 0; i < count; ++i)
             if (!affine_K(K + 9 * i))
                 return MVS_ERR_BAD_INTRINSICS;
-        HIP_TRY(ctx, hipStreamSynchronize(s));   // an earlier asynchronous upload may still be reading the slots
+    const bool staged = K || !global_index;
+    const int set = b->pin_turn;
+    char *base = b->h_pin + (size_t)set * set_bytes;
+    double *kinv = reinterpret_cast<double *>(base) + (size_t)first * 9;
+    int64_t *gi = reinterpret_cast<int64_t *>(base + (size_t)d.n_pairs * 9 * sizeof(double)) + first;
+    if (staged && b->pin_ev_live[set])
+        HIP_TRY(ctx, hipEventSynchronize(b->pin_ev[set]));   // only the copies that last read this slot set
+    if (K)
         for (int i = 0; i < count; ++i)
             mat3_inverse(K + 9 * i, kinv + 9 * i);
-    }
     if (!global_index) {
-        if (!K)
-            HIP_TRY(ctx, hipStreamSynchronize(s));
         for (int i = 0; i < count; ++i)
             gi[i] = first + i;
         global_index = gi;
@@ -590,8 +635,13 @@ static mvs_status batch_upload_impl(mvs_batch *b, int first, int count, const ui
     UP(const_cast<double *>(d.Kinv), kinv_p, 9 * sizeof(double));
     UP(const_cast<int64_t *>(d.gidx), global_index, sizeof(int64_t));
 #undef UP
+    if (staged) {
+        HIP_TRY(ctx, hipEventRecord(b->pin_ev[set], s));
+        b->pin_ev_live[set] = true;
+        b->pin_turn = set ^ 1;
+    }
     if (sync)
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 
@@ -630,18 +680,20 @@ static mvs_status check_params(const mvs_params *p)
     return MVS_OK;
 }
 
-static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_active, bool stats, hipEvent_t *ev)
+static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_active, bool stats, hipEvent_t *ev,
+                                   LaunchTimer *lt = nullptr)
 {
     hipStream_t s = b->ctx->stream;
     if (ev) (void)hipEventRecord(ev[0], s);
-    launch_match_topk(b->d, rp, n_active, s);
+    launch_match_topk(b->d, rp, n_active, s, lt);
     if (ev) (void)hipEventRecord(ev[1], s);
-    launch_match_compact(b->d, rp, n_active, s);
+    launch_match_compact(b->d, rp, n_active, s, lt);
     if (ev) (void)hipEventRecord(ev[2], s);
-    launch_ransac(b->d, rp, n_active, stats, s);
+    launch_ransac(b->d, rp, n_active, stats, s, lt);
     if (ev) (void)hipEventRecord(ev[3], s);
-    launch_finalize(b->d, rp, n_active, kFinalizeFull, s);
+    launch_finalize(b->d, rp, n_active, kFinalizeFull, s, lt);
     if (ev) (void)hipEventRecord(ev[4], s);
+    if (lt) lt->end();
     HIP_TRY(b->ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -666,7 +718,7 @@ mvs_status mvs_batch_sync(mvs_batch *b)
 {
     if (!b)
         return MVS_ERR_INVALID_ARG;
-    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(b->ctx, sync_stream(b->ctx));
     return MVS_OK;
 }
 
@@ -690,7 +742,7 @@ mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, 
     for (int i = 0; i < warmup; ++i)
         if ((st = enqueue_pipeline(b, rp, n_active, false, nullptr)) != MVS_OK)
             return st;
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     HIP_TRY(ctx, hipEventRecord(b->ev[5], s));
     for (int i = 0; i < steps; ++i)
         if ((st = enqueue_pipeline(b, rp, n_active, false, nullptr)) != MVS_OK)
@@ -713,6 +765,98 @@ mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, 
             }
         }
     }
+    return MVS_OK;
+}
+
+mvs_status mvs_batch_time_kernels(mvs_batch *b, const mvs_params *params, int n_active, int steps, int cap,
+                                  int32_t *kernel_id, float *ms, int *n_launches)
+{
+    if (!b || !kernel_id || !ms || !n_launches || n_active < 1 || n_active > b->d.n_pairs || steps < 1 || cap < 1)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    const RunParams rp = to_run(*params);
+    constexpr int kMaxLaunches = 32;
+    cap = std::min(cap, kMaxLaunches);
+    hipEvent_t ev[kMaxLaunches + 1] = {};
+    int32_t kid[kMaxLaunches];
+    for (int k = 0; k <= cap; ++k)
+        if (hipEventCreate(&ev[k]) != hipSuccess) {
+            for (int j = 0; j < k; ++j)
+                (void)hipEventDestroy(ev[j]);
+            ctx->err = "mvs_batch_time_kernels: hipEventCreate failed";
+            return MVS_ERR_HIP;
+        }
+    int n = 0;
+    st = MVS_OK;
+    for (int k = 0; k < cap; ++k)
+        ms[k] = 0.f;
+    for (int i = 0; i < steps && st == MVS_OK; ++i) {
+        LaunchTimer lt{ctx->stream, ev, kid, cap, 0};
+        st = enqueue_pipeline(b, rp, n_active, false, nullptr, &lt);
+        if (st != MVS_OK)
+            break;
+        if (hipEventSynchronize(ev[lt.n]) != hipSuccess) {
+            ctx->err = "mvs_batch_time_kernels: hipEventSynchronize failed";
+            st = MVS_ERR_HIP;
+            break;
+        }
+        n = lt.n;
+        for (int k = 0; k < n; ++k) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev[k], ev[k + 1]) != hipSuccess) {
+                ctx->err = "mvs_batch_time_kernels: hipEventElapsedTime failed";
+                st = MVS_ERR_HIP;
+                break;
+            }
+            ms[k] += t;
+            kernel_id[k] = kid[k];
+        }
+    }
+    for (int k = 0; k <= cap; ++k)
+        (void)hipEventDestroy(ev[k]);
+    if (st != MVS_OK)
+        return st;
+    for (int k = 0; k < n; ++k)
+        ms[k] /= (float)steps;
+    *n_launches = n;
+    return MVS_OK;
+}
+
+mvs_status mvs_kernel_info_get(mvs_ctx *ctx, int index, int max_kp, int desc_bytes, mvs_kernel_info *out)
+{
+    if (!ctx || !out || index < 0 || max_kp < 1 || max_kp > kMaxKp)
+        return MVS_ERR_INVALID_ARG;
+    KernelDesc kd;
+    if (!kernel_desc(index, max_kp, desc_bytes / 4, &kd))
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->name, sizeof(out->name), "%s", kd.name);
+    const char *sym = hipKernelNameRefByPtr(kd.fn, ctx->stream);
+    std::snprintf(out->symbol, sizeof(out->symbol), "%s", sym ? sym : "");
+    hipFuncAttributes fa;
+    HIP_TRY(ctx, hipFuncGetAttributes(&fa, kd.fn));
+    out->kernel_id = index;
+    out->threads_per_block = kd.threads;
+    out->num_regs = fa.numRegs;
+    out->static_lds_bytes = (int32_t)fa.sharedSizeBytes;
+    out->dynamic_lds_bytes = (int32_t)kd.dynamic_lds;
+    out->scratch_bytes_per_lane = (int32_t)fa.localSizeBytes;
+    out->max_threads_per_block = fa.maxThreadsPerBlock;
+    int nb = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kd.fn, kd.threads, kd.dynamic_lds));
+    out->blocks_per_cu = nb;
+    const int waves = nb * ((kd.threads + 63) / 64);
+    out->waves_per_simd = waves ? std::max(1, waves / 4) : 0;
     return MVS_OK;
 }
 
@@ -751,7 +895,7 @@ mvs_status mvs_batch_download(mvs_batch *b, int first, int count, mvs_pair_resul
                                            point_idx ? tmp.data() : nullptr);
     if (st != MVS_OK)
         return st;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_stream(ctx));
     for (size_t i = 0; i < tmp.size(); ++i)
         point_idx[i] = tmp[i];  // reference type: size_t (sfm.hpp:35)
     return MVS_OK;
@@ -824,7 +968,7 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     st = enqueue_pipeline(b, to_run(*params), n_active, true, nullptr);
     if (st != MVS_OK)
         return st;
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     unsigned long long h[4];
     HIP_TRY(ctx, hipMemcpy(h, b->d.stats, sizeof(h), hipMemcpyDeviceToHost));
     std::vector<mvs_pair_result> res(n_active);
@@ -832,6 +976,7 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     std::memset(out, 0, sizeof(*out));
     out->rotations9 = (int64_t)h[0];
     out->pairs9 = (int64_t)h[1];
+    out->score_evals_executed = (int64_t)h[2];
     for (const auto &r : res) {
         out->matches += r.n_matches;
         out->inliers += r.n_inliers;
@@ -953,7 +1098,7 @@ static mvs_status fetch_single(mvs_ctx *ctx, int m, mvs_pair_result *res, double
         HIP_TRY(ctx, hipMemcpyAsync(h_idx, b->d.point_idx, rows * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (h_mt)
         HIP_TRY(ctx, hipMemcpyAsync(h_mt, b->d.matches, rows * sizeof(mvs_match), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     *res = *h_res;
     const size_t M = (size_t)std::min<int>(std::max(res->n_matches, 0), (int)rows);
@@ -1012,7 +1157,7 @@ mvs_status mvs_match_hamming(mvs_ctx *ctx, const uint8_t *train_desc, int n_trai
     PIN_TRY(ctx, h_mt);
     HIP_TRY(ctx, hipMemcpyAsync(h_M, b->d.M, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(h_mt, b->d.matches, (size_t)n_query * sizeof(mvs_match), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     const int32_t M = *h_M;
     if (M > 0)
@@ -1206,9 +1351,9 @@ mvs_status mvs_find_fundamental_matrix(mvs_ctx *ctx, const double p1_xy[16], con
     double *d = ctx->d_small;  // [0,16) p1, [16,32) p2, [32,41) F, [48] ok flag (as int)
     HIP_TRY(ctx, hipMemcpyAsync(d, p1_xy, 16 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d + 16, p2_xy, 16 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     launch_fundamental(d, d + 16, d + 32, reinterpret_cast<int *>(d + 48), s);
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     int ok = 0;
     HIP_TRY(ctx, hipMemcpy(F, d + 32, 9 * sizeof(double), hipMemcpyDeviceToHost));
@@ -1354,7 +1499,7 @@ mvs_status mvs_seq_create(mvs_ctx *ctx, int n_frames, int max_kp, int desc_bytes
         hipError_t e = hipMemcpyAsync(gidx, g.data(), T * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(n_corr, 0, T * sizeof(int32_t), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(po, 0, T * sizeof(PnpOut), ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // `g` lives on this frame
+        if (e == hipSuccess) e = sync_stream(ctx);   // `g` lives on this frame
         if (e != hipSuccess) {
             ctx->err = std::string("mvs_seq_create: ") + hipGetErrorString(e);
             mvs_seq_destroy(q);
@@ -1404,7 +1549,7 @@ void mvs_seq_destroy(mvs_seq *q)
     if (!q)
         return;
     (void)hipSetDevice(q->ctx->device);
-    (void)hipStreamSynchronize(q->ctx->stream);
+    (void)sync_stream(q->ctx);
     if (q->batch)
         mvs_batch_destroy(q->batch);
     for (void *p : q->allocs)
@@ -1457,7 +1602,7 @@ mvs_status mvs_seq_upload(mvs_seq *q, int first, int count, const uint8_t *desc,
         HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(q->pnp.K), kk.data(), T * 9 * sizeof(double), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(const_cast<double *>(q->pnp.Kinv), ki.data(), T * 9 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 
@@ -1475,7 +1620,7 @@ static mvs_status seq_prepare(mvs_seq *q, const mvs_params *tv, const mvs_pnp_pa
         return st;
     const int G = (pp->num_hypotheses + 255) / 256;
     if (G > q->rec_groups) {
-        HIP_TRY(q->ctx, hipStreamSynchronize(q->ctx->stream));
+        HIP_TRY(q->ctx, sync_stream(q->ctx));
         PnpRec *rec;
         if ((st = seq_alloc(q, &rec, (size_t)q->n_tracks * G)) != MVS_OK)
             return st;
@@ -1558,7 +1703,7 @@ mvs_status mvs_seq_sync(mvs_seq *q)
 {
     if (!q)
         return MVS_ERR_INVALID_ARG;
-    HIP_TRY(q->ctx, hipStreamSynchronize(q->ctx->stream));
+    HIP_TRY(q->ctx, sync_stream(q->ctx));
     return MVS_OK;
 }
 
@@ -1575,7 +1720,7 @@ mvs_status mvs_seq_time(mvs_seq *q, const mvs_params *two_view, const mvs_pnp_pa
     for (int i = 0; i < warmup; ++i)
         if ((st = seq_enqueue(q, rp)) != MVS_OK)
             return st;
-    HIP_TRY(q->ctx, hipStreamSynchronize(s));
+    HIP_TRY(q->ctx, sync_stream(q->ctx));
     HIP_TRY(q->ctx, hipEventRecord(q->batch->ev[5], s));
     for (int i = 0; i < steps; ++i)
         if ((st = seq_enqueue(q, rp)) != MVS_OK)
@@ -1639,7 +1784,7 @@ mvs_status mvs_seq_download_tracks(mvs_seq *q, int first, int count, mvs_track_r
         return MVS_ERR_INVALID_ARG;
     mvs_ctx *ctx = q->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_stream(ctx));
     const size_t S = q->stride, N = q->batch->d.max_kp, off = first, cnt = count;
     if (tracks) {
         std::vector<PnpOut> po(cnt);
@@ -1738,7 +1883,7 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
     HIP_TRY(ctx, hipMemcpyAsync(duv, image_uv, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dK, kk, sizeof(kk), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dinl + n, &n32, sizeof(n32), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     PnpDev p{};
     p.n_problems = 1;
     p.stride = n;
@@ -1760,7 +1905,7 @@ mvs_status mvs_pnp_solve(mvs_ctx *ctx, const double *world_xyz, const double *im
     p.out = reinterpret_cast<PnpOut *>(base + off_out);
     p.inliers = dinl;
     launch_pnp(p, s);
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     PnpOut out;
     HIP_TRY(ctx, hipMemcpy(&out, p.out, sizeof(out), hipMemcpyDeviceToHost));
@@ -1913,7 +2058,7 @@ static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, c
     HIP_TRY(ctx, hipMemcpyAsync(dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dpose, pose, sizeof(pose), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dm, &m32, sizeof(m32), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));  // the staging buffers above live on this frame
+    HIP_TRY(ctx, sync_stream(ctx));  // the staging buffers above live on this frame
     RefineDev d{};
     d.n_problems = 1;
     d.stride = m;
@@ -1946,7 +2091,7 @@ static mvs_status refine_single(mvs_ctx *ctx, int frames, const double *obs_a, c
         HIP_TRY(ctx, hipMemcpyAsync(points_out, dpts, M * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (point_cov_out)
         HIP_TRY(ctx, hipMemcpyAsync(point_cov_out, dpcov, M * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     return result->ok ? MVS_OK : MVS_NO_MODEL;
 }
 
@@ -2098,7 +2243,7 @@ mvs_status mvs_batch_download_refined(mvs_batch *b, mvs_refine_result *refined, 
         HIP_TRY(ctx, hipMemcpyAsync(points_xyz, d.pts, P * N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (point_cov)
         HIP_TRY(ctx, hipMemcpyAsync(point_cov, d.point_cov, P * N * 9 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 
@@ -2118,7 +2263,7 @@ mvs_status mvs_seq_download_trajectory(mvs_seq *q, double *R, double *t, double 
         HIP_TRY(ctx, hipMemcpyAsync(pair_scale, q->chain.traj_sigma, (F - 1) * sizeof(double), hipMemcpyDeviceToHost, s));
     if (track_scale)
         HIP_TRY(ctx, hipMemcpyAsync(track_scale, q->chain.track_scale, (F - 2) * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 
@@ -2146,7 +2291,7 @@ mvs_status mvs_batch_upload_octaves(mvs_batch *b, int first, int count, const ui
     if (pair_octave)
         HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t *>(b->d.oct2) + off, pair_octave, bytes, hipMemcpyHostToDevice,
                                     ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 
@@ -2162,7 +2307,7 @@ mvs_status mvs_seq_upload_octaves(mvs_seq *q, int first, int count, const uint8_
             return MVS_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t *>(q->batch->d.oct1) + (size_t)first * N, octave, bytes,
                                 hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 
@@ -2338,8 +2483,12 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     if (!tab.empty())
         HIP_TRY(ctx, hipMemcpyAsync(base + o_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d.pyr, images, (size_t)w * h * B, hipMemcpyHostToDevice, s));  // level 0 = the input
-    HIP_TRY(ctx, hipStreamSynchronize(s));   // `pat` and `tab` live on this frame
-    static const bool no_graph = std::getenv("MVS_NO_GRAPH") != nullptr;   // A/B switch for tools/extract_bench.py
+    HIP_TRY(ctx, sync_stream(ctx));   // `pat` and `tab` live on this frame
+#ifdef MVS_DEBUG_HOOKS
+    static const bool no_graph = std::getenv("MVS_NO_GRAPH") != nullptr;   // A/B switch for tools/extract_bench.py (diagnostics build only)
+#else
+    constexpr bool no_graph = false;
+#endif
     if (no_graph) {
         launch_orb(d, s);
     } else {
@@ -2362,8 +2511,35 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     HIP_TRY(ctx, hipGetLastError());
     int32_t ovf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&ovf, d.overflow, sizeof(ovf), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     return ovf ? MVS_ERR_CAPACITY : MVS_OK;
+}
+
+mvs_status mvs_extract_time(mvs_ctx *ctx, int steps, float *ms_total)
+{
+    if (!ctx || !ms_total || steps < 1)
+        return MVS_ERR_INVALID_ARG;
+    if (!ctx->orb_graph_valid || !ctx->orb_graph)
+        return MVS_ERR_INVALID_ARG;   // nothing has been extracted on this context yet
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        ctx->err = "mvs_extract_time: hipEventCreate failed";
+        return MVS_ERR_HIP;
+    }
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipEventRecord(e0, s);
+    for (int i = 0; i < steps && e == hipSuccess; ++i)
+        e = hipGraphLaunch(ctx->orb_graph, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms_total, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(ctx, e);
+    return MVS_OK;
 }
 
 mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int width, int height,
@@ -2380,7 +2556,7 @@ mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int wi
     HIP_TRY(ctx, hipMemcpyAsync(keypoints, d.kp, B * NF * sizeof(mvs_keypoint), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(descriptors, d.desc, B * NF * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(n_keypoints, d.n_kp, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, sync_stream(ctx));
     return MVS_OK;
 }
 

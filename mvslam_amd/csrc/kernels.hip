@@ -17,7 +17,6 @@
 // problems per wave keep every lane busy, need no cross-lane traffic, and give the
 // reference's sequential residual order for free.  See DESIGN.md.
 #include <algorithm>
-#include <cstdlib>
 #include "kernels.hpp"
 
 #include "device_math.hpp"
@@ -670,8 +669,8 @@ __device__ __forceinline__ int count_block(const double (&F)[9], const double4 &
 // (hypothesis, block) -- count add, exit test, slot skip: the scalar unit is shared by the four SIMDs and was ~70 % busy
 // with 8 scalar instructions per 9 vector ones -- is amortised over 18 vector instructions; a dying hypothesis is noticed
 // up to 64 points later.
-template <int kCntThreads, int PPL>
-__global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, RunParams rp, int wg_per_pair)
+template <int CNT_THREADS, int PPL, bool STATS = false>
+__global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, RunParams rp, int wg_per_pair)
 {
     // two planes of double2, [nblk * 64] each: (x1, y1) and (x2, y2), NaN padded.  A lane reads one element of each with
     // ds_read_b128 at a 16-byte lane stride = 1 KB contiguous per wavefront: conflict-free (the AoS form, 32-byte
@@ -691,7 +690,7 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
     {
         const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
         const double qnan = __builtin_nan("");
-        for (int i = tid; i < nblk * BW; i += kCntThreads) {
+        for (int i = tid; i < nblk * BW; i += CNT_THREADS) {
             const double4 p = i < M ? src[i] : make_double4(qnan, qnan, qnan, qnan);
             s_p1[i] = make_double2(p.x, p.y);
             s_p2[i] = make_double2(p.z, p.w);
@@ -708,9 +707,10 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
     const double2 *L1 = s_p1 + lane, *L2 = s_p2 + lane;
     const int n_groups = (H + kCntSlots - 1) / kCntSlots;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_waves = wg_per_pair * (kCntThreads / 64);
+    const int n_waves = wg_per_pair * (CNT_THREADS / 64);
     int B = 0;
-    for (int g = blockIdx.x * (kCntThreads / 64) + wave; g < n_groups; g += n_waves) {
+    unsigned long long visits = 0;   // STATS: (hypothesis, block) evaluations this wavefront executed
+    for (int g = blockIdx.x * (CNT_THREADS / 64) + wave; g < n_groups; g += n_waves) {
         const int h0 = g * kCntSlots;
         // the pair's bound as other workgroups see it: load now, use after this group
         const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -761,6 +761,8 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
             for (int u = 0; u < PPL; ++u)
                 p[u] = make_double4(pa[u].x, pa[u].y, pb[u].x, pb[u].y);
             const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
+            if (STATS)
+                visits += (unsigned)__builtin_popcount(alive);
             if (alive & 1u) {
 #pragma unroll
                 for (int u = 0; u < PPL; ++u)
@@ -810,6 +812,8 @@ __global__ __launch_bounds__(kCntThreads) void ransac_count_kernel(BatchDev b, R
         }
         B = max(B, __builtin_amdgcn_readfirstlane(gb));
     }
+    if (STATS && lane == 0 && b.stats)
+        atomicAdd(&b.stats[2], visits * (unsigned long long)BW);   // executed (hypothesis, point) evaluations incl. padding
 }
 
 // grid P, 256 threads.  bound[pair] is now the largest full count (every surviving hypothesis went through the
@@ -1493,10 +1497,102 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
-void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
+constexpr int kCntThreads = 768;   // 12 wavefronts: two workgroups fit a CU (2 x 64 KB of LDS, 6 of the 7 wavefronts per SIMD the
+constexpr int kCntPpl = 2;         // 70 registers allow) against one workgroup of 1024 (4 per SIMD): 42.7 -> 42.3 ms per 512 pairs
+constexpr int kSolveBlock = 64;    // one wavefront per workgroup: every SIMD refills on its own (45.4 -> 44.5 ms, same bits)
+constexpr int kSplitMinPairs = 3;  // one or two pairs stay on the fused kernel (latency: fewer launches)
+
+static size_t count_lds_bytes(int max_kp)
+{
+    const int bw = 64 * kCntPpl;
+    return (size_t)((max_kp + bw - 1) / bw) * bw * 4 * sizeof(double);
+}
+
+bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
+{
+    KernelDesc d{nullptr, nullptr, 0, 0};
+    switch (id) {
+    case kKMatchTopk:
+        d.name = desc_words == 4 ? "match_topk_kernel<4>" : desc_words == 16 ? "match_topk_kernel<16>" : "match_topk_kernel<8>";
+        d.fn = desc_words == 4    ? reinterpret_cast<const void *>(match_topk_kernel<4>)
+               : desc_words == 16 ? reinterpret_cast<const void *>(match_topk_kernel<16>)
+                                  : reinterpret_cast<const void *>(match_topk_kernel<8>);
+        d.threads = 1024;
+        break;
+    case kKMatchCompact:
+        d.name = "match_compact_kernel";
+        d.fn = reinterpret_cast<const void *>(match_compact_kernel);
+        d.threads = 1024;
+        break;
+    case kKRansacFused:
+        d.name = "ransac_kernel<false, 1272>";
+        d.fn = reinterpret_cast<const void *>(ransac_kernel<false, 248 + 1024>);
+        d.threads = kHypPerBlock;
+        break;
+    case kKRansacSolve:
+        d.name = "ransac_solve_kernel<1264>";
+        d.fn = reinterpret_cast<const void *>(ransac_solve_kernel<240 + 1024>);
+        d.threads = kSolveBlock;
+        break;
+    case kKRansacScore:
+        d.name = "ransac_score_kernel";
+        d.fn = reinterpret_cast<const void *>(ransac_score_kernel);
+        d.threads = kHypPerBlock;
+        break;
+    case kKRansacCount:
+        d.name = "ransac_count_kernel<768, 2>";
+        d.fn = reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>);
+        d.threads = kCntThreads;
+        d.dynamic_lds = count_lds_bytes(max_kp);
+        break;
+    case kKRansacSelect:
+        d.name = "ransac_select_kernel";
+        d.fn = reinterpret_cast<const void *>(ransac_select_kernel);
+        d.threads = kSelThreads;
+        d.dynamic_lds = (size_t)max_kp * 4 * sizeof(double);
+        break;
+    case kKFinModel:
+        d.name = "finalize_model_kernel";
+        d.fn = reinterpret_cast<const void *>(finalize_model_kernel);
+        d.threads = kFinThreads;
+        break;
+    case kKTriangulate:
+        d.name = "triangulate_kernel";
+        d.fn = reinterpret_cast<const void *>(triangulate_kernel);
+        d.threads = 256;
+        break;
+    case kKFinSelect:
+        d.name = "finalize_select_kernel";
+        d.fn = reinterpret_cast<const void *>(finalize_select_kernel);
+        d.threads = kFinThreads;
+        break;
+    default: return false;
+    }
+    *out = d;
+    return true;
+}
+
+// The opt-in to more than 64 KB of dynamic LDS is a per-device function attribute.  Called from mvs_ctx_create (once per
+// context, i.e. per (thread, device)); the result is checked there, so a part without 160 KB of LDS fails at create time
+// with a clear message instead of at the first launch.
+hipError_t prepare_kernels()
+{
+    const void *fns[] = {reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>),
+                         reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl, true>),
+                         reinterpret_cast<const void *>(ransac_select_kernel)};
+    for (const void *f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt)
 {
     const dim3 grid((b.max_kp + 63) / 64, n_active), block(1024);
     const double ratio = rp.ratio, md = rp.max_dist;
+    if (lt) lt->mark(kKMatchTopk);
     switch (b.desc_words) {
     case 4: hipLaunchKernelGGL(match_topk_kernel<4>, grid, block, 0, stream, b, ratio, md); break;
     case 8: hipLaunchKernelGGL(match_topk_kernel<8>, grid, block, 0, stream, b, ratio, md); break;
@@ -1505,8 +1601,9 @@ void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hip
     }
 }
 
-void launch_match_compact(const BatchDev &b, const RunParams &, int n_active, hipStream_t stream)
+void launch_match_compact(const BatchDev &b, const RunParams &, int n_active, hipStream_t stream, LaunchTimer *lt)
 {
+    if (lt) lt->mark(kKMatchCompact);
     hipLaunchKernelGGL(match_compact_kernel, dim3(n_active), dim3(1024), 0, stream, b);
 }
 
@@ -1523,85 +1620,51 @@ void set_ransac_variant(int v) { g_ransac_variant = v; }
 int get_ransac_variant() { return g_ransac_variant; }
 
 template <int VAR>
-static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid, dim3 block, bool stats, hipStream_t stream)
+static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid, dim3 block, bool stats, hipStream_t stream,
+                              LaunchTimer *lt)
 {
+    if (lt) lt->mark(kKRansacFused);
     if (stats)
         hipLaunchKernelGGL((ransac_kernel<true, VAR>), grid, block, 0, stream, b, rp);
     else
         hipLaunchKernelGGL((ransac_kernel<false, VAR>), grid, block, 0, stream, b, rp);
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
+static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt,
+                                  bool stats = false)
 {
     // enough workgroups to fill the chip for a small launch, few enough that every wavefront works through many
     // groups of four hypotheses (the bound only helps once the first groups have finished)
-    // 768 threads = 12 wavefronts: two workgroups fit a CU (2 x 64 KB of LDS, 6 of the 7 wavefronts per SIMD the 70
-    // registers allow), against one workgroup of 1024 (4 wavefronts per SIMD): more wavefronts to cover the scalar loads
-    // of a group of four hypotheses, 42.7 -> 42.3 ms per 512 pairs (896 = 7 per SIMD on paper, uneven over the SIMDs: 43.1)
-    static const int threads_env = env_int("MVS_CNT_THREADS", 768);   // experiment knobs
-    static const int threads = threads_env == 512 ? 512 : threads_env == 1024 ? 1024 : threads_env == 896 ? 896 : 768;
-    static const int ppl = env_int("MVS_CNT_PPL", 2) == 1 ? 1 : 2;
     const int n_groups4 = (rp.num_hypotheses + kCntSlots - 1) / kCntSlots;
-    const int wpw = threads / 64;
+    const int wpw = kCntThreads / 64;
     int wg = (512 + n_active - 1) / n_active;
     wg = std::max(wg, 4);
     wg = std::min(wg, std::max(1, (n_groups4 + wpw - 1) / wpw));
-    const int bw = 64 * ppl;
-    const size_t lds_cnt = (size_t)((b.max_kp + bw - 1) / bw) * bw * 4 * sizeof(double);
+    const size_t lds_cnt = count_lds_bytes(b.max_kp);
     const size_t lds_sel = (size_t)b.max_kp * 4 * sizeof(double);
-    // the opt-in to more than 64 KB of dynamic LDS is a per-device function attribute: once per device of this process
-    static bool attr_done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    bool &attr_set = attr_done[dev & 63];
-    if (!attr_set) {
-        const void *fns[] = {reinterpret_cast<const void *>(ransac_count_kernel<512, 1>),
-                             reinterpret_cast<const void *>(ransac_count_kernel<1024, 1>),
-                             reinterpret_cast<const void *>(ransac_count_kernel<512, 2>),
-                             reinterpret_cast<const void *>(ransac_count_kernel<1024, 2>),
-                             reinterpret_cast<const void *>(ransac_count_kernel<768, 2>),
-                             reinterpret_cast<const void *>(ransac_count_kernel<896, 2>),
-                             reinterpret_cast<const void *>(ransac_select_kernel)};
-        for (const void *f : fns)
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
-        attr_set = true;
-    }
     const dim3 grid(wg, n_active);
-    if (threads == 768)
-        hipLaunchKernelGGL((ransac_count_kernel<768, 2>), grid, dim3(768), lds_cnt, stream, b, rp, wg);
-    else if (threads == 896)
-        hipLaunchKernelGGL((ransac_count_kernel<896, 2>), grid, dim3(896), lds_cnt, stream, b, rp, wg);
-    else if (threads == 512 && ppl == 1)
-        hipLaunchKernelGGL((ransac_count_kernel<512, 1>), grid, dim3(512), lds_cnt, stream, b, rp, wg);
-    else if (threads == 512)
-        hipLaunchKernelGGL((ransac_count_kernel<512, 2>), grid, dim3(512), lds_cnt, stream, b, rp, wg);
-    else if (ppl == 1)
-        hipLaunchKernelGGL((ransac_count_kernel<1024, 1>), grid, dim3(1024), lds_cnt, stream, b, rp, wg);
+    if (lt) lt->mark(kKRansacCount);
+    if (stats)
+        hipLaunchKernelGGL((ransac_count_kernel<kCntThreads, kCntPpl, true>), grid, dim3(kCntThreads), lds_cnt, stream, b, rp, wg);
     else
-        hipLaunchKernelGGL((ransac_count_kernel<1024, 2>), grid, dim3(1024), lds_cnt, stream, b, rp, wg);
+        hipLaunchKernelGGL((ransac_count_kernel<kCntThreads, kCntPpl>), grid, dim3(kCntThreads), lds_cnt, stream, b, rp, wg);
+    if (lt) lt->mark(kKRansacSelect);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
-void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream)
+void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream, LaunchTimer *lt)
 {
     const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
     const dim3 grid(G, n_active), block(kHypPerBlock);
     // the instrumented replay and the per-hypothesis tables (every count AND every residual) stay on the
     // hypothesis-per-lane kernels; so does a launch of one or two pairs (latency: fewer launches)
-    static const int split_min = env_int("MVS_SPLIT_MIN_PAIRS", 3);   // experiment knob
-    const bool split_ok = !stats && b.hyp_F && n_active >= split_min;
+    const bool split_ok = !stats && b.hyp_F && n_active >= kSplitMinPairs;
     switch (g_ransac_variant) {
-    case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream); break;
-    case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream); break;   // timing experiment: no V rotations
+    case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream, lt); break;
+    case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream, lt); break;   // timing experiment: no V rotations
     case 632:
         if (!split_ok) {
-            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
         } else {
             hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
             hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
@@ -1609,7 +1672,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
         break;
     case 760:   // 632 + sqrt-free convergence test
         if (!split_ok) {
-            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
         } else {
             hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
             hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
@@ -1617,55 +1680,54 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
         break;
     case 3832:  // 1784 with the solve as A / V wavefront pairs
         if (!split_ok || b.hyp_count) {
-            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
+            launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
         } else {
             hipLaunchKernelGGL((ransac_solve_av_kernel<240>), grid, dim3(512), 0, stream, b, rp);
-            launch_pruned_scoring(b, rp, n_active, stream);
-        }
-        break;
-    case 5880:  // experiment: 1784 with the 3x3 SVD on the unscaled sequences too
-        if (!split_ok || b.hyp_count) {
-            launch_ransac_var<120>(b, rp, grid, block, stats, stream);
-        } else {
-            hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), grid, block, 0, stream, b, rp);
-            launch_pruned_scoring(b, rp, n_active, stream);
+            launch_pruned_scoring(b, rp, n_active, stream, lt);
         }
         break;
     case 1656:  // 632 + pruned scoring
-    case 1784:  // 760 + pruned scoring
+    case 1784:  // 760 + pruned scoring (+ the 3x3 SVD on the unscaled sequences): the default
         if (!split_ok) {
             // one or two pairs, per-hypothesis tables: the fused kernel (with the same sqrt-free pair step for 1784);
             // the instrumented replay stays on variant 120, whose counters the flop model was derived with
             if (g_ransac_variant == 1784 && !stats)
-                launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream);
+                launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
             else
-                launch_ransac_var<120>(b, rp, grid, block, stats, stream);
-        } else {
-            if (g_ransac_variant == 1784) {
-                // one wavefront per workgroup: the kernel runs at one wavefront per SIMD, and a 256-thread workgroup holds
-                // its four SIMDs until its slowest wavefront (one more Jacobi sweep than the others) has finished;
-                // single-wavefront workgroups refill every SIMD on its own: 45.4 -> 44.5 ms per 512 pairs, same bits
-                static const int sb = env_int("MVS_SOLVE_BLOCK", 64);   // experiment knob: 64, 128 or 256
-                const int bs = (sb == 128 || sb == 256) ? sb : 64;
-                hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / bs), n_active), dim3(bs), 0,
-                                   stream, b, rp);
+                launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
+            if (stats && b.hyp_F && !b.hyp_count && n_active >= kSplitMinPairs && g_ransac_variant == 1784) {
+                // the instrumented replay also runs the product path once with the counting kernel's evaluation counter
+                // (stats[2]): the roofline quotes EXECUTED evaluations for the pruned kernel, not the H x M it avoids
+                hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active),
+                                   dim3(kSolveBlock), 0, stream, b, rp);
+                launch_pruned_scoring(b, rp, n_active, stream, nullptr, true);
             }
+        } else {
+            if (lt) lt->mark(kKRansacSolve);
+            if (g_ransac_variant == 1784)
+                hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active),
+                                   dim3(kSolveBlock), 0, stream, b, rp);
             else
                 hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
-            if (b.hyp_count)
+            if (b.hyp_count) {
+                if (lt) lt->mark(kKRansacScore);
                 hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
-            else
-                launch_pruned_scoring(b, rp, n_active, stream);
+            } else {
+                launch_pruned_scoring(b, rp, n_active, stream, lt);
+            }
         }
         break;
-    default: launch_ransac_var<120>(b, rp, grid, block, stats, stream); break;
+    default: launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt); break;
     }
 }
 
-void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream)
+void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream, LaunchTimer *lt)
 {
+    if (lt) lt->mark(kKFinModel);
     hipLaunchKernelGGL(finalize_model_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b, rp, mode);
+    if (lt) lt->mark(kKTriangulate);
     hipLaunchKernelGGL(triangulate_kernel, dim3((4 * b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b);
+    if (lt) lt->mark(kKFinSelect);
     hipLaunchKernelGGL(finalize_select_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b);
 }
 

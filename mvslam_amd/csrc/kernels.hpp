@@ -248,12 +248,55 @@ struct OrbDev {
 hipError_t orb_prepare(int cand_cap);
 void launch_orb(const OrbDev &d, hipStream_t stream);
 
-// launch wrappers (all asynchronous on `stream`)
-void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
-void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
+// ---- kernel table (mvs_kernel_info_get) and per-launch timing (mvs_batch_time_kernels) ---------------------------
+// One id per kernel of the two-view pipeline.  launch_* record an event in front of every launch when given a
+// LaunchTimer, so the per-kernel times of the bench line are measured on the launches' own stream, launch by launch.
+enum KernelId : int {
+    kKMatchTopk = 0,
+    kKMatchCompact,
+    kKRansacFused,     // solve + hypothesis-per-lane scoring in one launch (one or two pairs, per-hypothesis tables)
+    kKRansacSolve,
+    kKRansacScore,     // hypothesis-per-lane scoring of stored F records (per-hypothesis tables)
+    kKRansacCount,
+    kKRansacSelect,
+    kKFinModel,
+    kKTriangulate,
+    kKFinSelect,
+    kKernelCount
+};
+struct LaunchTimer {
+    hipStream_t stream;
+    hipEvent_t *ev;   // cap + 1 events
+    int32_t *kid;     // kernel id of launch k
+    int cap;
+    int n;
+    void mark(int id)
+    {
+        if (n < cap) {
+            (void)hipEventRecord(ev[n], stream);
+            kid[n] = id;
+            ++n;
+        }
+    }
+    void end() { (void)hipEventRecord(ev[n], stream); }
+};
+struct KernelDesc {
+    const char *name;     // as rocprofv3 prints it
+    const void *fn;       // host-side handle of the __global__ function
+    int threads;          // threads per workgroup as launched
+    size_t dynamic_lds;   // bytes of dynamic LDS as launched for `max_kp`
+};
+// entry `id` of the table for a batch with `max_kp` keypoints per image; false past the end
+bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out);
+
+// launch wrappers (all asynchronous on `stream`); lt: optional per-launch timer
+void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt = nullptr);
+void launch_match_compact(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt = nullptr);
 void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2, int n_active, hipStream_t stream);
-void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream);
-void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
+void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream, LaunchTimer *lt = nullptr);
+void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream, LaunchTimer *lt = nullptr);
+// opt-in to > 64 KB of dynamic LDS for the kernels that need it, once per device; hipSuccess or the first error
+hipError_t prepare_kernels();
 void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)
 int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);

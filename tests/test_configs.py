@@ -37,12 +37,21 @@ def _threads(fn, items, n=16):
     return out
 
 
+_BATCH512 = {}
+
+
+def _batch512():
+    if "d" not in _BATCH512:
+        _BATCH512["d"] = synth.make_batch(0, 512, n_kp=2000)
+    return _BATCH512["d"]
+
+
 def test_config3_batch512(ctx):
     from mvslam_amd import capi
 
     P, N, H, THR = 512, 2000, 50000, 1e-2
     prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=THR)
-    data = synth.make_batch(0, P, n_kp=N)
+    data = _batch512()
     b = capi.Batch(ctx, P, N, 32)
     b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
              data["global_index"])
@@ -105,6 +114,103 @@ def test_config3_batch512(ctx):
         assert r["n_points"] == n and np.array_equal(out["point_idx"][i][:n], ref["point_idx"])
         assert np.abs(out["points"][i][:n] - ref["points"]).max() <= 1e-12 * max(1.0, np.abs(ref["points"]).max())
         assert np.abs(r["R"] - ref["R"]).max() <= 1e-12 and np.abs(r["t"] - ref["t"]).max() <= 1e-12
+
+
+def test_config3_batch512_reference_threshold(ctx):
+    """configs[2] at SURVEY 8(d)'s own threshold: max_error_sq = 0 selects the reference formula 5e-2 / K00 / K11
+    (sfm-solve.cpp:18-19,311).  Best counts are ~5-10, hundreds of hypotheses tie at the maximum and the winner is decided
+    by the residual sum (estimator-RANSAC.cpp:76-84): the regime that exercises the tie paths of the selection at full
+    size.  Determinism over two runs of the batch + oracle parity on the same 16 sampled pairs as the 1e-2 leg."""
+    from mvslam_amd import capi
+
+    P, N, H = 512, 2000, 50000
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=0.0)
+    data = _batch512()
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+             data["global_index"])
+    b.run(prm)
+    b.sync()
+    out = b.download()
+    b.run(prm)
+    b.sync()
+    out2 = b.download()
+    b.close()
+    res = out["results"]
+    assert res.tobytes() == out2["results"].tobytes()
+    assert out["mask"].tobytes() == out2["mask"].tobytes() and out["points"].tobytes() == out2["points"].tobytes()
+    assert out["point_idx"].tobytes() == out2["point_idx"].tobytes()
+    thr = 5e-2 / 525.0 / 525.0
+    assert (res["best_hyp"] >= 0).all() and (res["best_count"] >= 1).all() and (res["best_count"] < 200).all()
+    Kinv = np.linalg.inv(synth.K_DEFAULT)
+    for i in range(P):
+        r = res[i]
+        M = int(r["n_matches"])
+        assert out["mask"][i][:M].sum() == r["n_inliers"] == r["best_count"]
+        mt = out["matches"][i][:M]
+        x1 = (Kinv @ np.c_[data["kp1"][i][mt["trainIdx"]].astype(float), np.ones(M)].T).T
+        x2 = (Kinv @ np.c_[data["kp2"][i][mt["queryIdx"]].astype(float), np.ones(M)].T).T
+        e = np.abs(np.einsum("ij,jk,ik->i", x2, r["F"], x1))
+        inl = out["mask"][i][:M].astype(bool)
+        assert (e[inl] < thr * (1 + 1e-6)).all() and (e[~inl] > thr * (1 - 1e-6)).all()
+        assert bool(r["valid"]) == (r["n_points"] > 0)
+    rng = np.random.default_rng(2)
+    sample = [0, P - 1] + sorted(rng.choice(np.arange(1, P - 1), size=14, replace=False).tolist())
+
+    def oracle(i):
+        return o.image_pair(data["desc1"][i], data["kp1"][i], data["desc2"][i], data["kp2"][i],
+                            data["K"][i].reshape(3, 3),
+                            o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(data["global_index"][i]), 0.0), 0.7, 10.0)
+
+    n_valid = 0
+    for i, ref in zip(sample, _threads(oracle, sample)):
+        r = res[i]
+        M = ref["n_matches"]
+        assert r["n_matches"] == M and out["matches"][i][:M].tobytes() == ref["matches"].tobytes()
+        assert bool(r["valid"]) == bool(ref["ok"])
+        assert r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"]
+        assert r["best_residual"] == ref["best_residual"]                         # the tie-breaker, bit for bit
+        assert np.array_equal(out["mask"][i][:M], ref["mask"])
+        if ref["ok"]:
+            n_valid += 1
+            n = ref["n_points"]
+            assert r["n_points"] == n and np.array_equal(out["point_idx"][i][:n], ref["point_idx"])
+            assert np.abs(r["R"] - ref["R"]).max() <= 1e-12 and np.abs(r["t"] - ref["t"]).max() <= 1e-12
+    print("config3 at the reference threshold: best_count min/median/max = %d / %d / %d, valid %d of 512 (sample: %d of 16)"
+          % (res["best_count"].min(), np.median(res["best_count"]), res["best_count"].max(), int(res["valid"].sum()), n_valid))
+
+
+def test_config5_sequence_window_reference_threshold(ctx):
+    """One window of configs[4] at the reference threshold (max_error_sq = 0 -> 5e-2 / K00 / K11): the first 64 frames of
+    the 1000-frame sequence at full size per frame (2000 keypoints, 50 000 hypotheses), determinism over two runs and
+    oracle parity of every pair of one 4-frame window."""
+    from mvslam_amd import capi
+    from test_sequence import oracle_sequence
+
+    F, N, H, HP = 64, 2000, 50000, 100
+    seq = synth.make_sequence(1000, n_kp=N)
+    seq = dict(desc=seq["desc"][:F], kp=seq["kp"][:F], n_kp=seq["n_kp"][:F], K=seq["K"])
+    s = capi.Sequence(ctx, F, N, 32)
+    s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
+    p2 = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=0.0)
+    pp = capi.default_pnp_params(num_hypotheses=HP, seed=7, reproj_error=2.0)
+    s.run(p2, pp)
+    gp = s.download_pairs()
+    s.run(p2, pp)
+    gp2 = s.download_pairs()
+    s.close()
+    res = gp["results"]
+    assert res.tobytes() == gp2["results"].tobytes() and gp["mask"].tobytes() == gp2["mask"].tobytes()
+    k0 = 30
+    sub = dict(desc=seq["desc"][k0:k0 + 4], kp=seq["kp"][k0:k0 + 4], n_kp=seq["n_kp"][k0:k0 + 4], K=seq["K"])
+    pairs, _ = oracle_sequence(sub, dict(H=H, seed=synth.SEED_BASE + k0, thr=0.0), dict(H=HP, seed=7 + k0, err=2.0))
+    for j, ref in enumerate(pairs):
+        k = k0 + j
+        r, M = res[k], ref["n_matches"]
+        assert r["n_matches"] == M and gp["matches"][k][:M].tobytes() == ref["matches"].tobytes()
+        assert bool(r["valid"]) == ref["ok"] and np.array_equal(gp["mask"][k][:M], ref["mask"])
+        assert r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"]
+        assert r["best_residual"] == ref["best_residual"]
 
 
 def test_config5_sequence1000(ctx):
