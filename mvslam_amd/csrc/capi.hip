@@ -227,24 +227,33 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
         return MVS_OK;
     HIP_TRY(b->ctx, sync_stream(b->ctx));
     const size_t P = (size_t)b->d.n_pairs, Hp = (size_t)G * kHypPerBlock;
+    if (P * Hp >= (size_t(1) << 32))
+        return MVS_ERR_CAPACITY;   // the exact solve's work list holds flat 32-bit record indices
     WgBest *p = nullptr;
-    double *hf = nullptr;   // F of every hypothesis (solve -> scoring hand-over): 72 B x hypotheses x pairs
+    double *hf = nullptr;   // record of every hypothesis (F + counting threshold): 80 B x hypotheses x pairs
     uint8_t *ho = nullptr;
     int32_t *hc = nullptr;
+    uint32_t *xl = nullptr;
     mvs_status st;
     if ((st = dev_alloc(b, &p, P * G)) != MVS_OK) return st;
-    if ((st = dev_alloc(b, &hf, P * 9 * Hp)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &hf, P * kHypRec * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &ho, P * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &hc, P * Hp)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &xl, P * Hp)) != MVS_OK) return st;
     if (!b->d.bound && (st = dev_alloc(b, &b->d.bound, P)) != MVS_OK) return st;
+    if (!b->d.box && (st = dev_alloc(b, &b->d.box, P * 8)) != MVS_OK) return st;
+    if (!b->d.mode && (st = dev_alloc(b, &b->d.mode, P)) != MVS_OK) return st;
+    if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 2)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
     dev_release(b, b->d.hyp_F);
     dev_release(b, b->d.hyp_okf);
     dev_release(b, b->d.hyp_cnt);
+    dev_release(b, b->d.xlist);
     b->d.wgbest = p;
     b->d.hyp_F = hf;
     b->d.hyp_okf = ho;
     b->d.hyp_cnt = hc;
+    b->d.xlist = xl;
     b->d.max_groups = G;
     return MVS_OK;
 }
@@ -320,15 +329,52 @@ int mvs_debug_set_ransac_variant(int v)
 }
 
 // diagnostics only: the per-hypothesis F records the solve launch handed to the scoring launch (pair `pair` of a batch)
-int mvs_debug_read_hyp_F(mvs_batch *b, int pair, int n_hyp, double *F_out, unsigned char *ok_out)
+int mvs_debug_set_prescreen_force(int m)
+{
+    set_prescreen_force(m);
+    return MVS_OK;
+}
+
+// records of the RANSAC stage as the last run left them: rec_out n_hyp x 10 (F, counting threshold), state bytes, counts;
+// info[0..3] = {mode of the pair, bound of the pair, work-list entries 0, work-list entries 1}
+int mvs_debug_read_hyp_rec(mvs_batch *b, int pair, int n_hyp, double *rec_out, unsigned char *state_out, int32_t *cnt_out,
+                           int32_t *info)
 {
     if (!b || !b->d.hyp_F || pair < 0 || pair >= b->d.n_pairs || n_hyp < 1 || n_hyp > b->d.max_groups * kHypPerBlock)
         return MVS_ERR_INVALID_ARG;
     const size_t Hp = (size_t)b->d.max_groups * kHypPerBlock;
     HIP_TRY(b->ctx, sync_stream(b->ctx));
-    HIP_TRY(b->ctx, hipMemcpy(F_out, b->d.hyp_F + (size_t)pair * Hp * 9, (size_t)n_hyp * 9 * sizeof(double), hipMemcpyDeviceToHost));
-    if (ok_out)
-        HIP_TRY(b->ctx, hipMemcpy(ok_out, b->d.hyp_okf + (size_t)pair * Hp, (size_t)n_hyp, hipMemcpyDeviceToHost));
+    if (rec_out)
+        HIP_TRY(b->ctx, hipMemcpy(rec_out, b->d.hyp_F + (size_t)pair * Hp * kHypRec, (size_t)n_hyp * kHypRec * sizeof(double),
+                                  hipMemcpyDeviceToHost));
+    if (state_out)
+        HIP_TRY(b->ctx, hipMemcpy(state_out, b->d.hyp_okf + (size_t)pair * Hp, (size_t)n_hyp, hipMemcpyDeviceToHost));
+    if (cnt_out)
+        HIP_TRY(b->ctx, hipMemcpy(cnt_out, b->d.hyp_cnt + (size_t)pair * Hp, (size_t)n_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (info) {
+        uint32_t xc[2] = {0, 0};
+        HIP_TRY(b->ctx, hipMemcpy(&info[0], b->d.mode + pair, sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(b->ctx, hipMemcpy(&info[1], b->d.bound + pair, sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(b->ctx, hipMemcpy(xc, b->d.xcount, sizeof(xc), hipMemcpyDeviceToHost));
+        info[2] = (int32_t)xc[0];
+        info[3] = (int32_t)xc[1];
+    }
+    return MVS_OK;
+}
+
+// the pre-screen alone over pairs [0, n_active) of a batch that has been run (matches and points resident): pair_prepare +
+// ransac_prescreen, every pair forced into the pre-screened mode, nothing solved exactly afterwards -- the records then
+// hold F~ and thr + band (state 1), or wait for the exact solve (state 2): tests compare them with the oracle's exact F
+int mvs_debug_prescreen_only(mvs_batch *b, const mvs_params *params, int n_active)
+{
+    if (!b || !params || n_active < 1 || n_active > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    launch_prescreen_only(b->d, to_run(*params), n_active, b->ctx->stream);
+    HIP_TRY(b->ctx, hipGetLastError());
+    HIP_TRY(b->ctx, sync_stream(b->ctx));
     return MVS_OK;
 }
 #endif  // MVS_DEBUG_HOOKS
@@ -522,6 +568,10 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.hyp_okf = nullptr;
     d.hyp_cnt = nullptr;
     d.bound = nullptr;
+    d.box = nullptr;
+    d.mode = nullptr;
+    d.xlist = nullptr;
+    d.xcount = nullptr;
     d.hyp_count = nullptr;
     d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;

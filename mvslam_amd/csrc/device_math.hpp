@@ -892,8 +892,9 @@ MVS_DEV bool eight_point_front(const double (&x1)[8], const double (&y1)[8], con
 
 // back half: rank-2 enforcement (:127-136) and de-normalisation (:245) of the null vector f
 // VAR bit 1024 (with 32 and 128): the 3x3 SVD with the unscaled sequences too
+// wout: the singular values of reshape(f) as the 3x3 Jacobi computed them (the pre-screen's gap test reads them)
 template <int VAR = 0>
-MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double (&F)[9], bool &bad)
+MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double (&F)[9], bool &bad, double (&wout)[3])
 {
     double Fn[3][3];
     {
@@ -902,6 +903,7 @@ MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double 
         unsigned r3 = 0, p3 = 0;
         constexpr bool F3 = (VAR & (32 | 128 | 1024)) == (32 | 128 | 1024);
         svd3_full<F3 && (VAR & 16) != 0, F3, F3>(Fp, w, U, Vt, r3, p3, bad);
+        wout[0] = w[0]; wout[1] = w[1]; wout[2] = w[2];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double a = U[i][0] * w[0], b = U[i][1] * w[1];
@@ -926,6 +928,13 @@ MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double 
         F[i * 3 + 1] = G[i][1] * s1;
         F[i * 3 + 2] = (G[i][0] * tx1 + G[i][1] * ty1) + G[i][2];
     }
+}
+
+template <int VAR = 0>
+MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double (&F)[9], bool &bad)
+{
+    double w[3];
+    eight_point_back<VAR>(f, nm, F, bad, w);
 }
 
 // VAR: 16 = in-place rotation; 32 = unscaled sqrt / div sequences (flag + recompute);

@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 
 #include "device_math.hpp"
+#include "prescreen.hpp"
 
 namespace mvs {
 
@@ -349,14 +350,10 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
             const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
             const bool in = r < thr;
             cnt += in ? 1 : 0;
-            if (VAR & 64) {
-                // res += in ? r : 0 as ONE select + ONE fma: the mask is 1.0 or 0.0 (only the high dword differs),
-                // fma(r, 1, res) == res + r and fma(r, 0, res) == res exactly for finite r (F is finite here)
-                const double m = __hiloint2double(in ? 0x3ff00000 : 0, 0);
-                res = dfma(r, m, res);
-            } else {
-                res += in ? r : 0.0;
-            }
+            // (round 1-2 accumulated fma(r, in ? 1.0 : 0.0, res): one select + one fma, exact for FINITE r only -- a
+            // degenerate sample can give an F with NaN entries, NaN * 0 poisons the sum where the reference adds nothing;
+            // found by the adversarial pairs of tests/prescreen_gpu_check.py)
+            res += in ? r : 0.0;   // adding +0.0 is exact: identical to the conditional add
         }
     } else {
         const double4 *P4 = reinterpret_cast<const double4 *>(P);
@@ -431,12 +428,14 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
 // its own kernel it runs at 4 waves/SIMD and the compare / count / mask instructions overlap with other waves' FMAs.
 // Price: F of every hypothesis goes through HBM once (72 B x 50 000 x 512 pairs = 1.8 GB written + read per batch).
 template <int VAR>
-__global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp)
+__global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp, int respect_mode)
 {
     const int pair = blockIdx.y, tid = threadIdx.x;
     const int M = b.M[pair];
     if (M < 8)
         return;
+    if (respect_mode && b.mode[pair] != 0)
+        return;   // this pair's hypotheses are pre-screened (ransac_prescreen_kernel)
     const int H = rp.num_hypotheses;
     const uint32_t h = blockIdx.x * blockDim.x + tid;   // any block size that divides 256 (the launch picks it)
     const uint32_t hh = h < (uint32_t)H ? h : (uint32_t)(H - 1);
@@ -452,11 +451,12 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunPar
         ok = solve_hypothesis<(VAR & ~(32 | 128))>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
     }
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * 9;   // [Hp][9]: 72 contiguous bytes per hypothesis (scalar loads
-#pragma unroll                                            // in ransac_count_kernel); the stores cover whole lines
+    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * kHypRec;   // one contiguous record per hypothesis (scalar loads in
+#pragma unroll                                                  // the counting kernels); the stores cover whole lines
     for (int k = 0; k < 9; ++k)
         Fo[k] = F[k];
-    b.hyp_okf[(size_t)pair * Hp + h] = ok ? 1 : 0;
+    Fo[9] = pair_max_error_sq(b, rp, pair);   // exact F: counted against the threshold itself (band 0)
+    b.hyp_okf[(size_t)pair * Hp + h] = ok ? kPsExact : kPsInvalid;
     if (h == 0)
         b.bound[pair] = 0;   // pruning bound of the scoring launch that follows on the stream
 }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams
     const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
     const bool live = h < (uint32_t)H;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const double *Fi = b.hyp_F + ((size_t)pair * Hp + h) * 9;
+    const double *Fi = b.hyp_F + ((size_t)pair * Hp + h) * kHypRec;
     double F[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -505,8 +505,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams
             const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
             const bool in = r < thr;
             cnt += in ? 1 : 0;
-            const double m = __hiloint2double(in ? 0x3ff00000 : 0, 0);
-            res = dfma(r, m, res);
+            res += in ? r : 0.0;   // NaN-safe (a NaN residual is no inlier and adds nothing, as in the reference)
         }
     }
     if (!ok || !live) {
@@ -628,11 +627,12 @@ __global__ __launch_bounds__(512, 1) void ransac_solve_av_kernel(BatchDev b, Run
         ok = solve_hypothesis<16>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad2);
     }
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * 9;
+    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * kHypRec;
 #pragma unroll
     for (int k = 0; k < 9; ++k)
         Fo[k] = F[k];
-    b.hyp_okf[(size_t)pair * Hp + h] = ok ? 1 : 0;
+    Fo[9] = pair_max_error_sq(b, rp, pair);
+    b.hyp_okf[(size_t)pair * Hp + h] = ok ? kPsExact : kPsInvalid;
     if (g == 0 && tid == 0)
         b.bound[pair] = 0;
 }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
         s_bound = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const double thr = pair_max_error_sq(b, rp, pair);
-    const double *Fp = b.hyp_F + (size_t)pair * Hp * 9;
+    const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
     const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
     int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
     const double2 *L1 = s_p1 + lane, *L2 = s_p2 + lane;
@@ -719,13 +719,13 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
         // same-address vector loads per group, which kept the texture-address unit busier than the VALU.  The records
         // were written by the solve launch; nothing writes them while this kernel runs.
         double F0[9], F1[9], F2[9], F3[9];
-        const CDouble *f = (const CDouble *)(uintptr_t)(Fp + (size_t)h0 * 9);
+        const CDouble *f = (const CDouble *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             F0[k] = f[k];
-            F1[k] = f[9 + k];
-            F2[k] = f[18 + k];
-            F3[k] = f[27 + k];
+            F1[k] = f[kHypRec + k];
+            F2[k] = f[2 * kHypRec + k];
+            F3[k] = f[3 * kHypRec + k];
         }
         // a v_fma_f64 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group,
         // otherwise it is copied there again for every block
@@ -816,6 +816,392 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
         atomicAdd(&b.stats[2], visits * (unsigned long long)BW);   // executed (hypothesis, point) evaluations incl. padding
 }
 
+// ---- sound pre-screen of the hypotheses (prescreen.hpp) -------------------------------------------------
+// pair_prepare   grid P          bounding box of the pair's matches; probe of the first 64 hypotheses: a pair is pre-screened
+//                                only if the certified band is useful at its threshold for most of them (otherwise every
+//                                hypothesis of the pair is solved exactly by ransac_solve_kernel, as before)
+// prescreen      grid (G', P)    approximate F + band per hypothesis -> record; hypotheses without a certificate -> work list
+// exact_list     persistent      exact solve of the listed hypotheses, records overwritten in place (band 0)
+// count2         grid (wg, P)    ransac_count_kernel with one counting threshold per hypothesis: upper bounds prune, lower
+//                                bounds of the hypotheses that finish raise the pair's bound
+// survivors      flat            approximate records whose upper bound reaches the final bound -> work list (-> exact_list)
+// select         grid P          exact count + residual of everything at or above the bound (ransac_select_kernel)
+__device__ __forceinline__ PairBox load_box(const BatchDev &b, int pair)
+{
+    const double *q = b.box + (size_t)pair * 8;
+    PairBox bx;
+    bx.x1lo = q[0]; bx.x1hi = q[1]; bx.y1lo = q[2]; bx.y1hi = q[3];
+    bx.x2lo = q[4]; bx.x2hi = q[5]; bx.y2lo = q[6]; bx.y2hi = q[7];
+    return bx;
+}
+
+// sample + gather + pre-screen of one hypothesis (one lane)
+template <int VAR>
+__device__ __forceinline__ int prescreen_sample(uint64_t seed, uint32_t hyp, int M, int sampler, const double *P,
+                                                const PairBox &bx, double thr, double (&F)[9], double &band, bool &bad3)
+{
+    int idx[8];
+    sample8(seed, hyp, M, sampler, idx);
+    double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
+        x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
+    }
+    return prescreen_hypothesis<VAR>(x1, y1, x2, y2, bx, thr, F, band, bad3);
+}
+
+constexpr int kPsVar = 16 + 32 + 128 + 1024;   // the 3x3 SVD of the pre-screen runs the solve's guarded pair step
+
+__global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams rp, int force_mode)
+{
+    __shared__ double s_red[4][8];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int M = min(b.M[pair], b.max_kp);
+    if (pair == 0 && tid < 2)
+        b.xcount[tid] = 0u;
+    if (tid == 0)
+        b.bound[pair] = 0;
+    if (M < 8) {
+        if (tid == 0)
+            b.mode[pair] = 0;
+        return;
+    }
+    const double4 *P4 = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+    const double big = 0x1p1000;
+    double lo[4] = {big, big, big, big}, hi[4] = {-big, -big, -big, -big};
+    for (int i = tid; i < M; i += 256) {
+        const double4 p = P4[i];
+        const double v[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = fmin(lo[k], v[k]);
+            hi[k] = fmax(hi[k], v[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[k] = fmin(lo[k], __shfl_xor(lo[k], o));
+            hi[k] = fmax(hi[k], __shfl_xor(hi[k], o));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_red[w][2 * k] = lo[k];
+            s_red[w][2 * k + 1] = hi[k];
+        }
+    }
+    __syncthreads();
+    PairBox bx;
+    {
+        double q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double a0 = s_red[0][k], a1 = s_red[1][k], a2 = s_red[2][k], a3 = s_red[3][k];
+            q[k] = (k & 1) ? fmax(fmax(a0, a1), fmax(a2, a3)) : fmin(fmin(a0, a1), fmin(a2, a3));
+        }
+        bx.x1lo = q[0]; bx.x1hi = q[1]; bx.y1lo = q[2]; bx.y1hi = q[3];
+        bx.x2lo = q[4]; bx.x2hi = q[5]; bx.y2lo = q[6]; bx.y2hi = q[7];
+        if (tid < 8)
+            b.box[(size_t)pair * 8 + tid] = q[tid];
+    }
+    // probe: the first 64 hypotheses of the pair through the pre-screen
+    if (w == 0) {
+        const int H = rp.num_hypotheses;
+        const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+        const double thr = pair_max_error_sq(b, rp, pair);
+        const uint32_t hh = (uint32_t)min(lane, H - 1);
+        double F[9], band;
+        bool bad3 = false;
+        int flag = prescreen_sample<kPsVar>(seed, hh, M, rp.sampler, reinterpret_cast<const double *>(P4), bx, thr, F, band, bad3);
+        if (bad3 && flag == kPsApprox)
+            flag = kPsNeedExact;
+        const bool live = lane < H;
+        const int n_ok = __popcll(__ballot(live && flag != kPsInvalid));
+        const int n_scr = __popcll(__ballot(live && flag == kPsApprox));
+        if (lane == 0)
+            b.mode[pair] = force_mode >= 0 ? force_mode : (n_ok > 0 && 4 * n_scr >= 3 * n_ok) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_prescreen_kernel(BatchDev b, RunParams rp)
+{
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int M = b.M[pair];
+    if (M < 8 || b.mode[pair] == 0)
+        return;
+    const int H = rp.num_hypotheses;
+    const uint32_t h = blockIdx.x * 64 + lane;
+    const bool live = h < (uint32_t)H;
+    const uint32_t hh = live ? h : (uint32_t)(H - 1);
+    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+    const PairBox bx = load_box(b, pair);
+    const double thr = pair_max_error_sq(b, rp, pair);
+    double F[9], band;
+    bool bad3 = false;
+    int flag = prescreen_sample<kPsVar>(seed, hh, M, rp.sampler, P, bx, thr, F, band, bad3);
+    if (bad3 && flag == kPsApprox)
+        flag = kPsNeedExact;   // a range guard of the unscaled 3x3 sequences was violated: F~ is not to be trusted
+    if (!live)
+        flag = kPsInvalid;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const size_t rec = (size_t)pair * Hp + h;
+    double *Fo = b.hyp_F + rec * kHypRec;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        Fo[k] = F[k];
+    Fo[9] = flag == kPsApprox ? thr + band : thr;
+    b.hyp_okf[rec] = (uint8_t)flag;
+    // hypotheses without a certificate: append to the work list of the exact solve (one atomic per wavefront)
+    const unsigned long long need = __ballot(flag == kPsNeedExact);
+    if (need) {
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(&b.xcount[0], (unsigned)__popcll(need));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (flag == kPsNeedExact)
+            b.xlist[base + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)rec;
+    }
+}
+
+// exact solve of the hypotheses on the work list (flat indices pair * Hp + h; list `which`).  Persistent grid: wavefront
+// w takes entries [64 w, 64 w + 64), then strides by the grid; the list length is fixed before the launch, so every
+// wavefront reaches its exit.
+template <int VAR>
+__global__ __launch_bounds__(64, 1) void ransac_exact_list_kernel(BatchDev b, RunParams rp, int which)
+{
+    const unsigned n = b.xcount[which];
+    const int lane = threadIdx.x;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    for (unsigned base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+        const bool live = base + lane < n;
+        const uint32_t rec = b.xlist[live ? base + lane : base];
+        const int pair = (int)(rec / Hp);
+        const uint32_t h = (uint32_t)(rec - (size_t)pair * Hp);
+        const int M = b.M[pair];
+        const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+        const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+        double F[9];
+        unsigned rot = 0, pairs = 0;
+        bool bad = false;
+        bool ok = solve_hypothesis<VAR>(seed, h, M, rp.sampler, P, F, rot, pairs, bad);
+        if ((VAR & 32) && __builtin_expect(__any(bad), 0)) {
+            rot = 0;
+            pairs = 0;
+            ok = solve_hypothesis<(VAR & ~(32 | 128))>(seed, h, M, rp.sampler, P, F, rot, pairs, bad);
+        }
+        if (live) {
+            double *Fo = b.hyp_F + (size_t)rec * kHypRec;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                Fo[k] = F[k];
+            Fo[9] = pair_max_error_sq(b, rp, pair);
+            b.hyp_okf[rec] = ok ? kPsExact : kPsInvalid;
+        }
+    }
+}
+
+__device__ __forceinline__ int count_block_thr(const double (&F)[9], const double4 &p, double thr)
+{
+    const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
+    return __popcll(__ballot(r < thr));   // NaN (padding lanes, degenerate F) compares false
+}
+
+// ransac_count_kernel with one counting threshold per hypothesis (record[9] = thr + band).  The running counts are UPPER
+// bounds of the exact counts: a slot dies when even its upper bound can no longer reach the pair's bound.  A slot that
+// survives all blocks is counted once more against thr - band: a LOWER bound of its exact count, and only lower bounds
+// raise the pair's bound.  Exact records have band 0: upper = lower = exact, no second pass -- the kernel then does
+// exactly what ransac_count_kernel does.
+template <int CNT_THREADS, int PPL, bool STATS = false>
+__global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, RunParams rp, int wg_per_pair)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
+    __shared__ int s_bound;
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8)
+        return;
+    const int H = rp.num_hypotheses;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    constexpr int BW = 64 * PPL;                  // points per block
+    const int nblk = (M + BW - 1) / BW;
+    double2 *s_p1 = reinterpret_cast<double2 *>(s_cpts);
+    double2 *s_p2 = s_p1 + nblk * BW;
+    {
+        const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+        const double qnan = __builtin_nan("");
+        for (int i = tid; i < nblk * BW; i += CNT_THREADS) {
+            const double4 p = i < M ? src[i] : make_double4(qnan, qnan, qnan, qnan);
+            s_p1[i] = make_double2(p.x, p.y);
+            s_p2[i] = make_double2(p.z, p.w);
+        }
+    }
+    int *gbound = b.bound + pair;
+    if (tid == 0)
+        s_bound = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double thr = pair_max_error_sq(b, rp, pair);
+    const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
+    const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
+    int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
+    const double2 *L1 = s_p1 + lane, *L2 = s_p2 + lane;
+    const int n_groups = (H + kCntSlots - 1) / kCntSlots;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = wg_per_pair * (CNT_THREADS / 64);
+    int B = 0;
+    unsigned long long visits = 0;   // STATS: (hypothesis, block) evaluations this wavefront executed
+    for (int g = blockIdx.x * (CNT_THREADS / 64) + wave; g < n_groups; g += n_waves) {
+        const int h0 = g * kCntSlots;
+        const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
+        double F0[9], F1[9], F2[9], F3[9];
+        const CDouble *f = (const CDouble *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            F0[k] = f[k];
+            F1[k] = f[kHypRec + k];
+            F2[k] = f[2 * kHypRec + k];
+            F3[k] = f[3 * kHypRec + k];
+        }
+        const double t0 = f[9], t1 = f[kHypRec + 9], t2 = f[2 * kHypRec + 9], t3 = f[3 * kHypRec + 9];
+#pragma unroll
+        for (int k = 6; k < 9; ++k) {
+            asm volatile("" : "+v"(F0[k]));
+            asm volatile("" : "+v"(F1[k]));
+            asm volatile("" : "+v"(F2[k]));
+            asm volatile("" : "+v"(F3[k]));
+        }
+        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
+        unsigned alive = 0;
+#pragma unroll
+        for (int k = 0; k < kCntSlots; ++k)
+            alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        double2 pa0[PPL], pb0[PPL], pa1[PPL], pb1[PPL];
+        auto load = [&](double2 (&pa)[PPL], double2 (&pb)[PPL], int blk) {
+            const int nb = min(blk, nblk - 1) * BW;
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) {
+                pa[u] = L1[nb + u * 64];
+                pb[u] = L2[nb + u * 64];
+            }
+        };
+        auto process = [&](const double2 (&pa)[PPL], const double2 (&pb)[PPL], int blk) {
+            double4 p[PPL];
+#pragma unroll
+            for (int u = 0; u < PPL; ++u)
+                p[u] = make_double4(pa[u].x, pa[u].y, pb[u].x, pb[u].y);
+            const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
+            if (STATS)
+                visits += (unsigned)__builtin_popcount(alive);
+            if (alive & 1u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c0 += count_block_thr(F0, p[u], t0);
+                if (c0 < need) alive &= ~1u;
+            }
+            if (alive & 2u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c1 += count_block_thr(F1, p[u], t1);
+                if (c1 < need) alive &= ~2u;
+            }
+            if (alive & 4u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c2 += count_block_thr(F2, p[u], t2);
+                if (c2 < need) alive &= ~4u;
+            }
+            if (alive & 8u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c3 += count_block_thr(F3, p[u], t3);
+                if (c3 < need) alive &= ~8u;
+            }
+        };
+        load(pa0, pb0, 0);
+        for (int blk = 0; blk < nblk && alive; blk += 2) {
+            load(pa1, pb1, blk + 1);
+            process(pa0, pb0, blk);
+            if (!(blk + 1 < nblk && alive))
+                break;
+            load(pa0, pb0, blk + 2);
+            process(pa1, pb1, blk + 1);
+        }
+        // a slot that is still alive has seen every point: its upper-bound count is final.  Its lower bound: the same
+        // count for an exact record (threshold == thr), one more pass against thr - band for an approximate one.
+        auto lower = [&](const double (&F)[9], double tu, int cu) -> int {
+            if (tu == thr)
+                return cu;
+            // thr - band, rounded down: band' = tu - thr is at most one rounding below the certified band
+            const double tl = thr - (tu - thr) * (1.0 + 1e-9) - 1e-15 * thr;
+            int cl = 0;
+            for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) {
+                    const double2 a = L1[blk * BW + u * 64], c = L2[blk * BW + u * 64];
+                    cl += count_block_thr(F, make_double4(a.x, a.y, c.x, c.y), tl);
+                }
+            }
+            if (STATS)
+                visits += (unsigned)nblk;
+            return cl;
+        };
+        const int v0 = (alive & 1u) ? c0 : -1, v1 = (alive & 2u) ? c1 : -1;
+        const int v2 = (alive & 4u) ? c2 : -1, v3 = (alive & 8u) ? c3 : -1;
+        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
+        if (alive & 1u) l0 = lower(F0, t0, c0);
+        if (alive & 2u) l1 = lower(F1, t1, c1);
+        if (alive & 4u) l2 = lower(F2, t2, c2);
+        if (alive & 8u) l3 = lower(F3, t3, c3);
+        if (lane < kCntSlots)
+            cntp[h0 + lane] = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
+        const int cm = __builtin_amdgcn_readfirstlane(max(max(l0, l1), max(l2, l3)));
+        if (cm > B) {
+            B = cm;
+            if (lane == 0) {
+                atomicMax(&s_bound, cm);
+                __hip_atomic_fetch_max(gbound, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        B = max(B, __builtin_amdgcn_readfirstlane(gb));
+    }
+    if (STATS && lane == 0 && b.stats)
+        atomicAdd(&b.stats[2], visits * (unsigned long long)BW);
+}
+
+// approximate records whose upper-bound count reaches the pair's final bound: they may be the winner, so they get their
+// exact F (work list 1 -> ransac_exact_list_kernel) before ransac_select_kernel scores everything at or above the bound
+__global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunParams rp, int n_active)
+{
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const size_t total = (size_t)n_active * Hp;
+    const int lane = threadIdx.x & 63;
+    for (size_t base0 = (size_t)blockIdx.x * 256; base0 < total; base0 += (size_t)gridDim.x * 256) {
+        const size_t rec = base0 + threadIdx.x;
+        bool take = false;
+        if (rec < total) {
+            const int pair = (int)(rec / Hp);
+            const uint32_t h = (uint32_t)(rec - (size_t)pair * Hp);
+            take = h < (uint32_t)rp.num_hypotheses && b.M[pair] >= 8 && b.hyp_okf[rec] == kPsApprox &&
+                   b.hyp_cnt[rec] >= b.bound[pair];
+        }
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            unsigned base = 0;
+            if (lane == 0)
+                base = atomicAdd(&b.xcount[1], (unsigned)__popcll(m));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (take)
+                b.xlist[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)rec;
+        }
+    }
+}
+
 // grid P, 256 threads.  bound[pair] is now the largest full count (every surviving hypothesis went through the
 // atomicMax); hypotheses at that count are collected in index order and scored once more, one per lane over the LDS
 // point stream with the fused kernel's exact operations (count AND residual sum in index order), and the best by
@@ -863,7 +1249,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
     __syncthreads();
     const int cmax = b.bound[pair];
     const int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
-    const double *Fp = b.hyp_F + (size_t)pair * Hp * 9;
+    const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
     const double thr = pair_max_error_sq(b, rp, pair);
     const double4 *L4 = reinterpret_cast<const double4 *>(s_spts);
     double *s_r = s_spts;
@@ -874,7 +1260,9 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
         int n_list = 0;
         while (scan < H && n_list <= kSelList - kSelThreads) {
             const int h = scan + tid;
-            const bool flag = h < H && cntp[h] == cmax;
+            // every hypothesis whose (upper-bound) count reaches the pair's bound; with exact counts these are the ties at
+            // the maximum, with pre-screened ones the survivors -- all of them carry their exact F by now
+            const bool flag = h < H && cntp[h] >= cmax;
             const unsigned long long bal = __ballot(flag);
             if (lane == 0)
                 s_tot[w] = __popcll(bal);
@@ -901,7 +1289,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
             for (int q = 0; q < n_list; ++q) {
                 const uint32_t h = s_list[q];
                 if (tid < 9)
-                    s_F[tid] = Fp[(size_t)h * 9 + tid];
+                    s_F[tid] = Fp[(size_t)h * kHypRec + tid];
                 __syncthreads();
                 double F[9];
 #pragma unroll
@@ -970,7 +1358,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
             Cand me{-2, h, 0.0};
             double F[9];
             if (have) {
-                const double *f = Fp + (size_t)h * 9;
+                const double *f = Fp + (size_t)h * kHypRec;
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
                     F[k] = f[k];
@@ -982,8 +1370,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
                     const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
                     const bool in = r < thr;
                     cnt += in ? 1 : 0;
-                    const double m = __hiloint2double(in ? 0x3ff00000 : 0, 0);
-                    res = dfma(r, m, res);
+                    res += in ? r : 0.0;   // NaN-safe (a NaN residual is no inlier and adds nothing, as in the reference)
                 }
                 me.cnt = cnt;
                 me.res = res;
@@ -1551,6 +1938,32 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.threads = kSelThreads;
         d.dynamic_lds = (size_t)max_kp * 4 * sizeof(double);
         break;
+    case kKPairPrepare:
+        d.name = "pair_prepare_kernel";
+        d.fn = reinterpret_cast<const void *>(pair_prepare_kernel);
+        d.threads = 256;
+        break;
+    case kKRansacPrescreen:
+        d.name = "ransac_prescreen_kernel";
+        d.fn = reinterpret_cast<const void *>(ransac_prescreen_kernel);
+        d.threads = 64;
+        break;
+    case kKRansacExactList:
+        d.name = "ransac_exact_list_kernel<1264>";
+        d.fn = reinterpret_cast<const void *>(ransac_exact_list_kernel<240 + 1024>);
+        d.threads = 64;
+        break;
+    case kKRansacCount2:
+        d.name = "ransac_count2_kernel<768, 2>";
+        d.fn = reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>);
+        d.threads = kCntThreads;
+        d.dynamic_lds = count_lds_bytes(max_kp);
+        break;
+    case kKRansacSurvivors:
+        d.name = "ransac_survivors_kernel";
+        d.fn = reinterpret_cast<const void *>(ransac_survivors_kernel);
+        d.threads = 256;
+        break;
     case kKFinModel:
         d.name = "finalize_model_kernel";
         d.fn = reinterpret_cast<const void *>(finalize_model_kernel);
@@ -1579,6 +1992,8 @@ hipError_t prepare_kernels()
 {
     const void *fns[] = {reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>),
                          reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl, true>),
+                         reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>),
+                         reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
@@ -1612,10 +2027,13 @@ void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2,
     hipLaunchKernelGGL(prep_points_kernel, dim3((b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b, uv1, uv2);
 }
 
+// 9000 (default, round 3) = the pre-screened stage: pair_prepare -> prescreen (+ the exact solve for pairs the probe sends
+// there) -> exact solve of the hypotheses without a certificate -> count with per-hypothesis thresholds -> survivors ->
+// their exact solve -> select.
 // 120 fused; 632 = solve + hypothesis-per-lane scoring as two launches (round 1); 1784 = solve (with the sqrt-free
 // convergence test, bit 128 of the kernel's VAR, for the 9x9 and -- kernel bit 1024 -- the 3x3 SVD) + pruned
 // point-per-lane scoring (bit 1024 of the launch variant): ransac_count + ransac_select
-static int g_ransac_variant = 1784;
+static int g_ransac_variant = 9000;
 void set_ransac_variant(int v) { g_ransac_variant = v; }
 int get_ransac_variant() { return g_ransac_variant; }
 
@@ -1652,6 +2070,55 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
+static int g_force_mode = -1;   // diagnostics: -1 = the probe decides, 0 / 1 = every pair exact / pre-screened
+void set_prescreen_force(int m) { g_force_mode = m; }
+
+void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, 1);
+    hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((rp.num_hypotheses + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
+}
+
+// the pre-screened RANSAC stage (variant 9000)
+static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt,
+                               bool stats)
+{
+    const int H = rp.num_hypotheses;
+    const int G = (H + kHypPerBlock - 1) / kHypPerBlock;
+    if (lt) lt->mark(kKPairPrepare);
+    hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, g_force_mode);
+    if (lt) lt->mark(kKRansacPrescreen);
+    hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((H + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
+    // pairs the probe did not certify: every hypothesis through the exact solve (its workgroups leave at once for the others)
+    if (lt) lt->mark(kKRansacSolve);
+    hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active), dim3(kSolveBlock),
+                       0, stream, b, rp, 1);
+    if (lt) lt->mark(kKRansacExactList);
+    hipLaunchKernelGGL((ransac_exact_list_kernel<240 + 1024>), dim3(1024), dim3(64), 0, stream, b, rp, 0);
+    const int n_groups4 = (H + kCntSlots - 1) / kCntSlots;
+    const int wpw = kCntThreads / 64;
+    int wg = (512 + n_active - 1) / n_active;
+    wg = std::max(wg, 4);
+    wg = std::min(wg, std::max(1, (n_groups4 + wpw - 1) / wpw));
+    const size_t lds_cnt = count_lds_bytes(b.max_kp);
+    if (lt) lt->mark(kKRansacCount2);
+    if (stats)
+        hipLaunchKernelGGL((ransac_count2_kernel<kCntThreads, kCntPpl, true>), dim3(wg, n_active), dim3(kCntThreads), lds_cnt,
+                           stream, b, rp, wg);
+    else
+        hipLaunchKernelGGL((ransac_count2_kernel<kCntThreads, kCntPpl>), dim3(wg, n_active), dim3(kCntThreads), lds_cnt, stream,
+                           b, rp, wg);
+    const size_t total = (size_t)n_active * b.max_groups * kHypPerBlock;
+    const int sg = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (lt) lt->mark(kKRansacSurvivors);
+    hipLaunchKernelGGL(ransac_survivors_kernel, dim3(sg), dim3(256), 0, stream, b, rp, n_active);
+    if (lt) lt->mark(kKRansacExactList);
+    hipLaunchKernelGGL((ransac_exact_list_kernel<240 + 1024>), dim3(1024), dim3(64), 0, stream, b, rp, 1);
+    if (lt) lt->mark(kKRansacSelect);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), (size_t)b.max_kp * 4 * sizeof(double), stream,
+                       b, rp);
+}
+
 void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream, LaunchTimer *lt)
 {
     const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
@@ -1660,13 +2127,26 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     // hypothesis-per-lane kernels; so does a launch of one or two pairs (latency: fewer launches)
     const bool split_ok = !stats && b.hyp_F && n_active >= kSplitMinPairs;
     switch (g_ransac_variant) {
+    case 9000:
+        if (!split_ok || b.hyp_count) {
+            // one or two pairs, per-hypothesis tables, the instrumented replay's rotation counters: hypothesis-per-lane kernels
+            if (!stats)
+                launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
+            else
+                launch_ransac_var<120>(b, rp, grid, block, true, stream, lt);
+            if (stats && b.hyp_F && !b.hyp_count && n_active >= kSplitMinPairs)
+                launch_prescreened(b, rp, n_active, stream, nullptr, true);   // + the product path's own counters
+        } else {
+            launch_prescreened(b, rp, n_active, stream, lt, false);
+        }
+        break;
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream, lt); break;
     case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream, lt); break;   // timing experiment: no V rotations
     case 632:
         if (!split_ok) {
             launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
         } else {
-            hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
+            hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp, 0);
             hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
         }
         break;
@@ -1674,7 +2154,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
         if (!split_ok) {
             launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
         } else {
-            hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp);
+            hipLaunchKernelGGL((ransac_solve_kernel<240>), grid, block, 0, stream, b, rp, 0);
             hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);
         }
         break;
@@ -1699,16 +2179,16 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
                 // the instrumented replay also runs the product path once with the counting kernel's evaluation counter
                 // (stats[2]): the roofline quotes EXECUTED evaluations for the pruned kernel, not the H x M it avoids
                 hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active),
-                                   dim3(kSolveBlock), 0, stream, b, rp);
+                                   dim3(kSolveBlock), 0, stream, b, rp, 0);
                 launch_pruned_scoring(b, rp, n_active, stream, nullptr, true);
             }
         } else {
             if (lt) lt->mark(kKRansacSolve);
             if (g_ransac_variant == 1784)
                 hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active),
-                                   dim3(kSolveBlock), 0, stream, b, rp);
+                                   dim3(kSolveBlock), 0, stream, b, rp, 0);
             else
-                hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp);
+                hipLaunchKernelGGL((ransac_solve_kernel<112>), grid, block, 0, stream, b, rp, 0);
             if (b.hyp_count) {
                 if (lt) lt->mark(kKRansacScore);
                 hipLaunchKernelGGL(ransac_score_kernel, grid, block, 0, stream, b, rp);

@@ -10,6 +10,7 @@ namespace mvs {
 constexpr int kMaxKp = 4096;          // capacity limit of one image (LDS lists in finalize/compact)
 constexpr int kHypPerBlock = 256;     // hypotheses per RANSAC workgroup (one per lane, 4 waves)
 constexpr int kMaxDescWords = 16;     // descriptor <= 64 bytes
+constexpr int kHypRec = 10;           // doubles per hypothesis record: F[9], counting threshold (thr + band)
 
 // Best hypothesis of one RANSAC workgroup.  count < 0: no valid hypothesis in the group.
 struct WgBest {
@@ -58,10 +59,16 @@ struct BatchDev {
     mvs_match *matches;  // [P][N]
     double *pts;         // [P][N][4]  (x1, y1, x2, y2) ideal-camera coordinates of match m
     WgBest *wgbest;      // [P][max_groups]
-    double *hyp_F;       // [P][max_groups * 256][9] F of every hypothesis (solve -> scoring hand-over), may be null
-    uint8_t *hyp_okf;    // [P][max_groups * 256] solve succeeded
-    int32_t *hyp_cnt;    // [P][max_groups * 256] full inlier count of a hypothesis that can still win, -1 otherwise
-    int32_t *bound;      // [P] largest full count seen so far (the pruning bound of ransac_count_kernel)
+    double *hyp_F;       // [P][max_groups * 256][kHypRec]: F (9) of every hypothesis + its counting threshold thr + band
+                         // (solve / pre-screen -> scoring hand-over), may be null
+    uint8_t *hyp_okf;    // [P][max_groups * 256] state of the record: 0 rejected sample, 1 approximate F (pre-screen), 2 waits
+                         // for the exact solve, 3 exact F
+    int32_t *hyp_cnt;    // [P][max_groups * 256] full (upper-bound) inlier count of a hypothesis that can still win, -1 otherwise
+    int32_t *bound;      // [P] largest full (lower-bound) count seen so far: the pruning bound of the counting kernel
+    double *box;         // [P][8] bounding box of the pair's matches (x1lo, x1hi, y1lo, y1hi, x2lo, x2hi, y2lo, y2hi)
+    int32_t *mode;       // [P] 1: the pair's hypotheses are pre-screened, 0: every hypothesis is solved exactly
+    uint32_t *xlist;     // [P * max_groups * 256] work list of the list-driven exact solve: flat indices pair * Hp + h
+    uint32_t *xcount;    // [2] entries of the list: {flagged by the pre-screen, survivors of the count}
     double *cand_pts;    // [P][4][N][3] triangulation scratch
     FinModel *fin;       // [P]
     uint16_t *inl;       // [P][N] ordered inlier list
@@ -259,6 +266,11 @@ enum KernelId : int {
     kKRansacScore,     // hypothesis-per-lane scoring of stored F records (per-hypothesis tables)
     kKRansacCount,
     kKRansacSelect,
+    kKPairPrepare,     // bounding box of the pair's matches + probe: is this pair pre-screened?
+    kKRansacPrescreen, // approximate F + certified band per hypothesis
+    kKRansacExactList, // exact solve of the listed hypotheses (flagged by the pre-screen / survivors of the count)
+    kKRansacCount2,    // pruned counting with per-hypothesis thresholds (upper / lower bounds of the exact count)
+    kKRansacSurvivors, // hypotheses whose upper bound reaches the pair's best lower bound -> work list
     kKFinModel,
     kKTriangulate,
     kKFinSelect,
@@ -297,6 +309,9 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
 void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream, LaunchTimer *lt = nullptr);
 // opt-in to > 64 KB of dynamic LDS for the kernels that need it, once per device; hipSuccess or the first error
 hipError_t prepare_kernels();
+// diagnostics: pair_prepare + ransac_prescreen only, every pair forced into the pre-screened mode
+void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
+void set_prescreen_force(int m);   // diagnostics: -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened
 void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)
 int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""GPU check of the RANSAC pre-screen against the oracle, hypothesis by hypothesis (run by tests/test_prescreen.py in its
+own process with MVS_USE_DEBUG_LIB=1: the record reader and the mode switch exist in the diagnostics library only).
+
+For every pair of a small batch (random synthetic pairs + adversarial ones: collinear keypoints, a coarse grid with
+duplicates, a tight cluster with far outliers, identical views) and every hypothesis:
+  * the state byte is 0 exactly when the oracle rejects the sample;
+  * a certified record (state 1) satisfies  | r_i(F_J) - r_i(F~) | <= band  for every match i, with F_J the oracle's
+    find_fundamental_matrix of the same sample, and hence  U >= count_J >= L;
+then the whole stage is run with every pair forced exact, forced pre-screened, and with the probe deciding: the result
+records, masks and points must be byte-identical, and equal to the oracle's image_pair.
+Prints one JSON line with the statistics; exit code 0 = all checks passed."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["MVS_USE_DEBUG_LIB"] = "1"
+import oracle_lib as o  # noqa: E402
+import prescreen_model as pm  # noqa: E402
+from mvslam_amd import capi, synth  # noqa: E402
+
+
+def adversarial(data, rng):
+    """overwrite the keypoints of pairs 2.. with degenerate layouts (descriptors keep matching by construction)"""
+    n = data["kp1"].shape[1]
+    # pair 2: every keypoint on one line (all samples degenerate for the 8-point algorithm)
+    t = rng.uniform(0, 1, n)
+    data["kp1"][2] = np.stack([40 + 500 * t, 100 + 300 * t], 1)
+    # pair 3: a coarse 12 x 9 grid -> exact duplicates and collinear subsets in most samples
+    gx, gy = rng.integers(0, 12, n), rng.integers(0, 9, n)
+    data["kp1"][3] = np.stack([30 + 50.0 * gx, 30 + 50.0 * gy], 1)
+    # pair 4: a tight cluster (3 px) plus a few far points
+    c = 300 + rng.normal(scale=1.0, size=(n, 2))
+    far = rng.random(n) < 0.02
+    c[far] = rng.uniform(0, 480, size=(int(far.sum()), 2))
+    data["kp1"][4] = c
+    # pair 5: identical views (rank-deficient beyond the 8-point null space; F arbitrary)
+    return data
+
+
+def main():
+    P, N, H = 8, 600, 1536
+    thr_list = [1e-2, 1e-4]
+    rng = np.random.default_rng(11)
+    data = synth.make_batch(0, P, n_kp=N)
+    data = adversarial(data, rng)
+    # image 2 of the adversarial pairs = image 1 moved by the synthetic pair's own geometry is not needed: any keypoints do
+    data["kp2"][5] = data["kp1"][5].copy()
+    data["desc2"][5] = data["desc1"][5].copy()
+    ctx = capi.Context(0)
+    lib = capi.lib()
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
+    stats = dict(hyp=0, invalid=0, certified=0, need_exact=0, worst_ratio=0.0, viol=0, count_viol=0)
+    for thr in thr_list:
+        prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=thr)
+        b.run(prm)
+        b.sync()
+        base = b.download()
+        st = lib.mvs_debug_prescreen_only(b._h, C.byref(prm), C.c_int(P))
+        assert st == 0, st
+        for p in range(P):
+            M = int(base["results"][p]["n_matches"])
+            if M < 8:
+                continue
+            mt = base["matches"][p][:M]
+            K = data["K"][p].reshape(3, 3)
+            p1 = o.normalize_points(K, data["kp1"][p][mt["trainIdx"]].astype(np.float64))
+            p2 = o.normalize_points(K, data["kp2"][p][mt["queryIdx"]].astype(np.float64))
+            rec = np.zeros((H, 10))
+            state = np.zeros(H, dtype=np.uint8)
+            info = (C.c_int32 * 4)()
+            st = lib.mvs_debug_read_hyp_rec(b._h, C.c_int(p), C.c_int(H), rec.ctypes.data_as(C.POINTER(C.c_double)),
+                                            state.ctypes.data_as(C.POINTER(C.c_ubyte)), None, info)
+            assert st == 0 and info[0] == 1
+            seed = synth.SEED_BASE + int(data["global_index"][p])
+            for h in range(H):
+                idx = o.sample8(seed, h, M)
+                ok, FJ = o.find_fundamental_matrix(p1[idx], p2[idx])
+                stats["hyp"] += 1
+                assert (state[h] == 0) == (not ok), (p, h, state[h], ok)
+                if state[h] == 0:
+                    stats["invalid"] += 1
+                    continue
+                if state[h] == 2:
+                    stats["need_exact"] += 1
+                    continue
+                assert state[h] == 1
+                stats["certified"] += 1
+                band = rec[h, 9] - thr
+                assert 0 < band <= 0.125 * thr * (1 + 1e-12) + 1e-300, (p, h, band)
+                rj = pm.residuals(FJ, p1, p2)
+                ra = pm.residuals(rec[h, :9].reshape(3, 3), p1, p2)
+                d = float(np.abs(rj - ra).max())
+                stats["worst_ratio"] = max(stats["worst_ratio"], d / band)
+                if d > band:
+                    stats["viol"] += 1
+                cj = int((rj < thr).sum())
+                cu, cl = int((ra < thr + band).sum()), int((ra < thr - band).sum())
+                if not (cu >= cj >= cl):
+                    stats["count_viol"] += 1
+        # the whole stage: every pair exact / every pair pre-screened / the probe decides
+        outs = []
+        for mode in (0, 1, -1):
+            lib.mvs_debug_set_prescreen_force(C.c_int(mode))
+            b.run(prm)
+            b.sync()
+            outs.append(b.download())
+            info = (C.c_int32 * 4)()
+            lib.mvs_debug_read_hyp_rec(b._h, C.c_int(0), C.c_int(1), None, None, None, info)
+            stats["mode%d_list" % mode if mode >= 0 else "auto_list"] = [int(info[2]), int(info[3])]
+        lib.mvs_debug_set_prescreen_force(C.c_int(-1))
+        for k in ("results", "mask", "points", "point_idx", "matches"):
+            assert outs[0][k].tobytes() == outs[1][k].tobytes() == outs[2][k].tobytes(), ("modes differ", thr, k)
+        for p in range(P):
+            ref = o.image_pair(data["desc1"][p], data["kp1"][p], data["desc2"][p], data["kp2"][p], data["K"][p].reshape(3, 3),
+                               o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(data["global_index"][p]), thr), 0.7, 10.0)
+            r = outs[1]["results"][p]
+            M = ref["n_matches"]
+            assert r["n_matches"] == M and bool(r["valid"]) == bool(ref["ok"]), (p, thr)
+            assert r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"], (p, thr, r["best_hyp"], ref["best_hyp"])
+            assert r["best_residual"] == ref["best_residual"], (p, thr, float(r["best_residual"]), ref["best_residual"],
+                                                                int(r["best_hyp"]), int(r["best_count"]))
+            assert np.array_equal(outs[1]["mask"][p][:M], ref["mask"])
+    b.close()
+    ctx.close()
+    print(json.dumps(stats))
+    assert stats["viol"] == 0 and stats["count_viol"] == 0
+    assert stats["certified"] > 0.5 * stats["hyp"]
+
+
+if __name__ == "__main__":
+    main()
