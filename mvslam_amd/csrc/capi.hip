@@ -363,16 +363,17 @@ int mvs_debug_read_hyp_rec(mvs_batch *b, int pair, int n_hyp, double *rec_out, u
 }
 
 // the pre-screen alone over pairs [0, n_active) of a batch that has been run (matches and points resident): pair_prepare +
-// ransac_prescreen, every pair forced into the pre-screened mode, nothing solved exactly afterwards -- the records then
-// hold F~ and thr + band (state 1), or wait for the exact solve (state 2): tests compare them with the oracle's exact F
-int mvs_debug_prescreen_only(mvs_batch *b, const mvs_params *params, int n_active)
+// ransac_prescreen, every pair forced into pre-screened mode `mode` (1: single-precision records, 2: double precision),
+// nothing solved exactly afterwards -- the records then hold F~ and the widened thresholds (state 1), or wait for the exact
+// solve (state 2): tests compare them with the oracle's exact F
+int mvs_debug_prescreen_only(mvs_batch *b, const mvs_params *params, int n_active, int mode)
 {
-    if (!b || !params || n_active < 1 || n_active > b->d.n_pairs)
+    if (!b || !params || n_active < 1 || n_active > b->d.n_pairs || (mode != 1 && mode != 2))
         return MVS_ERR_INVALID_ARG;
     mvs_status st = ensure_groups(b, params->num_hypotheses);
     if (st != MVS_OK)
         return st;
-    launch_prescreen_only(b->d, to_run(*params), n_active, b->ctx->stream);
+    launch_prescreen_only(b->d, to_run(*params), n_active, mode, b->ctx->stream);
     HIP_TRY(b->ctx, hipGetLastError());
     HIP_TRY(b->ctx, sync_stream(b->ctx));
     return MVS_OK;

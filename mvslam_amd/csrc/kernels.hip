@@ -837,18 +837,13 @@ __device__ __forceinline__ PairBox load_box(const BatchDev &b, int pair)
 
 // sample + gather + pre-screen of one hypothesis (one lane)
 template <int VAR>
-__device__ __forceinline__ int prescreen_sample(uint64_t seed, uint32_t hyp, int M, int sampler, const double *P,
-                                                const PairBox &bx, double thr, double (&F)[9], double &band, bool &bad3)
+__device__ __forceinline__ int prescreen_sample(uint64_t seed, uint32_t hyp, int M, int sampler, const double *P, double *park,
+                                                const PairBox &bx, double thr, double (&F)[9], double &band, double &e32,
+                                                bool &bad3)
 {
     int idx[8];
     sample8(seed, hyp, M, sampler, idx);
-    double x1[8], y1[8], x2[8], y2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
-        x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
-    }
-    return prescreen_hypothesis<VAR>(x1, y1, x2, y2, bx, thr, F, band, bad3);
+    return prescreen_hypothesis<VAR>(P, idx, park, bx, thr, F, band, e32, bad3);
 }
 
 constexpr int kPsVar = 16 + 32 + 128 + 1024;   // the 3x3 SVD of the pre-screen runs the solve's guarded pair step
@@ -856,6 +851,7 @@ constexpr int kPsVar = 16 + 32 + 128 + 1024;   // the 3x3 SVD of the pre-screen 
 __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams rp, int force_mode)
 {
     __shared__ double s_red[4][8];
+    __shared__ double s_park[kPsParked * 64];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int M = min(b.M[pair], b.max_kp);
     if (pair == 0 && tid < 2)
@@ -914,21 +910,27 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
         const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
         const double thr = pair_max_error_sq(b, rp, pair);
         const uint32_t hh = (uint32_t)min(lane, H - 1);
-        double F[9], band;
+        double F[9], band, e32;
         bool bad3 = false;
-        int flag = prescreen_sample<kPsVar>(seed, hh, M, rp.sampler, reinterpret_cast<const double *>(P4), bx, thr, F, band, bad3);
+        int flag = prescreen_sample<kPsVar>(seed, hh, M, rp.sampler, reinterpret_cast<const double *>(P4), s_park + lane, bx, thr,
+                                            F, band, e32, bad3);
         if (bad3 && flag == kPsApprox)
             flag = kPsNeedExact;
         const bool live = lane < H;
         const int n_ok = __popcll(__ballot(live && flag != kPsInvalid));
-        const int n_scr = __popcll(__ballot(live && flag == kPsApprox));
+        const int n_s64 = __popcll(__ballot(live && flag == kPsApprox && band <= kPsBandFrac * thr));
+        const int n_s32 = __popcll(__ballot(live && flag == kPsApprox && band + e32 <= kPsBandFrac * thr));
+        // 1: pre-screened, counted in single precision; 2: pre-screened, counted in double precision (the band is useful
+        // at this threshold but single-precision evaluation is too coarse for it); 0: every hypothesis solved exactly
+        const int mode = n_ok == 0 ? 0 : 4 * n_s32 >= 3 * n_ok ? 1 : 4 * n_s64 >= 3 * n_ok ? 2 : 0;
         if (lane == 0)
-            b.mode[pair] = force_mode >= 0 ? force_mode : (n_ok > 0 && 4 * n_scr >= 3 * n_ok) ? 1 : 0;
+            b.mode[pair] = force_mode >= 0 ? force_mode : mode;
     }
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_prescreen_kernel(BatchDev b, RunParams rp)
 {
+    __shared__ double s_park[kPsParked * 64];   // this wavefront's parked R entries: [entry][lane]
     const int pair = blockIdx.y, lane = threadIdx.x;
     const int M = b.M[pair];
     if (M < 8 || b.mode[pair] == 0)
@@ -941,20 +943,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double *P = b.pts + (size_t)pair * b.max_kp * 4;
     const PairBox bx = load_box(b, pair);
     const double thr = pair_max_error_sq(b, rp, pair);
-    double F[9], band;
+    double F[9], band, e32;
     bool bad3 = false;
-    int flag = prescreen_sample<kPsVar>(seed, hh, M, rp.sampler, P, bx, thr, F, band, bad3);
-    if (bad3 && flag == kPsApprox)
-        flag = kPsNeedExact;   // a range guard of the unscaled 3x3 sequences was violated: F~ is not to be trusted
+    int flag = prescreen_sample<kPsVar>(seed, hh, M, rp.sampler, P, s_park + lane, bx, thr, F, band, e32, bad3);
+    const int mode = b.mode[pair];
+    const double btot = mode == 1 ? band + e32 : band;   // what the counting kernel of this pair has to allow for
+    if (flag == kPsApprox && (bad3 || !(btot <= kPsBandFrac * thr)))
+        flag = kPsNeedExact;   // band too wide for the threshold, or a range guard of the unscaled 3x3 sequences was violated
     if (!live)
         flag = kPsInvalid;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     const size_t rec = (size_t)pair * Hp + h;
     double *Fo = b.hyp_F + rec * kHypRec;
+    if (mode == 1) {
+        // single-precision record: F~ (9 floats), upper and lower counting thresholds rounded outwards
+        float *fo = reinterpret_cast<float *>(Fo);
+        float q[12];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-        Fo[k] = F[k];
-    Fo[9] = flag == kPsApprox ? thr + band : thr;
+        for (int k = 0; k < 9; ++k)
+            q[k] = (float)F[k];
+        q[9] = (float)((thr + btot) * (1.0 + 0x1p-22));
+        q[10] = (float)((thr - btot) * (1.0 - 0x1p-22));
+        q[11] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; k += 4)
+            *reinterpret_cast<float4 *>(fo + k) = make_float4(q[k], q[k + 1], q[k + 2], q[k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            Fo[k] = F[k];
+        Fo[9] = flag == kPsApprox ? thr + band : thr;
+    }
     b.hyp_okf[rec] = (uint8_t)flag;
     // hypotheses without a certificate: append to the work list of the exact solve (one atomic per wavefront)
     const unsigned long long need = __ballot(flag == kPsNeedExact);
@@ -1023,8 +1042,8 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, 
     __shared__ int s_bound;
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int M = min(b.M[pair], b.max_kp);
-    if (M < 8)
-        return;
+    if (M < 8 || b.mode[pair] == 1)
+        return;   // mode 1: this pair's records are single precision (ransac_count32_kernel)
     const int H = rp.num_hypotheses;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     constexpr int BW = 64 * PPL;                  // points per block
@@ -1076,10 +1095,15 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, 
             asm volatile("" : "+v"(F3[k]));
         }
         const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
-        unsigned alive = 0;
+        // state bytes of the four records: 1 (approximate) and 3 (exact) are counted; 2 waits for the exact solve that
+        // follows the counting and goes straight to the selection (count "infinite"); 0 is a rejected sample
+        unsigned alive = 0, wait = 0;
 #pragma unroll
-        for (int k = 0; k < kCntSlots; ++k)
-            alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
+        for (int k = 0; k < kCntSlots; ++k) {
+            const unsigned st = (ok4 >> (8 * k)) & 0xffu;
+            alive |= ((st == kPsApprox || st == kPsExact) && h0 + k < H) ? (1u << k) : 0u;
+            wait |= (st == kPsNeedExact && h0 + k < H) ? (1u << k) : 0u;
+        }
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         double2 pa0[PPL], pb0[PPL], pa1[PPL], pb1[PPL];
         auto load = [&](double2 (&pa)[PPL], double2 (&pb)[PPL], int blk) {
@@ -1151,8 +1175,8 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, 
                 visits += (unsigned)nblk;
             return cl;
         };
-        const int v0 = (alive & 1u) ? c0 : -1, v1 = (alive & 2u) ? c1 : -1;
-        const int v2 = (alive & 4u) ? c2 : -1, v3 = (alive & 8u) ? c3 : -1;
+        const int v0 = (alive & 1u) ? c0 : (wait & 1u) ? 0x7fffffff : -1, v1 = (alive & 2u) ? c1 : (wait & 2u) ? 0x7fffffff : -1;
+        const int v2 = (alive & 4u) ? c2 : (wait & 4u) ? 0x7fffffff : -1, v3 = (alive & 8u) ? c3 : (wait & 8u) ? 0x7fffffff : -1;
         int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
         if (alive & 1u) l0 = lower(F0, t0, c0);
         if (alive & 2u) l1 = lower(F1, t1, c1);
@@ -1174,6 +1198,191 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, 
         atomicAdd(&b.stats[2], visits * (unsigned long long)BW);
 }
 
+// Single-precision form of ransac_count2_kernel for pairs in mode 1: the record holds F~ as 9 floats and the two counting
+// thresholds, already widened by the pre-screen's band AND by the bound on the binary32 evaluation error (prescreen.hpp),
+// the points are rounded to binary32 in LDS (16 bytes per point: one ds_read_b128).  v_fma_f32 issues at twice the rate of
+// v_fma_f64, the residual is the same nine instructions.  Exact records do not occur in these pairs before the selection
+// (hypotheses without a certificate wait for the exact solve with an "infinite" count).
+typedef __attribute__((address_space(4))) float CFloat;
+
+// v_fma_f32 d = a * F + c with F in a scalar register, written out: left to itself hipcc packs pairs of these into
+// v_pk_fma_f32, which needs both operands in vector register PAIRS (200 v_mov per 192 packed FMAs in the kernel's text) and
+// issues no faster than two plain FMAs on this part
+__device__ __forceinline__ float fma_vs(float a, float f_sgpr, float c)
+{
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(f_sgpr), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_vv(float a, float b, float c)
+{
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// F[0..5] in scalar registers, F[6..8] (the inner addends: an instruction takes one scalar operand) in vector registers
+__device__ __forceinline__ int count_block32(const float (&F)[9], const float4 &p, float thr)
+{
+    const float u0 = fma_vs(p.z, F[0], fma_vs(p.w, F[3], F[6]));
+    const float u1 = fma_vs(p.z, F[1], fma_vs(p.w, F[4], F[7]));
+    const float u2 = fma_vs(p.z, F[2], fma_vs(p.w, F[5], F[8]));
+    const float r = __builtin_fabsf(fma_vv(u0, p.x, fma_vv(u1, p.y, u2)));
+    return __popcll(__ballot(r < thr));   // NaN (padding lanes) compares false
+}
+
+template <int CNT_THREADS, int PPL, bool STATS = false>
+__global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b, RunParams rp, int wg_per_pair)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
+    __shared__ int s_bound;
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8 || b.mode[pair] != 1)
+        return;
+    const int H = rp.num_hypotheses;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    constexpr int BW = 64 * PPL;                  // points per block
+    const int nblk = (M + BW - 1) / BW;
+    float4 *s_p = reinterpret_cast<float4 *>(s_cpts);
+    {
+        const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+        const float qnan = __builtin_nanf("");
+        for (int i = tid; i < nblk * BW; i += CNT_THREADS) {
+            float4 q = make_float4(qnan, qnan, qnan, qnan);
+            if (i < M) {
+                const double4 p = src[i];
+                q = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+            }
+            s_p[i] = q;
+        }
+    }
+    int *gbound = b.bound + pair;
+    if (tid == 0)
+        s_bound = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
+    const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
+    int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
+    const float4 *L = s_p + lane;
+    const int n_groups = (H + kCntSlots - 1) / kCntSlots;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = wg_per_pair * (CNT_THREADS / 64);
+    constexpr int RF = kHypRec * 2;   // floats per record
+    int B = 0;
+    unsigned long long visits = 0;
+    for (int g = blockIdx.x * (CNT_THREADS / 64) + wave; g < n_groups; g += n_waves) {
+        const int h0 = g * kCntSlots;
+        const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
+        float F0[9], F1[9], F2[9], F3[9];
+        const CFloat *f = (const CFloat *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            F0[k] = f[k];
+            F1[k] = f[RF + k];
+            F2[k] = f[2 * RF + k];
+            F3[k] = f[3 * RF + k];
+        }
+        const float tu0 = f[9], tu1 = f[RF + 9], tu2 = f[2 * RF + 9], tu3 = f[3 * RF + 9];
+        const float tl0 = f[10], tl1 = f[RF + 10], tl2 = f[2 * RF + 10], tl3 = f[3 * RF + 10];
+        // a v_fma_f32 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group
+#pragma unroll
+        for (int k = 6; k < 9; ++k) {
+            asm volatile("" : "+v"(F0[k]));
+            asm volatile("" : "+v"(F1[k]));
+            asm volatile("" : "+v"(F2[k]));
+            asm volatile("" : "+v"(F3[k]));
+        }
+        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
+        unsigned alive = 0, wait = 0;
+#pragma unroll
+        for (int k = 0; k < kCntSlots; ++k) {
+            const unsigned st = (ok4 >> (8 * k)) & 0xffu;
+            alive |= (st == kPsApprox && h0 + k < H) ? (1u << k) : 0u;
+            wait |= (st == kPsNeedExact && h0 + k < H) ? (1u << k) : 0u;
+        }
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        float4 pa[PPL], pb[PPL];
+        auto load = [&](float4 (&p)[PPL], int blk) {
+            const int nb = min(blk, nblk - 1) * BW;
+#pragma unroll
+            for (int u = 0; u < PPL; ++u)
+                p[u] = L[nb + u * 64];
+        };
+        auto process = [&](const float4 (&p)[PPL], int blk) {
+            const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
+            if (STATS)
+                visits += (unsigned)__builtin_popcount(alive);
+            if (alive & 1u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c0 += count_block32(F0, p[u], tu0);
+                if (c0 < need) alive &= ~1u;
+            }
+            if (alive & 2u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c1 += count_block32(F1, p[u], tu1);
+                if (c1 < need) alive &= ~2u;
+            }
+            if (alive & 4u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c2 += count_block32(F2, p[u], tu2);
+                if (c2 < need) alive &= ~4u;
+            }
+            if (alive & 8u) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    c3 += count_block32(F3, p[u], tu3);
+                if (c3 < need) alive &= ~8u;
+            }
+        };
+        load(pa, 0);
+        for (int blk = 0; blk < nblk && alive; blk += 2) {
+            load(pb, blk + 1);
+            process(pa, blk);
+            if (!(blk + 1 < nblk && alive))
+                break;
+            load(pa, blk + 2);
+            process(pb, blk + 1);
+        }
+        // lower bounds of the slots that saw every point: one more pass against the lower threshold
+        auto lower = [&](const float (&F)[9], float tl) -> int {
+            int cl = 0;
+            for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u)
+                    cl += count_block32(F, L[blk * BW + u * 64], tl);
+            }
+            if (STATS)
+                visits += (unsigned)nblk;
+            return cl;
+        };
+        const int v0 = (alive & 1u) ? c0 : (wait & 1u) ? 0x7fffffff : -1, v1 = (alive & 2u) ? c1 : (wait & 2u) ? 0x7fffffff : -1;
+        const int v2 = (alive & 4u) ? c2 : (wait & 4u) ? 0x7fffffff : -1, v3 = (alive & 8u) ? c3 : (wait & 8u) ? 0x7fffffff : -1;
+        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
+        if (alive & 1u) l0 = lower(F0, tl0);
+        if (alive & 2u) l1 = lower(F1, tl1);
+        if (alive & 4u) l2 = lower(F2, tl2);
+        if (alive & 8u) l3 = lower(F3, tl3);
+        if (lane < kCntSlots)
+            cntp[h0 + lane] = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
+        const int cm = __builtin_amdgcn_readfirstlane(max(max(l0, l1), max(l2, l3)));
+        if (cm > B) {
+            B = cm;
+            if (lane == 0) {
+                atomicMax(&s_bound, cm);
+                __hip_atomic_fetch_max(gbound, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        B = max(B, __builtin_amdgcn_readfirstlane(gb));
+    }
+    if (STATS && lane == 0 && b.stats)
+        atomicAdd(&b.stats[3], visits * (unsigned long long)BW);   // executed single-precision evaluations
+}
+
 // approximate records whose upper-bound count reaches the pair's final bound: they may be the winner, so they get their
 // exact F (work list 1 -> ransac_exact_list_kernel) before ransac_select_kernel scores everything at or above the bound
 __global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunParams rp, int n_active)
@@ -1187,14 +1396,14 @@ __global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunPa
         if (rec < total) {
             const int pair = (int)(rec / Hp);
             const uint32_t h = (uint32_t)(rec - (size_t)pair * Hp);
-            take = h < (uint32_t)rp.num_hypotheses && b.M[pair] >= 8 && b.hyp_okf[rec] == kPsApprox &&
+            take = h < (uint32_t)rp.num_hypotheses && b.M[pair] >= 8 && b.mode[pair] != 0 && b.hyp_okf[rec] == kPsApprox &&
                    b.hyp_cnt[rec] >= b.bound[pair];
         }
         const unsigned long long m = __ballot(take);
         if (m) {
             unsigned base = 0;
             if (lane == 0)
-                base = atomicAdd(&b.xcount[1], (unsigned)__popcll(m));
+                base = atomicAdd(&b.xcount[0], (unsigned)__popcll(m));   // behind the entries the pre-screen flagged
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (take)
                 b.xlist[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)rec;
@@ -1249,6 +1458,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
     __syncthreads();
     const int cmax = b.bound[pair];
     const int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
+    const uint8_t *okb = b.hyp_okf + (size_t)pair * Hp;   // a listed hypothesis whose exact solve rejected the sample is out
     const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
     const double thr = pair_max_error_sq(b, rp, pair);
     const double4 *L4 = reinterpret_cast<const double4 *>(s_spts);
@@ -1262,7 +1472,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
             const int h = scan + tid;
             // every hypothesis whose (upper-bound) count reaches the pair's bound; with exact counts these are the ties at
             // the maximum, with pre-screened ones the survivors -- all of them carry their exact F by now
-            const bool flag = h < H && cntp[h] >= cmax;
+            const bool flag = h < H && cntp[h] >= cmax && okb[h] != kPsInvalid;
             const unsigned long long bal = __ballot(flag);
             if (lane == 0)
                 s_tot[w] = __popcll(bal);
@@ -1889,6 +2099,13 @@ constexpr int kCntPpl = 2;         // 70 registers allow) against one workgroup 
 constexpr int kSolveBlock = 64;    // one wavefront per workgroup: every SIMD refills on its own (45.4 -> 44.5 ms, same bits)
 constexpr int kSplitMinPairs = 3;  // one or two pairs stay on the fused kernel (latency: fewer launches)
 
+constexpr int kCnt32Ppl = 4;       // single-precision counting: four points per lane and block (scalar work per evaluation halves)
+static size_t count32_lds_bytes(int max_kp)
+{
+    const int bw = 64 * kCnt32Ppl;
+    return (size_t)((max_kp + bw - 1) / bw) * bw * 4 * sizeof(float);
+}
+
 static size_t count_lds_bytes(int max_kp)
 {
     const int bw = 64 * kCntPpl;
@@ -1959,6 +2176,12 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.threads = kCntThreads;
         d.dynamic_lds = count_lds_bytes(max_kp);
         break;
+    case kKRansacCount32:
+        d.name = "ransac_count32_kernel<768, 4>";
+        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCntThreads, kCnt32Ppl>);
+        d.threads = kCntThreads;
+        d.dynamic_lds = count32_lds_bytes(max_kp);
+        break;
     case kKRansacSurvivors:
         d.name = "ransac_survivors_kernel";
         d.fn = reinterpret_cast<const void *>(ransac_survivors_kernel);
@@ -1994,6 +2217,8 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl, true>),
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>),
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCntThreads, kCnt32Ppl>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCntThreads, kCnt32Ppl, true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
@@ -2073,9 +2298,9 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
 static int g_force_mode = -1;   // diagnostics: -1 = the probe decides, 0 / 1 = every pair exact / pre-screened
 void set_prescreen_force(int m) { g_force_mode = m; }
 
-void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream)
+void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream)
 {
-    hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, 1);
+    hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, mode);
     hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((rp.num_hypotheses + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
 }
 
@@ -2093,14 +2318,21 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     if (lt) lt->mark(kKRansacSolve);
     hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active), dim3(kSolveBlock),
                        0, stream, b, rp, 1);
-    if (lt) lt->mark(kKRansacExactList);
-    hipLaunchKernelGGL((ransac_exact_list_kernel<240 + 1024>), dim3(1024), dim3(64), 0, stream, b, rp, 0);
     const int n_groups4 = (H + kCntSlots - 1) / kCntSlots;
     const int wpw = kCntThreads / 64;
     int wg = (512 + n_active - 1) / n_active;
     wg = std::max(wg, 4);
     wg = std::min(wg, std::max(1, (n_groups4 + wpw - 1) / wpw));
-    const size_t lds_cnt = count_lds_bytes(b.max_kp);
+    const size_t lds_cnt = count_lds_bytes(b.max_kp), lds_c32 = count32_lds_bytes(b.max_kp);
+    // counting: single precision for the pairs in mode 1, double precision for the others (each launch's workgroups leave
+    // at once for the pairs of the other kind)
+    if (lt) lt->mark(kKRansacCount32);
+    if (stats)
+        hipLaunchKernelGGL((ransac_count32_kernel<kCntThreads, kCnt32Ppl, true>), dim3(wg, n_active), dim3(kCntThreads), lds_c32,
+                           stream, b, rp, wg);
+    else
+        hipLaunchKernelGGL((ransac_count32_kernel<kCntThreads, kCnt32Ppl>), dim3(wg, n_active), dim3(kCntThreads), lds_c32,
+                           stream, b, rp, wg);
     if (lt) lt->mark(kKRansacCount2);
     if (stats)
         hipLaunchKernelGGL((ransac_count2_kernel<kCntThreads, kCntPpl, true>), dim3(wg, n_active), dim3(kCntThreads), lds_cnt,
@@ -2112,8 +2344,9 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     const int sg = (int)std::min<size_t>((total + 255) / 256, 8192);
     if (lt) lt->mark(kKRansacSurvivors);
     hipLaunchKernelGGL(ransac_survivors_kernel, dim3(sg), dim3(256), 0, stream, b, rp, n_active);
+    // one exact solve over the whole work list: what the pre-screen flagged + the survivors of the counting
     if (lt) lt->mark(kKRansacExactList);
-    hipLaunchKernelGGL((ransac_exact_list_kernel<240 + 1024>), dim3(1024), dim3(64), 0, stream, b, rp, 1);
+    hipLaunchKernelGGL((ransac_exact_list_kernel<240 + 1024>), dim3(1024), dim3(64), 0, stream, b, rp, 0);
     if (lt) lt->mark(kKRansacSelect);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), (size_t)b.max_kp * 4 * sizeof(double), stream,
                        b, rp);

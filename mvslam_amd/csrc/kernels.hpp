@@ -66,9 +66,10 @@ struct BatchDev {
     int32_t *hyp_cnt;    // [P][max_groups * 256] full (upper-bound) inlier count of a hypothesis that can still win, -1 otherwise
     int32_t *bound;      // [P] largest full (lower-bound) count seen so far: the pruning bound of the counting kernel
     double *box;         // [P][8] bounding box of the pair's matches (x1lo, x1hi, y1lo, y1hi, x2lo, x2hi, y2lo, y2hi)
-    int32_t *mode;       // [P] 1: the pair's hypotheses are pre-screened, 0: every hypothesis is solved exactly
+    int32_t *mode;       // [P] 0: every hypothesis is solved exactly; 1: pre-screened, counted in single precision; 2: pre-
+                         // screened, counted in double precision
     uint32_t *xlist;     // [P * max_groups * 256] work list of the list-driven exact solve: flat indices pair * Hp + h
-    uint32_t *xcount;    // [2] entries of the list: {flagged by the pre-screen, survivors of the count}
+    uint32_t *xcount;    // [2] {entries of the list: flagged by the pre-screen + survivors of the count, unused}
     double *cand_pts;    // [P][4][N][3] triangulation scratch
     FinModel *fin;       // [P]
     uint16_t *inl;       // [P][N] ordered inlier list
@@ -270,6 +271,7 @@ enum KernelId : int {
     kKRansacPrescreen, // approximate F + certified band per hypothesis
     kKRansacExactList, // exact solve of the listed hypotheses (flagged by the pre-screen / survivors of the count)
     kKRansacCount2,    // pruned counting with per-hypothesis thresholds (upper / lower bounds of the exact count)
+    kKRansacCount32,   // the same in single precision (thresholds widened by the binary32 evaluation error)
     kKRansacSurvivors, // hypotheses whose upper bound reaches the pair's best lower bound -> work list
     kKFinModel,
     kKTriangulate,
@@ -310,7 +312,7 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
 // opt-in to > 64 KB of dynamic LDS for the kernels that need it, once per device; hipSuccess or the first error
 hipError_t prepare_kernels();
 // diagnostics: pair_prepare + ransac_prescreen only, every pair forced into the pre-screened mode
-void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream);
+void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
 void set_prescreen_force(int m);   // diagnostics: -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened
 void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)
 int get_ransac_variant();

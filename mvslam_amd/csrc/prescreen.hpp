@@ -33,72 +33,126 @@ constexpr double kPsSvd3 = 2.0e-11;       // backward error of the 3x3 Jacobi SV
 constexpr double kPsBandFrac = 0.125;     // screened only if band <= kPsBandFrac * thr
 constexpr int kPsInvalid = 0, kPsApprox = 1, kPsNeedExact = 2, kPsExact = 3;   // per-hypothesis state byte (hyp_okf)
 
-// Householder QR of A^T, in place.  c[j][0..8] = row j of A = column j of A^T.  After step k the strict upper triangle of R
-// sits in c[j][k] (k < j), R_kk in rd[k], the reflector's vector in c[k][k..8] and 1 / (v.v / 2) in beta[k].
-MVS_DEV void householder_qr_9x8(double (&c)[8][9], double (&rd)[8], double (&beta)[8])
+// 1 / x for 2^-190 <= |x| <= 2^190 (div_fast's guarded range), correctly rounded like the compiler's division
+MVS_DEV double recip_guarded(double x) { return div_fast(1.0, x); }
+
+// Hartley normalisation of a sample from its gathered points: means and scales only (the normalised coordinates are
+// rebuilt point by point where they are needed).  The same operations as normalise8: the same bits.
+MVS_DEV bool sample_norm(const double (&px)[8], const double (&py)[8], double &scale, double &mx, double &my, bool &tiny)
 {
+    mx = 0.0;
+    my = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        double ss = 0.0;
-#pragma unroll
-        for (int i = k; i < 9; ++i)
-            ss = dfma(c[k][i], c[k][i], ss);
-        const double nrm = dsqrt(ss);
-        const double x0 = c[k][k];
-        const double ax0 = dabs(x0);
-        const double alpha = x0 >= 0.0 ? -nrm : nrm;
-        c[k][k] = x0 - alpha;                  // v0: same sign as x0, no cancellation
-        const double vv = nrm * (nrm + ax0);   // = v.v / 2
-        const double bk = vv > 0.0 ? 1.0 / vv : 0.0;
-        rd[k] = alpha;
-        beta[k] = bk;
-#pragma unroll
-        for (int j = k + 1; j < 8; ++j) {
-            double d = 0.0;
-#pragma unroll
-            for (int i = k; i < 9; ++i)
-                d = dfma(c[k][i], c[j][i], d);
-            const double t = bk * d;
-#pragma unroll
-            for (int i = k; i < 9; ++i)
-                c[j][i] = dfma(-t, c[k][i], c[j][i]);
-        }
+    for (int i = 0; i < 8; ++i) {
+        mx += px[i];
+        my += py[i];
     }
+    mx *= 0.125;
+    my *= 0.125;
+    double sc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double dx = px[i] - mx, dy = py[i] - my;
+        const double q = dx * dx + dy * dy;
+        tiny = tiny || (q != 0.0 && !sqrt_fast_ok(q));
+        sc += sqrt_fast(q);
+    }
+    sc *= 0.125;
+    const bool ok = sc > kEps;
+    scale = kSqrt2 / sc;
+    return ok;
 }
 
-// flag (kPs*), F~ and band for one sample.  nm / a1..b2: the exact path's own normalisation of the sample (same bits).
-// w_out: singular values of reshape(n~) as the 3x3 Jacobi computed them (diagnostics).
+constexpr int kPsParked = 28;   // strict upper triangle of R, parked in LDS: [kPsParked][64 lanes] doubles per wavefront
+MVS_DEV constexpr int ps_tri(int i, int k) { return k * (k - 1) / 2 + i; }   // (i, k), i < k  ->  0 .. 27
+
+// flag (kPs*), F~ and band for one sample.  P: the pair's points [M][4]; idx: the sample; park: this lane's column of the
+// wavefront's LDS block (stride 64 doubles).
+//
+// Left-looking Householder QR of A^T (9 x 8): column j (= row j of A, a function of sample point j alone) is rebuilt from
+// a fresh gather of point j, the reflectors 0 .. j-1 are applied to it, its entries above the diagonal are final entries of
+// R and are parked in LDS, the rest defines reflector j.  Neither A nor the normalised sample ever exists as a whole in
+// registers: live state is the reflectors (44 doubles) + one column, and the kernel fits two wavefronts per SIMD.
 template <int VAR>
-MVS_DEV int prescreen_hypothesis(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8], const double (&y2)[8],
-                                 const PairBox &bx, double thr, double (&F)[9], double &band_out, bool &bad3)
+MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, const PairBox &bx, double thr, double (&F)[9],
+                                 double &band_out, double &e32_out, bool &bad3)
 {
-    double a1[8], b1[8], a2[8], b2[8];
     EightNorm nm;
-    bool ok = normalise8(x1, y1, a1, b1, nm.s1, nm.m1x, nm.m1y);
-    ok = normalise8(x2, y2, a2, b2, nm.s2, nm.m2x, nm.m2y) && ok;
+    bool ok, tiny = false;
+    {
+        double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
+            x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
+        }
+        ok = sample_norm(x1, y1, nm.s1, nm.m1x, nm.m1y, tiny);
+        ok = sample_norm(x2, y2, nm.s2, nm.m2x, nm.m2y, tiny) && ok;
+    }
     band_out = 0.0;
-    if (!ok) {   // reference: assert(scale > epsilon); the exact path rejects the sample too (same bits, same decision)
+    e32_out = 0.0;
+    if (!ok && !tiny) {   // reference: assert(scale > epsilon); the exact path rejects the sample too (same bits, same decision)
 #pragma unroll
         for (int k = 0; k < 9; ++k)
             F[k] = 0.0;
         return kPsInvalid;
     }
-    // design matrix rows (fundamental-matrix.cpp:78-87), the exact path's products
-    double c[8][9];
+    double v[8][9];   // v[k][k..8]: reflector k (entries below k are never touched)
+    double rd[8], beta[8];
     double S = 0.0;   // ||A||_F^2
+    bool piv_ok = !tiny;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c[i][0] = a2[i] * a1[i]; c[i][1] = a2[i] * b1[i]; c[i][2] = a2[i];
-        c[i][3] = b2[i] * a1[i]; c[i][4] = b2[i] * b1[i]; c[i][5] = b2[i];
-        c[i][6] = a1[i];         c[i][7] = b1[i];         c[i][8] = 1.0;
+    for (int j = 0; j < 8; ++j) {
+        double col[9];
+        {
+            // a fresh gather: the first one's values must not stay alive across the QR, and the scheduler must not hoist the
+            // later columns above the earlier reflectors (it would rebuild the whole matrix in registers): the index is
+            // made opaque AND tied to the previous reflector's scale
+            if (j == 0)
+                asm volatile("" : "+v"(idx[j]));
+            else
+                asm volatile("" : "+v"(idx[j]) : "v"(beta[j > 0 ? j - 1 : 0]));
+            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[j] * 4);
+            const double a1 = (p.x - nm.m1x) * nm.s1, b1 = (p.y - nm.m1y) * nm.s1;   // normalise8's own operations
+            const double a2 = (p.z - nm.m2x) * nm.s2, b2 = (p.w - nm.m2y) * nm.s2;
+            // design matrix row (fundamental-matrix.cpp:78-87), the exact path's products
+            col[0] = a2 * a1; col[1] = a2 * b1; col[2] = a2;
+            col[3] = b2 * a1; col[4] = b2 * b1; col[5] = b2;
+            col[6] = a1;      col[7] = b1;      col[8] = 1.0;
+            // ||row||^2 = (a2^2 + b2^2 + 1)(a1^2 + b1^2 + 1): an upper estimate is all the bound needs
+            S = dfma(dfma(a2, a2, dfma(b2, b2, 1.0)), dfma(a1, a1, dfma(b1, b1, 1.0)), S);
+        }
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-            S = dfma(c[i][k], c[i][k], S);
+        for (int k = 0; k < j; ++k) {
+            double d = 0.0;
+#pragma unroll
+            for (int i = k; i < 9; ++i)
+                d = dfma(v[k][i], col[i], d);
+            const double t = beta[k] * d;
+#pragma unroll
+            for (int i = k; i < 9; ++i)
+                col[i] = dfma(-t, v[k][i], col[i]);
+            park[ps_tri(k, j) * 64] = col[k];   // R_kj
+        }
+        double ss = 0.0;
+#pragma unroll
+        for (int i = j; i < 9; ++i)
+            ss = dfma(col[i], col[i], ss);
+        piv_ok = piv_ok && (ss >= 0x1p-190);    // a (nearly) dependent row: no certificate; also keeps every divisor inside
+        const double nrm = sqrt_fast_nz(ss);    // the range of the unscaled sequences
+        const double x0 = col[j];
+        const double alpha = x0 >= 0.0 ? -nrm : nrm;
+        const double vv = nrm * (nrm + dabs(x0));    // = v.v / 2
+        rd[j] = alpha;
+        beta[j] = recip_guarded(vv);
+        v[j][j] = x0 - alpha;                        // v0: same sign as x0, no cancellation
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i)
+            v[j][i] = col[i];
     }
     S *= 1.0 + 1e-12;
+    piv_ok = piv_ok && (S <= 0x1p100);
     const double sqrtS = dsqrt(S) * (1.0 + 1e-12);
-    double rd[8], beta[8];
-    householder_qr_9x8(c, rd, beta);
     // n~ = H_0 H_1 ... H_7 e_8
     double n[9];
 #pragma unroll
@@ -109,50 +163,59 @@ MVS_DEV int prescreen_hypothesis(const double (&x1)[8], const double (&y1)[8], c
         double d = 0.0;
 #pragma unroll
         for (int i = k; i < 9; ++i)
-            d = dfma(c[k][i], n[i], d);
+            d = dfma(v[k][i], n[i], d);
         const double t = beta[k] * d;
 #pragma unroll
         for (int i = k; i < 9; ++i)
-            n[i] = dfma(-t, c[k][i], n[i]);
+            n[i] = dfma(-t, v[k][i], n[i]);
     }
-    // ||R^-1||_F by explicit back substitution, column by column (R_ik = c[k][i] for i < k)
-    double inv[8];
-    bool piv_ok = true;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        piv_ok = piv_ok && (dabs(rd[i]) > 0x1p-500);
-        inv[i] = 1.0 / rd[i];
-    }
+    // ||R^-1||_F by explicit back substitution, column by column; R's strict upper triangle comes back from LDS (the
+    // reflectors are dead by now)
     double y2sum = 0.0;
+    {
+        double R[kPsParked];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double y[8];
-        y[j] = inv[j];
-        y2sum = dfma(y[j], y[j], y2sum);
+        for (int q = 0; q < kPsParked; ++q)
+            R[q] = park[q * 64];
+        double inv[8];
 #pragma unroll
-        for (int i = j - 1; i >= 0; --i) {
-            double s = 0.0;
+        for (int i = 0; i < 8; ++i)
+            inv[i] = recip_guarded(rd[i]);
 #pragma unroll
-            for (int k = i + 1; k <= j; ++k)
-                s = dfma(c[k][i], y[k], s);
-            y[i] = -(s * inv[i]);
-            y2sum = dfma(y[i], y[i], y2sum);
+        for (int j = 0; j < 8; ++j) {
+            double y[8];
+            y[j] = inv[j];
+            y2sum = dfma(y[j], y[j], y2sum);
+#pragma unroll
+            for (int i = j - 1; i >= 0; --i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = i + 1; k <= j; ++k)
+                    s = dfma(R[ps_tri(i, k)], y[k], s);
+                y[i] = -(s * inv[i]);
+                y2sum = dfma(y[i], y[i], y2sum);
+            }
         }
     }
     const double yf = dsqrt(y2sum) * (1.0 + 1e-12);
-    // a-posteriori residual of n~ against the ORIGINAL rows of A (recomputed: the QR overwrote them)
+    // a-posteriori residual of n~ against the ORIGINAL rows of A, rebuilt from a second gather of the sample (the indices
+    // are made opaque so that the compiler does not keep the first gather's values alive across the QR instead)
     double rho2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        asm volatile("" : "+v"(idx[i]));
+        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[i] * 4);
+        const double a1 = (p.x - nm.m1x) * nm.s1, b1 = (p.y - nm.m1y) * nm.s1;   // normalise8's own operations: same bits
+        const double a2 = (p.z - nm.m2x) * nm.s2, b2 = (p.w - nm.m2y) * nm.s2;
         double r = n[8];
-        r = dfma(a1[i], n[6], r);
-        r = dfma(b1[i], n[7], r);
-        r = dfma(a2[i], n[2], r);
-        r = dfma(b2[i], n[5], r);
-        r = dfma(a2[i] * a1[i], n[0], r);
-        r = dfma(a2[i] * b1[i], n[1], r);
-        r = dfma(b2[i] * a1[i], n[3], r);
-        r = dfma(b2[i] * b1[i], n[4], r);
+        r = dfma(a1, n[6], r);
+        r = dfma(b1, n[7], r);
+        r = dfma(a2, n[2], r);
+        r = dfma(b2, n[5], r);
+        r = dfma(a2 * a1, n[0], r);
+        r = dfma(a2 * b1, n[1], r);
+        r = dfma(b2 * a1, n[3], r);
+        r = dfma(b2 * b1, n[4], r);
         rho2 = dfma(r, r, rho2);
     }
     const double rho = dsqrt(rho2) * (1.0 + 1e-12);
@@ -183,9 +246,21 @@ MVS_DEV int prescreen_hypothesis(const double (&x1)[8], const double (&y1)[8], c
     const double n12p = dfma(s1q, dfma(e1x, e1x, e1y * e1y), 1.0) * dfma(s2q, dfma(e2x, e2x, e2y * e2y), 1.0);
     const double band = (dfn * dsqrt(n12) * (1.0 + 1e-9) + 64.0 * kPsU * dsqrt(n12p)) * (1.0 + 1e-9) + 1e-15 * thr;
     band_out = band;
-    // every comparison is written so that a NaN anywhere lands in "needs the exact solve"
-    const bool certified = piv_ok && (z < 0.5) && (sig8 > 0.0) && (delta > 0.0) && (eta < 1e-3) &&
-                           (band <= kPsBandFrac * thr);
+    // single-precision counting (ransac_count32_kernel): r32 = the residual's fma chain in binary32 on F~ and the point
+    // rounded to binary32.  Every term p2_j F_jk p1_k passes at most 7 roundings (three inputs, four nested fma):
+    // | r32 - r(F~, p) | <= 8 * 2^-24 * T,  T = sum |p2_j| |F_jk| |p1_k| <= [X2 Y2 1] |F~| [X1 Y1 1]^T over the pair's box
+    {
+        const double X1 = fmax(dabs(bx.x1lo), dabs(bx.x1hi)), Y1 = fmax(dabs(bx.y1lo), dabs(bx.y1hi));
+        const double X2 = fmax(dabs(bx.x2lo), dabs(bx.x2hi)), Y2 = fmax(dabs(bx.y2lo), dabs(bx.y2hi));
+        const double t0 = dfma(X2, dabs(F[0]), dfma(Y2, dabs(F[3]), dabs(F[6])));
+        const double t1 = dfma(X2, dabs(F[1]), dfma(Y2, dabs(F[4]), dabs(F[7])));
+        const double t2 = dfma(X2, dabs(F[2]), dfma(Y2, dabs(F[5]), dabs(F[8])));
+        const double T = dfma(t0, X1, dfma(t1, Y1, t2));
+        e32_out = 8.0 * 0x1p-24 * T * (1.0 + 1e-6) + 1e-30;
+    }
+    // every comparison is written so that a NaN anywhere lands in "needs the exact solve"; the caller adds the band test
+    // of its counting precision (band, or band + e32, against kPsBandFrac * thr)
+    const bool certified = piv_ok && (z < 0.5) && (sig8 > 0.0) && (delta > 0.0) && (eta < 1e-3) && (band < 0x1p100);
     return certified ? kPsApprox : kPsNeedExact;
 }
 

@@ -46,7 +46,7 @@ def adversarial(data, rng):
 
 def main():
     P, N, H = 8, 600, 1536
-    thr_list = [1e-2, 1e-4]
+    thr_list = [1e-2, 1e-3]
     rng = np.random.default_rng(11)
     data = synth.make_batch(0, P, n_kp=N)
     data = adversarial(data, rng)
@@ -63,51 +63,68 @@ def main():
         b.run(prm)
         b.sync()
         base = b.download()
-        st = lib.mvs_debug_prescreen_only(b._h, C.byref(prm), C.c_int(P))
-        assert st == 0, st
-        for p in range(P):
-            M = int(base["results"][p]["n_matches"])
-            if M < 8:
-                continue
-            mt = base["matches"][p][:M]
-            K = data["K"][p].reshape(3, 3)
-            p1 = o.normalize_points(K, data["kp1"][p][mt["trainIdx"]].astype(np.float64))
-            p2 = o.normalize_points(K, data["kp2"][p][mt["queryIdx"]].astype(np.float64))
-            rec = np.zeros((H, 10))
-            state = np.zeros(H, dtype=np.uint8)
-            info = (C.c_int32 * 4)()
-            st = lib.mvs_debug_read_hyp_rec(b._h, C.c_int(p), C.c_int(H), rec.ctypes.data_as(C.POINTER(C.c_double)),
-                                            state.ctypes.data_as(C.POINTER(C.c_ubyte)), None, info)
-            assert st == 0 and info[0] == 1
-            seed = synth.SEED_BASE + int(data["global_index"][p])
-            for h in range(H):
-                idx = o.sample8(seed, h, M)
-                ok, FJ = o.find_fundamental_matrix(p1[idx], p2[idx])
-                stats["hyp"] += 1
-                assert (state[h] == 0) == (not ok), (p, h, state[h], ok)
-                if state[h] == 0:
-                    stats["invalid"] += 1
+        for pmode in (2, 1):    # 2: double-precision records, 1: single-precision records (thresholds widened by e32)
+            st = lib.mvs_debug_prescreen_only(b._h, C.byref(prm), C.c_int(P), C.c_int(pmode))
+            assert st == 0, st
+            for p in range(P):
+                M = int(base["results"][p]["n_matches"])
+                if M < 8:
                     continue
-                if state[h] == 2:
-                    stats["need_exact"] += 1
-                    continue
-                assert state[h] == 1
-                stats["certified"] += 1
-                band = rec[h, 9] - thr
-                assert 0 < band <= 0.125 * thr * (1 + 1e-12) + 1e-300, (p, h, band)
-                rj = pm.residuals(FJ, p1, p2)
-                ra = pm.residuals(rec[h, :9].reshape(3, 3), p1, p2)
-                d = float(np.abs(rj - ra).max())
-                stats["worst_ratio"] = max(stats["worst_ratio"], d / band)
-                if d > band:
-                    stats["viol"] += 1
-                cj = int((rj < thr).sum())
-                cu, cl = int((ra < thr + band).sum()), int((ra < thr - band).sum())
-                if not (cu >= cj >= cl):
-                    stats["count_viol"] += 1
+                mt = base["matches"][p][:M]
+                K = data["K"][p].reshape(3, 3)
+                p1 = o.normalize_points(K, data["kp1"][p][mt["trainIdx"]].astype(np.float64))
+                p2 = o.normalize_points(K, data["kp2"][p][mt["queryIdx"]].astype(np.float64))
+                rec = np.zeros((H, 10))
+                state = np.zeros(H, dtype=np.uint8)
+                info = (C.c_int32 * 4)()
+                st = lib.mvs_debug_read_hyp_rec(b._h, C.c_int(p), C.c_int(H), rec.ctypes.data_as(C.POINTER(C.c_double)),
+                                                state.ctypes.data_as(C.POINTER(C.c_ubyte)), None, info)
+                assert st == 0 and info[0] == pmode
+                rec32 = rec.view(np.float32).reshape(H, 20)
+                # single precision: the device evaluates the fma chain in binary32 on the rounded points
+                q1, q2 = p1.astype(np.float32).astype(np.float64), p2.astype(np.float32).astype(np.float64)
+                a1 = np.c_[np.abs(q1), np.ones(M)]
+                a2 = np.c_[np.abs(q2), np.ones(M)]
+                seed = synth.SEED_BASE + int(data["global_index"][p])
+                for h in range(H):
+                    idx = o.sample8(seed, h, M)
+                    ok, FJ = o.find_fundamental_matrix(p1[idx], p2[idx])
+                    stats["hyp"] += 1
+                    assert (state[h] == 0) == (not ok), (p, h, state[h], ok)
+                    if state[h] == 0:
+                        stats["invalid"] += 1
+                        continue
+                    if state[h] == 2:
+                        stats["need_exact"] += 1
+                        continue
+                    assert state[h] == 1
+                    stats["certified"] += 1
+                    rj = pm.residuals(FJ, p1, p2)
+                    cj = int((rj < thr).sum())
+                    if pmode == 2:
+                        band = rec[h, 9] - thr
+                        assert 0 < band <= 0.125 * thr * (1 + 1e-12), (p, h, band)
+                        ra = pm.residuals(rec[h, :9].reshape(3, 3), p1, p2)
+                        d = float(np.abs(rj - ra).max())
+                        cu, cl = int((ra < thr + band).sum()), int((ra < thr - band).sum())
+                    else:
+                        F32 = rec32[h, :9].astype(np.float64).reshape(3, 3)
+                        tu, tl = float(rec32[h, 9]), float(rec32[h, 10])
+                        band = min(tu - thr, thr - tl)
+                        assert 0 < band <= 0.125 * thr * (1 + 1e-5), (p, h, band)
+                        ra = pm.residuals(F32, q1, q2)      # binary64 evaluation of the binary32 operands ...
+                        T = np.einsum("ij,jk,ik->i", a2, np.abs(F32), a1)
+                        d = float((np.abs(rj - ra) + 4.01 * 2.0 ** -24 * T).max())   # ... + the four fma roundings of binary32
+                        slack = 4.01 * 2.0 ** -24 * T
+                        cu, cl = int((ra - slack < tu).sum()), int((ra + slack < tl).sum())
+                    stats["worst_ratio"] = max(stats["worst_ratio"], d / band)
+                    if d > band:
+                        stats["viol"] += 1
+                    if not (cu >= cj >= cl):
+                        stats["count_viol"] += 1
         # the whole stage: every pair exact / every pair pre-screened / the probe decides
         outs = []
-        for mode in (0, 1, -1):
+        for mode in (0, 1, 2, -1):
             lib.mvs_debug_set_prescreen_force(C.c_int(mode))
             b.run(prm)
             b.sync()
@@ -117,7 +134,7 @@ def main():
             stats["mode%d_list" % mode if mode >= 0 else "auto_list"] = [int(info[2]), int(info[3])]
         lib.mvs_debug_set_prescreen_force(C.c_int(-1))
         for k in ("results", "mask", "points", "point_idx", "matches"):
-            assert outs[0][k].tobytes() == outs[1][k].tobytes() == outs[2][k].tobytes(), ("modes differ", thr, k)
+            assert outs[0][k].tobytes() == outs[1][k].tobytes() == outs[2][k].tobytes() == outs[3][k].tobytes(), ("modes differ", thr, k)
         for p in range(P):
             ref = o.image_pair(data["desc1"][p], data["kp1"][p], data["desc2"][p], data["kp2"][p], data["K"][p].reshape(3, 3),
                                o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(data["global_index"][p]), thr), 0.7, 10.0)

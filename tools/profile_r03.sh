@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-3 profile set, run on the GPU box from the repo root: bash tools/profile_r03.sh [tag]
+# (rocprofv3 gets the program itself after `--`, never a wrapper; counters in their own passes)
+set -o pipefail
+export TMPDIR=/tmp
+TAG=${1:-r03}
+O=gpurun_out/prof_$TAG
+mkdir -p $O
+B="python3 bench.py --no-cpu-baseline --no-single-pair --no-ref-threshold --sections main"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $B --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
+         "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
+         "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" "SQ_WAIT_INST_LDS SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32"; do
+  D=$O/pmc_$(echo $G | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D -o p -- $B --steps 1 --warmup 0 --pairs 128 > $D.json 2> $D.err || { echo "pmc pass failed: $G"; tail -3 $D.err; }
+done
+python3 tools/pmc_summary.py $O/${TAG}_pmc_summary.json 128 $O/pmc_*
+ls $O/stats
