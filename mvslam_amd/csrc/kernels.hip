@@ -1205,35 +1205,27 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, 
 // (hypotheses without a certificate wait for the exact solve with an "infinite" count).
 typedef __attribute__((address_space(4))) float CFloat;
 
-// v_fma_f32 d = a * F + c with F in a scalar register, written out: left to itself hipcc packs pairs of these into
-// v_pk_fma_f32, which needs both operands in vector register PAIRS (200 v_mov per 192 packed FMAs in the kernel's text) and
-// issues no faster than two plain FMAs on this part
-__device__ __forceinline__ float fma_vs(float a, float f_sgpr, float c)
-{
-    float d;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(f_sgpr), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float fma_vv(float a, float b, float c)
-{
-    float d;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// Plain v_fma_f32 with scalar operands: left to itself hipcc's SLP vectoriser packs pairs of these into v_pk_fma_f32, which
+// needs both operands in vector register PAIRS (200 v_mov per 192 packed FMAs in the kernel's text) and issues no faster than
+// two plain FMAs on this part.  This file is therefore compiled with -fno-slp-vectorize (Makefile; nothing else in it has
+// packable arithmetic).  Inline asm would do it too, but draws an s_nop in front of every dependent instruction: 2.5 per 64
+// evaluations on a kernel that is short of scalar issue slots.
+#define MVS_NO_PK_F32
 
-// F[0..5] in scalar registers, F[6..8] (the inner addends: an instruction takes one scalar operand) in vector registers
-__device__ __forceinline__ int count_block32(const float (&F)[9], const float4 &p, float thr)
+// F[0..5] end up in scalar registers, F[6..8] (the inner addends: an instruction takes one scalar operand) in vector registers
+__device__ __forceinline__ MVS_NO_PK_F32 int count_block32(const float (&F)[9], const float4 &p, float thr)
 {
-    const float u0 = fma_vs(p.z, F[0], fma_vs(p.w, F[3], F[6]));
-    const float u1 = fma_vs(p.z, F[1], fma_vs(p.w, F[4], F[7]));
-    const float u2 = fma_vs(p.z, F[2], fma_vs(p.w, F[5], F[8]));
-    const float r = __builtin_fabsf(fma_vv(u0, p.x, fma_vv(u1, p.y, u2)));
+    const float u0 = __builtin_fmaf(p.z, F[0], __builtin_fmaf(p.w, F[3], F[6]));
+    const float u1 = __builtin_fmaf(p.z, F[1], __builtin_fmaf(p.w, F[4], F[7]));
+    const float u2 = __builtin_fmaf(p.z, F[2], __builtin_fmaf(p.w, F[5], F[8]));
+    const float r = __builtin_fabsf(__builtin_fmaf(u0, p.x, __builtin_fmaf(u1, p.y, u2)));
     return __popcll(__ballot(r < thr));   // NaN (padding lanes) compares false
 }
 
-template <int CNT_THREADS, int PPL, bool STATS = false>
-__global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b, RunParams rp, int wg_per_pair)
+template <int CNT_THREADS, int PPL, int SLOTS, bool STATS = false>
+__global__ __launch_bounds__(CNT_THREADS) MVS_NO_PK_F32 void ransac_count32_kernel(BatchDev b, RunParams rp, int wg_per_pair)
 {
+    static_assert(SLOTS == 4 || SLOTS == 8, "state bytes are read one or two dwords at a time");
     extern __shared__ __attribute__((aligned(16))) double s_cpts[];
     __shared__ int s_bound;
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -1265,44 +1257,46 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
     const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
     int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
     const float4 *L = s_p + lane;
-    const int n_groups = (H + kCntSlots - 1) / kCntSlots;
+    const int n_groups = (H + SLOTS - 1) / SLOTS;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_waves = wg_per_pair * (CNT_THREADS / 64);
     constexpr int RF = kHypRec * 2;   // floats per record
     int B = 0;
     unsigned long long visits = 0;
     for (int g = blockIdx.x * (CNT_THREADS / 64) + wave; g < n_groups; g += n_waves) {
-        const int h0 = g * kCntSlots;
+        const int h0 = g * SLOTS;
         const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
-        float F0[9], F1[9], F2[9], F3[9];
+        float F[SLOTS][9], tu[SLOTS], tl[SLOTS];
         const CFloat *f = (const CFloat *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            F0[k] = f[k];
-            F1[k] = f[RF + k];
-            F2[k] = f[2 * RF + k];
-            F3[k] = f[3 * RF + k];
-        }
-        const float tu0 = f[9], tu1 = f[RF + 9], tu2 = f[2 * RF + 9], tu3 = f[3 * RF + 9];
-        const float tl0 = f[10], tl1 = f[RF + 10], tl2 = f[2 * RF + 10], tl3 = f[3 * RF + 10];
-        // a v_fma_f32 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group
+        for (int q = 0; q < SLOTS; ++q) {
 #pragma unroll
-        for (int k = 6; k < 9; ++k) {
-            asm volatile("" : "+v"(F0[k]));
-            asm volatile("" : "+v"(F1[k]));
-            asm volatile("" : "+v"(F2[k]));
-            asm volatile("" : "+v"(F3[k]));
+            for (int k = 0; k < 9; ++k)
+                F[q][k] = f[q * RF + k];
+            tu[q] = f[q * RF + 9];
+            tl[q] = f[q * RF + 10];
+            // a v_fma_f32 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group
+#pragma unroll
+            for (int k = 6; k < 9; ++k)
+                asm volatile("" : "+v"(F[q][k]));
         }
-        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
         unsigned alive = 0, wait = 0;
 #pragma unroll
-        for (int k = 0; k < kCntSlots; ++k) {
-            const unsigned st = (ok4 >> (8 * k)) & 0xffu;
-            alive |= (st == kPsApprox && h0 + k < H) ? (1u << k) : 0u;
-            wait |= (st == kPsNeedExact && h0 + k < H) ? (1u << k) : 0u;
+        for (int w4 = 0; w4 < SLOTS / 4; ++w4) {
+            const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g * (SLOTS / 4) + w4]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned st = (ok4 >> (8 * k)) & 0xffu;
+                const int q = w4 * 4 + k;
+                alive |= (st == kPsApprox && h0 + q < H) ? (1u << q) : 0u;
+                wait |= (st == kPsNeedExact && h0 + q < H) ? (1u << q) : 0u;
+            }
         }
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        int c[SLOTS];
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q)
+            c[q] = 0;
         float4 pa[PPL], pb[PPL];
         auto load = [&](float4 (&p)[PPL], int blk) {
             const int nb = min(blk, nblk - 1) * BW;
@@ -1314,29 +1308,14 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
             const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
             if (STATS)
                 visits += (unsigned)__builtin_popcount(alive);
-            if (alive & 1u) {
 #pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c0 += count_block32(F0, p[u], tu0);
-                if (c0 < need) alive &= ~1u;
-            }
-            if (alive & 2u) {
+            for (int q = 0; q < SLOTS; ++q) {
+                if (alive & (1u << q)) {
 #pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c1 += count_block32(F1, p[u], tu1);
-                if (c1 < need) alive &= ~2u;
-            }
-            if (alive & 4u) {
-#pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c2 += count_block32(F2, p[u], tu2);
-                if (c2 < need) alive &= ~4u;
-            }
-            if (alive & 8u) {
-#pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c3 += count_block32(F3, p[u], tu3);
-                if (c3 < need) alive &= ~8u;
+                    for (int u = 0; u < PPL; ++u)
+                        c[q] += count_block32(F[q], p[u], tu[q]);
+                    if (c[q] < need) alive &= ~(1u << q);
+                }
             }
         };
         load(pa, 0);
@@ -1349,27 +1328,34 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
             process(pb, blk + 1);
         }
         // lower bounds of the slots that saw every point: one more pass against the lower threshold
-        auto lower = [&](const float (&F)[9], float tl) -> int {
-            int cl = 0;
-            for (int blk = 0; blk < nblk; ++blk) {
+        int v[SLOTS], lo[SLOTS];
+        int cm = -1;
 #pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    cl += count_block32(F, L[blk * BW + u * 64], tl);
+        for (int q = 0; q < SLOTS; ++q) {
+            const bool al = (alive >> q) & 1u;
+            v[q] = al ? c[q] : ((wait >> q) & 1u) ? 0x7fffffff : -1;
+            lo[q] = -1;
+            if (al) {
+                int cl = 0;
+                for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+                    for (int u = 0; u < PPL; ++u)
+                        cl += count_block32(F[q], L[blk * BW + u * 64], tl[q]);
+                }
+                if (STATS)
+                    visits += (unsigned)nblk;
+                lo[q] = cl;
             }
-            if (STATS)
-                visits += (unsigned)nblk;
-            return cl;
-        };
-        const int v0 = (alive & 1u) ? c0 : (wait & 1u) ? 0x7fffffff : -1, v1 = (alive & 2u) ? c1 : (wait & 2u) ? 0x7fffffff : -1;
-        const int v2 = (alive & 4u) ? c2 : (wait & 4u) ? 0x7fffffff : -1, v3 = (alive & 8u) ? c3 : (wait & 8u) ? 0x7fffffff : -1;
-        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
-        if (alive & 1u) l0 = lower(F0, tl0);
-        if (alive & 2u) l1 = lower(F1, tl1);
-        if (alive & 4u) l2 = lower(F2, tl2);
-        if (alive & 8u) l3 = lower(F3, tl3);
-        if (lane < kCntSlots)
-            cntp[h0 + lane] = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
-        const int cm = __builtin_amdgcn_readfirstlane(max(max(l0, l1), max(l2, l3)));
+            cm = max(cm, lo[q]);
+        }
+        if (lane < SLOTS) {
+            int mine = v[0];
+#pragma unroll
+            for (int q = 1; q < SLOTS; ++q)
+                mine = lane == q ? v[q] : mine;
+            cntp[h0 + lane] = mine;
+        }
+        cm = __builtin_amdgcn_readfirstlane(cm);
         if (cm > B) {
             B = cm;
             if (lane == 0) {
@@ -2099,6 +2085,8 @@ constexpr int kCntPpl = 2;         // 70 registers allow) against one workgroup 
 constexpr int kSolveBlock = 64;    // one wavefront per workgroup: every SIMD refills on its own (45.4 -> 44.5 ms, same bits)
 constexpr int kSplitMinPairs = 3;  // one or two pairs stay on the fused kernel (latency: fewer launches)
 
+constexpr int kCnt32Threads = 768;
+constexpr int kCnt32Slots = 4;     // hypotheses a wavefront carries at a time
 constexpr int kCnt32Ppl = 4;       // single-precision counting: four points per lane and block (scalar work per evaluation halves)
 static size_t count32_lds_bytes(int max_kp)
 {
@@ -2177,9 +2165,9 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.dynamic_lds = count_lds_bytes(max_kp);
         break;
     case kKRansacCount32:
-        d.name = "ransac_count32_kernel<768, 4>";
-        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCntThreads, kCnt32Ppl>);
-        d.threads = kCntThreads;
+        d.name = "ransac_count32_kernel<768, 4, 4>";
+        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots>);
+        d.threads = kCnt32Threads;
         d.dynamic_lds = count32_lds_bytes(max_kp);
         break;
     case kKRansacSurvivors:
@@ -2217,8 +2205,8 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl, true>),
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>),
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
-                         reinterpret_cast<const void *>(ransac_count32_kernel<kCntThreads, kCnt32Ppl>),
-                         reinterpret_cast<const void *>(ransac_count32_kernel<kCntThreads, kCnt32Ppl, true>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
@@ -2328,10 +2316,10 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     // at once for the pairs of the other kind)
     if (lt) lt->mark(kKRansacCount32);
     if (stats)
-        hipLaunchKernelGGL((ransac_count32_kernel<kCntThreads, kCnt32Ppl, true>), dim3(wg, n_active), dim3(kCntThreads), lds_c32,
-                           stream, b, rp, wg);
+        hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, true>), dim3(wg, n_active), dim3(kCnt32Threads),
+                           lds_c32, stream, b, rp, wg);
     else
-        hipLaunchKernelGGL((ransac_count32_kernel<kCntThreads, kCnt32Ppl>), dim3(wg, n_active), dim3(kCntThreads), lds_c32,
+        hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots>), dim3(wg, n_active), dim3(kCnt32Threads), lds_c32,
                            stream, b, rp, wg);
     if (lt) lt->mark(kKRansacCount2);
     if (stats)

@@ -54,7 +54,7 @@ MVS_DEV bool sample_norm(const double (&px)[8], const double (&py)[8], double &s
     for (int i = 0; i < 8; ++i) {
         const double dx = px[i] - mx, dy = py[i] - my;
         const double q = dx * dx + dy * dy;
-        tiny = tiny || (q != 0.0 && !sqrt_fast_ok(q));
+        tiny = tiny | ((q != 0.0) & !sqrt_fast_ok(q));   // bitwise: no branches in the normalisation
         sc += sqrt_fast(q);
     }
     sc *= 0.125;
@@ -203,7 +203,9 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     double rho2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        asm volatile("" : "+v"(idx[i]));
+        // opaque index, tied to the result of the previous stage: hoisted above the triangular inverse these sixteen loads
+        // were spilled to scratch memory as they arrived
+        asm volatile("" : "+v"(idx[i]) : "v"(yf));
         const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[i] * 4);
         const double a1 = (p.x - nm.m1x) * nm.s1, b1 = (p.y - nm.m1y) * nm.s1;   // normalise8's own operations: same bits
         const double a2 = (p.z - nm.m2x) * nm.s2, b2 = (p.w - nm.m2y) * nm.s2;

@@ -16,6 +16,7 @@ Per sample (8 point pairs, Hartley-normalised exactly like the exact path):
   delta  = w1 - w2 - eta - 2e-11      gap of the singular value that the rank-2 step removes
   dFn    = (2 + 2 (w2 + 3 eta) / delta) eta + 2e-11                        Wedin's sin-theta theorem
   band   = dFn N1 N2 (1 + 1e-9) + 64 u N1' N2'      N = max over the pair's points of ||T p||, N' with absolute values
+  e32    = 8 * 2^-24 * [X2 Y2 1] |F~| [X1 Y1 1]^T    single-precision evaluation of the residual (added to band there)
 """
 import numpy as np
 
@@ -113,10 +114,10 @@ def prescreen(x1, y1, x2, y2, bbox):
     rf = float(np.sqrt((R * R).sum()))
     if not np.isfinite(yf):
         return out
-    z = 8.1 * U * rf * yf
+    z = 12.0 * U * rf * yf
     if not (z < 0.5):
         return out
-    sig8 = (1.0 - z) / yf * (1 - 1e-13) - 1e-14 * np.sqrt(S)
+    sig8 = (1.0 - z) / yf * (1 - 1e-13) - 4e-14 * np.sqrt(S)
     if not (sig8 > 0):
         return out
     g = sig8 * sig8
@@ -144,7 +145,12 @@ def prescreen(x1, y1, x2, y2, bbox):
     N2p = np.sqrt(1 + s2 * s2 * (e2x * e2x + e2y * e2y))
     band = dfn * N1 * N2 * (1 + 1e-9) + 64 * U * N1p * N2p
     F = denormalise(Fn, s1, m1x, m1y, s2, m2x, m2y)
-    out.update(F=F, band=float(band), dfn=dfn, N=(N1, N2), Fn=Fn, screenable=bool(np.isfinite(band)))
+    # single-precision evaluation of the residual (ransac_count32_kernel): <= 8 roundings per term
+    X1, Y1 = max(abs(x1lo), abs(x1hi)), max(abs(y1lo), abs(y1hi))
+    X2, Y2 = max(abs(x2lo), abs(x2hi)), max(abs(y2lo), abs(y2hi))
+    T = np.array([X2, Y2, 1.0]) @ np.abs(F) @ np.array([X1, Y1, 1.0])
+    e32 = 8.0 * 2.0 ** -24 * T * (1 + 1e-6) + 1e-30
+    out.update(F=F, band=float(band), e32=float(e32), dfn=dfn, N=(N1, N2), Fn=Fn, screenable=bool(np.isfinite(band)))
     return out
 
 

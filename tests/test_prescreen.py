@@ -1,0 +1,104 @@
+"""The RANSAC pre-screen (mvslam_amd/csrc/prescreen.hpp): an approximate fundamental matrix per
+hypothesis with a certified bound on every match's residual against the exact (one-sided Jacobi) result, so that
+hypotheses which provably cannot win are never solved exactly -- and the winner is still the reference's, bit for bit.
+
+CPU part: tests/prescreen_model.py (the same arithmetic and the same constants in numpy) against the oracle's
+find_fundamental_matrix on random and adversarial samples: wherever the model certifies a band, the oracle's residuals lie
+within it.  GPU part: the device code itself, hypothesis by hypothesis, and the whole stage in every mode
+(tests/prescreen_gpu_check.py, its own process: the record reader lives in the diagnostics library)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+import prescreen_model as pm
+from mvslam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bbox(p1, p2):
+    return (p1[:, 0].min(), p1[:, 0].max(), p1[:, 1].min(), p1[:, 1].max(),
+            p2[:, 0].min(), p2[:, 0].max(), p2[:, 1].min(), p2[:, 1].max())
+
+
+def _check(p1, p2, idx, bbox, stats):
+    r = pm.prescreen(p1[idx, 0], p1[idx, 1], p2[idx, 0], p2[idx, 1], bbox)
+    ok, FJ = o.find_fundamental_matrix(p1[idx], p2[idx])
+    assert ok == r["ok"]
+    stats["n"] += 1
+    if not r["screenable"]:
+        return
+    stats["cert"] += 1
+    rj, ra = pm.residuals(FJ, p1, p2), pm.residuals(r["F"], p1, p2)
+    d = float(np.abs(rj - ra).max())
+    assert d <= r["band"], (d, r["band"])
+    stats["worst"] = max(stats["worst"], d / r["band"])
+    sv = np.linalg.svd(r["A"], compute_uv=False)
+    assert r["sig8_lb"] <= sv[7] * (1 + 1e-12)                      # a LOWER bound of sigma_8(A)
+    # the single-precision leg: residuals of the binary32-rounded F~ and points stay within band + e32 (the four fma
+    # roundings of the device's binary32 chain are part of e32's eight)
+    F32 = r["F"].astype(np.float32).astype(np.float64)
+    q1, q2 = p1.astype(np.float32).astype(np.float64), p2.astype(np.float32).astype(np.float64)
+    d32 = float(np.abs(rj - pm.residuals(F32, q1, q2)).max())
+    assert d32 <= r["band"] + 0.5 * r["e32"], (d32, r["band"], r["e32"])
+
+
+def test_model_band_covers_the_oracle_on_synthetic_pairs():
+    stats = dict(n=0, cert=0, worst=0.0)
+    for pi in range(2):
+        d = synth.make_pair(pi, n_kp=1000)
+        mt = o.match_visual_features(d["desc1"], d["desc2"], 0.7, 10.0)
+        p1 = o.normalize_points(d["K"], d["kp1"][mt["trainIdx"]].astype(np.float64))
+        p2 = o.normalize_points(d["K"], d["kp2"][mt["queryIdx"]].astype(np.float64))
+        bbox = _bbox(p1, p2)
+        for h in range(400):
+            _check(p1, p2, o.sample8(synth.SEED_BASE + pi, h, len(mt)), bbox, stats)
+    assert stats["cert"] > 0.9 * stats["n"]          # well-conditioned samples get a certificate ...
+    assert stats["worst"] < 1e-3                     # ... and the bound is conservative by orders of magnitude
+
+
+def test_model_band_on_adversarial_samples():
+    """near-degenerate samples: the model must either refuse a certificate or still cover the oracle"""
+    rng = np.random.default_rng(5)
+    stats = dict(n=0, cert=0, worst=0.0)
+    R = np.array([[0.9998, -0.01, 0.015], [0.0102, 0.9999, -0.004], [-0.0149, 0.0042, 0.9999]])
+    t = np.array([0.3, 0.02, 0.01])
+    for trial in range(300):
+        kind = trial % 6
+        n = 40
+        X = np.c_[rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n), rng.uniform(2, 10, n)]
+        if kind == 1:      # the sample almost collinear in image 1
+            X[:8, 1] = 0.3 * X[:8, 0] + 10.0 ** rng.uniform(-9, -2) * rng.normal(size=8)
+            X[:8, 2] = 4.0
+        if kind == 2:      # two sample points (nearly) identical
+            X[1] = X[0] + 10.0 ** rng.uniform(-12, -3) * rng.normal(size=3)
+        if kind == 3:      # the sample in a tiny cluster, the other points far away
+            X[:8] = X[0] + 10.0 ** rng.uniform(-6, -2) * rng.normal(size=(8, 3))
+        if kind == 4:      # coplanar scene (a degenerate configuration for F)
+            X[:, 2] = 5.0 + 10.0 ** rng.uniform(-8, -1) * rng.normal(size=n)
+        p1 = X[:, :2] / X[:, 2:3]
+        X2 = (R @ X.T).T + t
+        p2 = X2[:, :2] / X2[:, 2:3]
+        if kind == 5:      # pure outliers
+            p2 = rng.uniform(-0.5, 0.5, size=(n, 2))
+        p1 = p1 + rng.normal(scale=1e-3, size=p1.shape)
+        p2 = p2 + rng.normal(scale=1e-3, size=p2.shape)
+        _check(p1, p2, np.arange(8), _bbox(p1, p2), stats)
+    assert stats["n"] == 300 and stats["cert"] > 100
+
+
+@pytest.mark.gpu
+def test_device_prescreen_against_the_oracle_hypothesis_by_hypothesis():
+    env = dict(os.environ, MVS_USE_DEBUG_LIB="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "prescreen_gpu_check.py")], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    st = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert st["viol"] == 0 and st["count_viol"] == 0 and st["certified"] > 0.5 * st["hyp"]
+    assert st["mode0_list"] == [0, 0]                 # forced exact: nothing on the work list
+    assert st["mode1_list"][0] > 0 and st["auto_list"][0] > 0
