@@ -28,6 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector (v_pk_fma_f32: two FMAs per lane and instruction), MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the 157.3 TF fp32
 #                          vector rate of MI355X_MICROARCH.md; the fp64 MFMA dense peak is the same figure)
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -98,6 +99,10 @@ PER_HYP = 184 + 32 + 720 + 162 + 171 + 800 + 73   # normalise x2, A, A^T A, W in
 PER_PAIR9 = 21        # dot (9 fma) + threshold test
 PER_ROT9 = 172        # rotation angle (14) + 9 x (A rows 10 + V rows 6)
 PER_EVAL = 18         # 8 fma + compare + conditional add
+# the pre-screen of one hypothesis (prescreen.hpp): normalise x2 184, design row products + ||A||_F^2 112,
+# Householder QR of the 9x8 (392 fma + 44 fma for the norms + 8 sqrt + 8 div + 40) 920, null vector 176, triangular inverse
+# + its Frobenius norm 284, a-posteriori residual (second gather) 208, 3x3 SVD + rank-2 800, de-normalise 73, bounds 110
+PER_PRESCREEN = 184 + 112 + 920 + 176 + 284 + 208 + 800 + 73 + 110
 
 
 def solve_flops(stats):
@@ -175,46 +180,77 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
         e["occupancy_waves_per_simd"] = ki.get("waves_per_simd")
         if "build" in ki:
             e["vgprs"], e["agprs"], e["sgprs"] = ki["build"].get("vgprs"), ki["build"].get("agprs"), ki["build"].get("sgprs")
+    per_solve = solve_flops(stats) / max(stats["hypotheses"], 1)   # exact solve of one hypothesis, workload average
     for name, e in table.items():
         fl_exec = fl_alg = None
-        if name.startswith("ransac_solve_kernel"):
-            fl_exec = fl_alg = solve_flops(stats)
-        elif name.startswith("ransac_count_kernel"):
+        peak, bound = FP64_PEAK_TFLOPS, "valu_fp64"
+        if name.startswith("ransac_solve_kernel"):      # every hypothesis of the pairs in mode 0
+            fl_alg = solve_flops(stats)
+            fl_exec = per_solve * stats["pairs_mode"][0] * (stats["hypotheses"] / max(sum(stats["pairs_mode"]), 1)) \
+                if sum(stats["pairs_mode"]) else fl_alg
+        elif name.startswith("ransac_exact_list_kernel"):   # flagged by the pre-screen + survivors of the counting
+            mode0 = stats["pairs_mode"][0] * (stats["hypotheses"] / max(sum(stats["pairs_mode"]), 1))
+            fl_exec = fl_alg = per_solve * max(stats["exact_solves"] - mode0, 0)
+        elif name.startswith("ransac_prescreen_kernel"):
+            n_ps = stats["hypotheses"] - stats["pairs_mode"][0] * (stats["hypotheses"] / max(sum(stats["pairs_mode"]), 1))
+            fl_exec = fl_alg = n_ps * PER_PRESCREEN
+        elif name.startswith("ransac_count32_kernel"):
             fl_alg = stats["score_evals"] * PER_EVAL
-            fl_exec = stats["score_evals_executed"] * PER_EVAL
-            e["evals_executed_frac"] = round(stats["score_evals_executed"] / max(stats["score_evals"], 1), 4)
+            fl_exec = stats["score_evals_executed_f32"] * PER_EVAL
+            e["evals_executed_frac"] = round(stats["score_evals_executed_f32"] / max(stats["score_evals"], 1), 4)
+            peak, bound = FP32_PEAK_TFLOPS, "valu_fp32"
+        elif name.startswith("ransac_count_kernel") or name.startswith("ransac_count2_kernel"):
+            ev64 = stats["score_evals_executed"] - stats["score_evals_executed_f32"]
+            fl_alg = stats["score_evals"] * PER_EVAL
+            fl_exec = ev64 * PER_EVAL
+            e["evals_executed_frac"] = round(ev64 / max(stats["score_evals"], 1), 4)
         elif name.startswith("ransac_kernel"):   # fused: solve + every evaluation
             fl_exec = fl_alg = solve_flops(stats) + stats["score_evals"] * PER_EVAL
         if fl_exec is not None and e["ms"] > 0:
+            e["bound"], e["peak_tflops"] = bound, peak
             e["flops_executed"] = int(fl_exec)
             e["flops_algorithmic"] = int(fl_alg)
             e["tflops_executed"] = round(fl_exec / (e["ms"] * 1e-3) / 1e12, 3)
-            e["frac_executed"] = round(fl_exec / (e["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)
+            e["frac_executed"] = round(fl_exec / (e["ms"] * 1e-3) / 1e12 / peak, 4)
     return table
 
 
 def roofline_object(table, stats, traffic, traffic_src):
     """roofline of the DOMINANT kernel (executed work / its measured launch time) + the RANSAC stage as a whole."""
-    ransac = {k: v for k, v in table.items() if k.startswith("ransac_")}
+    ransac = {k: v for k, v in table.items() if k.startswith("ransac_") or k.startswith("pair_prepare")}
     dom_name = max(ransac, key=lambda k: ransac[k]["ms"]) if ransac else max(table, key=lambda k: table[k]["ms"])
     dom = table[dom_name]
     stage_ms = sum(v["ms"] for v in ransac.values())
     stage_exec = sum(v.get("flops_executed", 0) for v in ransac.values())
-    stage_alg = sum(v.get("flops_algorithmic", 0) for v in ransac.values())
+    # what the reference's algorithm asks for: every hypothesis solved exactly and scored on every match
+    stage_alg = solve_flops(stats) + stats["score_evals"] * PER_EVAL
     achieved = dom.get("tflops_executed", 0.0)
+    peak = dom.get("peak_tflops", FP64_PEAK_TFLOPS)
+    # peak-weighted time the executed work would take at the respective vector peaks
+    t_ideal = sum(v.get("flops_executed", 0) / (v.get("peak_tflops", FP64_PEAK_TFLOPS) * 1e12) for v in ransac.values()) * 1e3
     return {
-        "bound": "valu_fp64", "kernel": dom_name,
-        "bound_detail": "fp64 vector FMA rate: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s (no MFMA is "
-                        "issued: v_mfma_f64 shares the double-precision pipe, profiles/r02_mfma_coissue_microbench.txt)",
-        "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4),
-        "frac_definition": "EXECUTED algorithmic flops of the dominant kernel / its launch time (HIP events) / peak",
+        "bound": dom.get("bound", "valu_fp64"), "kernel": dom_name,
+        "bound_detail": "vector FMA rate of the kernel's arithmetic type: fp64 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = "
+                        "78.6 TFLOP/s (v_mfma_f64 shares the pipe: profiles/r02_mfma_coissue_microbench.txt), fp32 157.3 "
+                        "TFLOP/s (v_pk_fma_f32)",
+        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "frac_definition": "EXECUTED algorithmic flops of the dominant kernel / its launch time (HIP events) / the vector "
+                           "peak of its arithmetic type",
         "launch_ms": dom["ms"], "flops_per_launch": dom.get("flops_executed"),
         "traffic": traffic, "traffic_source": traffic_src,
         "stage": {"kernels": sorted(ransac), "ms": round(stage_ms, 3), "flops_executed": int(stage_exec),
-                  "frac_executed": round(stage_exec / max(stage_ms, 1e-9) / 1e9 / FP64_PEAK_TFLOPS, 4),
-                  "frac_algorithmic_equivalent": round(stage_alg / max(stage_ms, 1e-9) / 1e9 / FP64_PEAK_TFLOPS, 4),
-                  "note": "frac_algorithmic_equivalent also credits the (hypothesis, point) evaluations the pruned "
-                          "counting kernel provably skips; frac_executed does not"},
+                  "frac_executed": round(t_ideal / max(stage_ms, 1e-9), 4),
+                  "frac_executed_definition": "sum over the stage's kernels of executed flops / that kernel's vector peak, "
+                                              "divided by the stage's measured time",
+                  "reference_equivalent_flops": int(stage_alg),
+                  "reference_equivalent_tflops": round(stage_alg / max(stage_ms, 1e-9) / 1e9, 2),
+                  "note": "reference_equivalent_* price the stage as if every hypothesis had been solved exactly and scored "
+                          "on every match (what estimator-RANSAC.cpp does); the pre-screen and the pruned counting provably "
+                          "skip most of that work, so it is a speed-up figure, not a utilisation"},
+        "work": {"hypotheses": int(stats["hypotheses"]), "exact_solves": int(stats["exact_solves"]),
+                 "prescreened_only": int(stats["prescreened"]), "pairs_mode": stats["pairs_mode"],
+                 "evals_possible": int(stats["score_evals"]), "evals_executed": int(stats["score_evals_executed"]),
+                 "evals_executed_f32": int(stats["score_evals_executed_f32"])},
         "per_kernel": table,
         "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
                            "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"}

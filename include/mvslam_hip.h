@@ -258,8 +258,14 @@ typedef struct mvs_work_stats {
     int64_t score_evals;
     int64_t matches; /* sum of M */
     int64_t inliers; /* sum of n_inliers */
-    int64_t score_evals_executed; /* (hypothesis, point) evaluations the pruned counting kernel actually executed (incl. the
+    int64_t score_evals_executed; /* (hypothesis, point) evaluations the pruned counting kernels actually executed (incl. the
                                      NaN padding of a pair's last block); 0 when the batch runs on the fused kernel */
+    int64_t score_evals_executed_f32; /* the part of them evaluated in single precision (pairs in mode 1) */
+    int64_t exact_solves;         /* hypotheses that went through the exact (Jacobi) solve: every hypothesis of a pair in mode
+                                     0, + the ones the pre-screen could not certify, + the survivors of the counting */
+    int64_t prescreened;          /* hypotheses that only ever got the pre-screen's approximate F (never solved exactly) */
+    int64_t pairs_mode[3];        /* pairs per mode: 0 every hypothesis exact, 1 pre-screened + single-precision counting,
+                                     2 pre-screened + double-precision counting */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 

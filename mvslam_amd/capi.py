@@ -104,7 +104,8 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 
 class WorkStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers",
-                                              "score_evals_executed")]
+                                              "score_evals_executed", "score_evals_executed_f32", "exact_solves",
+                                              "prescreened")] + [("pairs_mode", C.c_int64 * 3)]
 
 
 class KernelInfo(C.Structure):
@@ -620,7 +621,9 @@ class Batch:
         ws = WorkStats()
         st = lib().mvs_batch_stats(self._h, C.byref(params), C.c_int(n_active or self.n_pairs), C.byref(ws))
         self.ctx._check(st, "mvs_batch_stats")
-        return {n: getattr(ws, n) for n, _ in WorkStats._fields_}
+        d = {n: getattr(ws, n) for n, _ in WorkStats._fields_ if n != "pairs_mode"}
+        d["pairs_mode"] = [int(x) for x in ws.pairs_mode]
+        return d
 
     def download(self, first=0, count=None, matches=True, mask=True, points=True):
         count = count or (self.n_pairs - first)

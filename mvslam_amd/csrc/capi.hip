@@ -1027,7 +1027,24 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     std::memset(out, 0, sizeof(*out));
     out->rotations9 = (int64_t)h[0];
     out->pairs9 = (int64_t)h[1];
-    out->score_evals_executed = (int64_t)h[2];
+    out->score_evals_executed = (int64_t)(h[2] + h[3]);   // double- + single-precision counting kernels
+    out->score_evals_executed_f32 = (int64_t)h[3];
+    if (b->d.mode && b->d.xcount && h[2] + h[3] > 0) {   // the pre-screened stage ran: its bookkeeping
+        std::vector<int32_t> mode(n_active);
+        uint32_t xc[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(mode.data(), b->d.mode, n_active * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(xc, b->d.xcount, sizeof(xc), hipMemcpyDeviceToHost));
+        int64_t legacy = 0, screened = 0;
+        for (int i = 0; i < n_active; ++i) {
+            if (res[i].n_matches < 8)
+                continue;
+            const int m = mode[i] < 0 || mode[i] > 2 ? 0 : mode[i];
+            out->pairs_mode[m] += 1;
+            (m == 0 ? legacy : screened) += params->num_hypotheses;
+        }
+        out->exact_solves = legacy + (int64_t)xc[0];
+        out->prescreened = screened - (int64_t)xc[0];
+    }
     for (const auto &r : res) {
         out->matches += r.n_matches;
         out->inliers += r.n_inliers;

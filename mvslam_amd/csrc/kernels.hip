@@ -1205,27 +1205,58 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count2_kernel(BatchDev b, 
 // (hypotheses without a certificate wait for the exact solve with an "infinite" count).
 typedef __attribute__((address_space(4))) float CFloat;
 
-// Plain v_fma_f32 with scalar operands: left to itself hipcc's SLP vectoriser packs pairs of these into v_pk_fma_f32, which
-// needs both operands in vector register PAIRS (200 v_mov per 192 packed FMAs in the kernel's text) and issues no faster than
-// two plain FMAs on this part.  This file is therefore compiled with -fno-slp-vectorize (Makefile; nothing else in it has
-// packable arithmetic).  Inline asm would do it too, but draws an s_nop in front of every dependent instruction: 2.5 per 64
-// evaluations on a kernel that is short of scalar issue slots.
-#define MVS_NO_PK_F32
+// Packed single precision.  A plain v_fma_f32 issues at the rate of v_fma_f64 on this part (16 lanes per clock and SIMD);
+// the fp32 vector peak is v_pk_fma_f32's: two FMAs per lane and instruction.  Each lane therefore carries TWO points per
+// packed register pair -- the LDS block is laid out so that (x2 of point l, x2 of point l + 64) arrive adjacent -- and F comes
+// straight out of the scalar registers the record was loaded into: op_sel picks the low or the high float of an aligned SGPR
+// pair for both halves, so nothing is duplicated or moved.  Written as inline asm: left to itself hipcc's SLP vectoriser does
+// emit v_pk_fma_f32, but with F splatted into vector register pairs first (200 v_mov per 192 packed FMAs; this file is built
+// with -fno-slp-vectorize).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) unsigned long long CU64;
 
-// F[0..5] end up in scalar registers, F[6..8] (the inner addends: an instruction takes one scalar operand) in vector registers
-__device__ __forceinline__ MVS_NO_PK_F32 int count_block32(const float (&F)[9], const float4 &p, float thr)
+// d = a * s.lo + c  /  d = a * s.hi + c  (both halves of a, c; s = an aligned scalar register pair holding two floats)
+__device__ __forceinline__ f32x2 pk_fma_slo(f32x2 a, unsigned long long s, f32x2 c)
 {
-    const float u0 = __builtin_fmaf(p.z, F[0], __builtin_fmaf(p.w, F[3], F[6]));
-    const float u1 = __builtin_fmaf(p.z, F[1], __builtin_fmaf(p.w, F[4], F[7]));
-    const float u2 = __builtin_fmaf(p.z, F[2], __builtin_fmaf(p.w, F[5], F[8]));
-    const float r = __builtin_fabsf(__builtin_fmaf(u0, p.x, __builtin_fmaf(u1, p.y, u2)));
-    return __popcll(__ballot(r < thr));   // NaN (padding lanes) compares false
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "s"(s), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_shi(f32x2 a, unsigned long long s, f32x2 c)
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "s"(s), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_vv(f32x2 a, f32x2 b, f32x2 c)
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+struct Rec32 {                 // one single-precision record as it sits in scalar registers
+    unsigned long long q01, q23, q45;   // (F0, F1), (F2, F3), (F4, F5)
+    f32x2 f6, f7, f8;                   // (F6, F6), (F7, F7), (F8, F8): the inner addends, in vector registers
+    float tu, tl;
+};
+
+// inliers among the 128 points a wavefront's lanes hold as two packed planes: A = (x1a, x1b, y1a, y1b), B = (x2a, x2b, y2a, y2b)
+__device__ __forceinline__ int count_pair32(const Rec32 &r, const float4 &A, const float4 &B, float thr)
+{
+    const f32x2 X1 = {A.x, A.y}, Y1 = {A.z, A.w}, X2 = {B.x, B.y}, Y2 = {B.z, B.w};
+    const f32x2 u0 = pk_fma_slo(X2, r.q01, pk_fma_shi(Y2, r.q23, r.f6));   // x2 F0 + (y2 F3 + F6)
+    const f32x2 u1 = pk_fma_shi(X2, r.q01, pk_fma_slo(Y2, r.q45, r.f7));   // x2 F1 + (y2 F4 + F7)
+    const f32x2 u2 = pk_fma_slo(X2, r.q23, pk_fma_shi(Y2, r.q45, r.f8));   // x2 F2 + (y2 F5 + F8)
+    const f32x2 e = pk_fma_vv(u0, X1, pk_fma_vv(u1, Y1, u2));
+    // NaN (padding lanes) compares false
+    return __popcll(__ballot(__builtin_fabsf(e.x) < thr)) + __popcll(__ballot(__builtin_fabsf(e.y) < thr));
 }
 
 template <int CNT_THREADS, int PPL, int SLOTS, bool STATS = false>
-__global__ __launch_bounds__(CNT_THREADS) MVS_NO_PK_F32 void ransac_count32_kernel(BatchDev b, RunParams rp, int wg_per_pair)
+__global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b, RunParams rp, int wg_per_pair)
 {
-    static_assert(SLOTS == 4 || SLOTS == 8, "state bytes are read one or two dwords at a time");
+    static_assert(SLOTS == 4 && PPL % 2 == 0, "four records per group; points come in packed pairs");
     extern __shared__ __attribute__((aligned(16))) double s_cpts[];
     __shared__ int s_bound;
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -1235,18 +1266,24 @@ __global__ __launch_bounds__(CNT_THREADS) MVS_NO_PK_F32 void ransac_count32_kern
     const int H = rp.num_hypotheses;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     constexpr int BW = 64 * PPL;                  // points per block
+    constexpr int NP = PPL / 2;                   // packed pairs per lane and block
     const int nblk = (M + BW - 1) / BW;
-    float4 *s_p = reinterpret_cast<float4 *>(s_cpts);
+    // LDS: [block][pair u][plane A / B][lane] float4; point i = blk * BW + u * 128 + half * 64 + lane sits in half `half`
+    float *s_f = reinterpret_cast<float *>(s_cpts);
     {
         const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
         const float qnan = __builtin_nanf("");
         for (int i = tid; i < nblk * BW; i += CNT_THREADS) {
-            float4 q = make_float4(qnan, qnan, qnan, qnan);
+            float x1 = qnan, y1 = qnan, x2 = qnan, y2 = qnan;
             if (i < M) {
                 const double4 p = src[i];
-                q = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.w);
+                x1 = (float)p.x; y1 = (float)p.y; x2 = (float)p.z; y2 = (float)p.w;
             }
-            s_p[i] = q;
+            const int blk = i / BW, w = i - blk * BW, u = w >> 7, half = (w >> 6) & 1, l = w & 63;
+            float *A = s_f + ((((size_t)blk * NP + u) * 2 + 0) * 64 + l) * 4;
+            float *Bp = s_f + ((((size_t)blk * NP + u) * 2 + 1) * 64 + l) * 4;
+            A[half] = x1; A[2 + half] = y1;
+            Bp[half] = x2; Bp[2 + half] = y2;
         }
     }
     int *gbound = b.bound + pair;
@@ -1256,50 +1293,47 @@ __global__ __launch_bounds__(CNT_THREADS) MVS_NO_PK_F32 void ransac_count32_kern
     const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
     const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
     int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
-    const float4 *L = s_p + lane;
+    const float4 *L = reinterpret_cast<const float4 *>(s_f) + lane;   // plane stride 64, pair stride 128, block stride 128 NP
     const int n_groups = (H + SLOTS - 1) / SLOTS;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_waves = wg_per_pair * (CNT_THREADS / 64);
-    constexpr int RF = kHypRec * 2;   // floats per record
     int B = 0;
     unsigned long long visits = 0;
     for (int g = blockIdx.x * (CNT_THREADS / 64) + wave; g < n_groups; g += n_waves) {
         const int h0 = g * SLOTS;
         const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
-        float F[SLOTS][9], tu[SLOTS], tl[SLOTS];
-        const CFloat *f = (const CFloat *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
+        Rec32 R[SLOTS];
+        const CU64 *f = (const CU64 *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                F[q][k] = f[q * RF + k];
-            tu[q] = f[q * RF + 9];
-            tl[q] = f[q * RF + 10];
-            // a v_fma_f32 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group
-#pragma unroll
-            for (int k = 6; k < 9; ++k)
-                asm volatile("" : "+v"(F[q][k]));
+            R[q].q01 = f[q * kHypRec + 0];
+            R[q].q23 = f[q * kHypRec + 1];
+            R[q].q45 = f[q * kHypRec + 2];
+            const unsigned long long q67 = f[q * kHypRec + 3], q8u = f[q * kHypRec + 4], ql = f[q * kHypRec + 5];
+            const float f6 = __uint_as_float((unsigned)q67), f7 = __uint_as_float((unsigned)(q67 >> 32));
+            const float f8 = __uint_as_float((unsigned)q8u);
+            R[q].f6 = f32x2{f6, f6};
+            R[q].f7 = f32x2{f7, f7};
+            R[q].f8 = f32x2{f8, f8};
+            R[q].tu = __uint_as_float((unsigned)(q8u >> 32));
+            R[q].tl = __uint_as_float((unsigned)ql);
         }
+        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
         unsigned alive = 0, wait = 0;
 #pragma unroll
-        for (int w4 = 0; w4 < SLOTS / 4; ++w4) {
-            const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g * (SLOTS / 4) + w4]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned st = (ok4 >> (8 * k)) & 0xffu;
-                const int q = w4 * 4 + k;
-                alive |= (st == kPsApprox && h0 + q < H) ? (1u << q) : 0u;
-                wait |= (st == kPsNeedExact && h0 + q < H) ? (1u << q) : 0u;
-            }
+        for (int k = 0; k < SLOTS; ++k) {
+            const unsigned st = (ok4 >> (8 * k)) & 0xffu;
+            alive |= (st == kPsApprox && h0 + k < H) ? (1u << k) : 0u;
+            wait |= (st == kPsNeedExact && h0 + k < H) ? (1u << k) : 0u;
         }
         int c[SLOTS];
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q)
             c[q] = 0;
-        float4 pa[PPL], pb[PPL];
+        float4 pa[PPL], pb[PPL];   // [2 u] = plane A, [2 u + 1] = plane B of packed pair u
         auto load = [&](float4 (&p)[PPL], int blk) {
-            const int nb = min(blk, nblk - 1) * BW;
+            const int nb = min(blk, nblk - 1) * (128 * NP);
 #pragma unroll
             for (int u = 0; u < PPL; ++u)
                 p[u] = L[nb + u * 64];
@@ -1308,13 +1342,32 @@ __global__ __launch_bounds__(CNT_THREADS) MVS_NO_PK_F32 void ransac_count32_kern
             const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
             if (STATS)
                 visits += (unsigned)__builtin_popcount(alive);
+            if (alive == (1u << SLOTS) - 1u) {
+                // all four alive (the usual state until they die together): one straight-line stretch, so that the
+                // scheduler interleaves the slots' independent FMA chains -- slot by slot behind uniform branches a
+                // wavefront has two short dependent chains in flight and the SIMD waits on latencies
+                int add[SLOTS];
 #pragma unroll
-            for (int q = 0; q < SLOTS; ++q) {
-                if (alive & (1u << q)) {
+                for (int q = 0; q < SLOTS; ++q) {
+                    add[q] = 0;
 #pragma unroll
-                    for (int u = 0; u < PPL; ++u)
-                        c[q] += count_block32(F[q], p[u], tu[q]);
-                    if (c[q] < need) alive &= ~(1u << q);
+                    for (int u = 0; u < NP; ++u)
+                        add[q] += count_pair32(R[q], p[2 * u], p[2 * u + 1], R[q].tu);
+                }
+#pragma unroll
+                for (int q = 0; q < SLOTS; ++q) {
+                    c[q] += add[q];
+                    alive &= (c[q] < need) ? ~(1u << q) : ~0u;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SLOTS; ++q) {
+                    if (alive & (1u << q)) {
+#pragma unroll
+                        for (int u = 0; u < NP; ++u)
+                            c[q] += count_pair32(R[q], p[2 * u], p[2 * u + 1], R[q].tu);
+                        if (c[q] < need) alive &= ~(1u << q);
+                    }
                 }
             }
         };
@@ -1339,8 +1392,8 @@ __global__ __launch_bounds__(CNT_THREADS) MVS_NO_PK_F32 void ransac_count32_kern
                 int cl = 0;
                 for (int blk = 0; blk < nblk; ++blk) {
 #pragma unroll
-                    for (int u = 0; u < PPL; ++u)
-                        cl += count_block32(F[q], L[blk * BW + u * 64], tl[q]);
+                    for (int u = 0; u < NP; ++u)
+                        cl += count_pair32(R[q], L[blk * (128 * NP) + (2 * u) * 64], L[blk * (128 * NP) + (2 * u + 1) * 64], R[q].tl);
                 }
                 if (STATS)
                     visits += (unsigned)nblk;
