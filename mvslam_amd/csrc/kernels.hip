@@ -922,7 +922,9 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
         const int n_s32 = __popcll(__ballot(live && flag == kPsApprox && band + e32 <= kPsBandFrac * thr));
         // 1: pre-screened, counted in single precision; 2: pre-screened, counted in double precision (the band is useful
         // at this threshold but single-precision evaluation is too coarse for it); 0: every hypothesis solved exactly
-        const int mode = n_ok == 0 ? 0 : 4 * n_s32 >= 3 * n_ok ? 1 : 4 * n_s64 >= 3 * n_ok ? 2 : 0;
+        // the pre-screen costs about a tenth of an exact solve, so it pays as soon as a fair share of the hypotheses gets
+        // a certificate (the others go to the exact solve either way): one third of the probe is asked for
+        const int mode = n_ok == 0 ? 0 : 3 * n_s32 >= n_ok ? 1 : 3 * n_s64 >= n_ok ? 2 : 0;
         if (lane == 0)
             b.mode[pair] = force_mode >= 0 ? force_mode : mode;
     }
