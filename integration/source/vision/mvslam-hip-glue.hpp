@@ -46,7 +46,8 @@ inline mvs_params two_view_params()
 
 inline void to_row_major(const Matrix3Type &M, double out[9])
 {
-    Eigen::Map<RowMajor3>(out) = M;
+    Eigen::Map<RowMajor3> view(out);   // (a temporary `Eigen::Map<RowMajor3>(out) = M;` parses as a DECLARATION of `out`:
+    view = M;                          // found by the syntax check of tests/test_integration_syntax.py)
 }
 inline Matrix3Type from_row_major(const double in[9])
 {
