@@ -329,6 +329,12 @@ int mvs_debug_set_ransac_variant(int v)
 }
 
 // diagnostics only: the per-hypothesis F records the solve launch handed to the scoring launch (pair `pair` of a batch)
+int mvs_debug_set_match_mfma(int v)
+{
+    set_match_mfma(v);
+    return MVS_OK;
+}
+
 int mvs_debug_set_prescreen_force(int m)
 {
     set_prescreen_force(m);

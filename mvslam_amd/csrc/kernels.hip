@@ -138,6 +138,145 @@ __global__ __launch_bounds__(1024) void match_topk_kernel(BatchDev b, double rat
 }
 
 // ---------------------------------------------------------------------------------------------
+// match_mfma (256-bit descriptors): the same 2-NN on the matrix cores.  Hamming(q, t) = |q| + |t| - 2 q.t with the bits as
+// {0, 1} int8: the all-pairs dot products of a pair are one [train x 256] . [256 x query] GEMM, exact in the i32
+// accumulators of v_mfma_i32_32x32x32_i8 (8 k-steps per 32 x 32 tile).  grid (ceil(N / 256), P), block 512 = 8 wavefronts;
+// wavefront w owns 32 queries (the MFMA's columns = lanes) whose unpacked bits stay in registers for the whole scan (the B
+// operand: 8 x 4 VGPRs); trains go by in tiles of 32 rows (the A operand), unpacked ONCE per workgroup into LDS (bit ->
+// byte: a nibble times 0x00204081, masked with 0x01010101, is its four bits as four bytes) and read by every wavefront
+// with ds_read_b128.  The accumulator tile has the query on the lane and 16 trains in the registers: key = ((|t| + 256) << 16
+// | index) - (dot << 17) is ONE v_mad_i32_i24 per element (the query's own popcount, equal for all its keys, is added at the
+// end; unique keys ordered like (distance, index), as in match_topk), inserted into the lane's running top-2 with v_min_u32 +
+// v_med3_u32.  Lanes l and l + 32 hold the same query over different rows and merge at the end.  Both operands take the
+// same (lane half, element) -> bit mapping, so the dot product does not depend on the k order inside a step.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMmThreads = 256;
+constexpr int kMmQpw = 64;                           // queries per wavefront: two 32-column blocks share every A fragment read
+constexpr int kMmQueries = kMmQpw * (kMmThreads / 64);   // 256 queries per workgroup
+constexpr int kMmRowBytes = 256 + 16;                // unpacked row of a train tile, padded: ds_read_b128 of 32 rows spread over the banks
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 16 bits -> 16 bytes of 0 / 1 (element j = bit j)
+__device__ __forceinline__ v4i unpack16(uint32_t bits)
+{
+    v4i r;
+    r.x = (int)((((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u);
+    r.y = (int)((((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u);
+    r.z = (int)((((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u);
+    r.w = (int)((((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+__global__ __launch_bounds__(kMmThreads) void match_mfma_kernel(BatchDev b, double ratio, double max_dist)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][32 * kMmRowBytes];   // unpacked train tiles (double buffer)
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[2][32];                        // (|t| + 256) << 16 | train index
+    __shared__ uint32_t s_k0[2][kMmThreads], s_k1[2][kMmThreads];
+    const int pair = blockIdx.y;
+    const int n1 = min(b.n1[pair], b.max_kp), n2 = min(b.n2[pair], b.max_kp);
+    const int q0 = blockIdx.x * kMmQueries;
+    if (q0 >= n2)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
+    const size_t base = (size_t)pair * b.max_kp;
+    // B operands: this lane's 16-bit slices of its two queries (column blocks 0 and 1), one per k-step, unpacked once
+    v4i Bf[2][8];
+    int qn[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int q = q0 + w * kMmQpw + c * 32 + col;
+        const uint32_t *qd = b.desc2 + (base + (q < n2 ? q : q0)) * 8;
+        const uint4 lo = *reinterpret_cast<const uint4 *>(qd), hi = *reinterpret_cast<const uint4 *>(qd + 4);
+        const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        qn[c] = 0;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            qn[c] += __popc(d[s8]);
+            Bf[c][s8] = unpack16(d[s8] >> (16 * half));
+        }
+    }
+    const uint32_t *tr = b.desc1 + base * 8;
+    // stage tile `t` (trains [32 t, 32 t + 32)) into buffer `buf`: thread = (row, dword): 32 bits -> 32 bytes
+    auto stage = [&](int t, int buf) {
+        const int row = tid >> 3, dw = tid & 7;
+        const int tr_i = t * 32 + row;
+        const uint32_t bits = tr_i < n1 ? tr[(size_t)tr_i * 8 + dw] : 0u;
+        unsigned char *dst = &s_tile[buf][row * kMmRowBytes + dw * 32];
+        *reinterpret_cast<v4i *>(dst) = unpack16(bits);
+        *reinterpret_cast<v4i *>(dst + 16) = unpack16(bits >> 16);
+        // the tile's key bases: |t| of the row, summed over its 8 dwords (8 adjacent lanes)
+        int tn = __popc(bits);
+        tn += __shfl_xor(tn, 1);
+        tn += __shfl_xor(tn, 2);
+        tn += __shfl_xor(tn, 4);
+        if (dw == 0)
+            s_key[buf][row] = tr_i < n1 ? (((uint32_t)(tn + 256) << 16) | (uint32_t)tr_i) : 0xffffffffu;
+    };
+    const int n_tiles = (n1 + 31) / 32;
+    uint32_t k0[2] = {kKeyNone, kKeyNone}, k1[2] = {kKeyNone, kKeyNone};
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles)
+            stage(t + 1, buf ^ 1);
+        v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        const unsigned char *arow = &s_tile[buf][col * kMmRowBytes + half * 16];   // A: row = lane & 31, k = 16 half + j
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const v4i Af = *reinterpret_cast<const v4i *>(arow + s8 * 32);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[0][s8], acc0, 0, 0, 0);   // two independent accumulation chains
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[1][s8], acc1, 0, 0, 0);
+        }
+        // accumulator: column = lane & 31 (this lane's query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (the train)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // registers 4 g4 .. 4 g4 + 3 are rows 8 g4 + 4 half + (0 .. 3): their key bases are 16 consecutive bytes
+            const v4i kb4 = *reinterpret_cast<const v4i *>(&s_key[buf][8 * g4 + 4 * half]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e, kb = kb4[e];
+                // key = kb - (dot << 17) (v_mad_i32_i24; exact: 0 <= dot <= 256); rows past the end have all-zero bits
+                // (dot = 0) and kb = 0xffffffff: never selected
+                key_insert(k0[0], k1[0], (uint32_t)(__mul24(acc0[r], -(1 << 17)) + kb));
+                key_insert(k0[1], k1[1], (uint32_t)(__mul24(acc1[r], -(1 << 17)) + kb));
+            }
+        }
+        __syncthreads();
+    }
+    // lanes l and l + 32 of a wavefront saw the same query over different rows: merge through LDS
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        s_k0[c][tid] = k0[c];
+        s_k1[c][tid] = k1[c];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int q = q0 + w * kMmQpw + c * 32 + col;
+            if (q >= n2)
+                continue;
+            uint32_t m0 = k0[c], m1 = k1[c];
+            key_insert(m0, m1, s_k0[c][tid + 32]);
+            key_insert(m0, m1, s_k1[c][tid + 32]);
+            // distance = (key >> 16) - 256 + |q|
+            const int D0 = m0 == kKeyNone ? 0x7fffffff : (int)(m0 >> 16) - 256 + qn[c];
+            const int D1 = m1 == kKeyNone ? 0x7fffffff : (int)(m1 >> 16) - 256 + qn[c];
+            const int I0 = m0 == kKeyNone ? -1 : (int)(m0 & 0xffffu);
+            // Lowe ratio in double on float distances (visual-feature.cpp:67-68)
+            const float f0 = (float)D0, f1 = (float)D1;
+            const bool check1 = (double)f0 < ratio * (double)f1;
+            const bool check2 = (max_dist < 0.0) || ((double)f0 <= max_dist);
+            const bool pass = (n1 >= 2) && check1 && check2;
+            b.knn_train[base + q] = pass ? I0 : -1;
+            b.knn_dist[base + q] = D0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // match_compact: grid P, block 1024.  Bitonic sort of the keys (distance << 16 | queryIdx) in LDS (unique keys,
 // rejected queries = 0xffffffff sort to the end) = the canonical (distance, queryIdx) order; then match m gathers its
 // two keypoints and applies K^-1.
@@ -2160,11 +2299,11 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
     KernelDesc d{nullptr, nullptr, 0, 0};
     switch (id) {
     case kKMatchTopk:
-        d.name = desc_words == 4 ? "match_topk_kernel<4>" : desc_words == 16 ? "match_topk_kernel<16>" : "match_topk_kernel<8>";
+        d.name = desc_words == 4 ? "match_topk_kernel<4>" : desc_words == 16 ? "match_topk_kernel<16>" : "match_mfma_kernel";
         d.fn = desc_words == 4    ? reinterpret_cast<const void *>(match_topk_kernel<4>)
                : desc_words == 16 ? reinterpret_cast<const void *>(match_topk_kernel<16>)
-                                  : reinterpret_cast<const void *>(match_topk_kernel<8>);
-        d.threads = 1024;
+                                  : reinterpret_cast<const void *>(match_mfma_kernel);
+        d.threads = desc_words == 8 ? kMmThreads : 1024;
         break;
     case kKMatchCompact:
         d.name = "match_compact_kernel";
@@ -2271,6 +2410,9 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
+static int g_match_mfma = 1;   // diagnostics: 0 = the VALU kernel for 256-bit descriptors too
+void set_match_mfma(int v) { g_match_mfma = v; }
+
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt)
 {
     const dim3 grid((b.max_kp + 63) / 64, n_active), block(1024);
@@ -2278,7 +2420,13 @@ void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hip
     if (lt) lt->mark(kKMatchTopk);
     switch (b.desc_words) {
     case 4: hipLaunchKernelGGL(match_topk_kernel<4>, grid, block, 0, stream, b, ratio, md); break;
-    case 8: hipLaunchKernelGGL(match_topk_kernel<8>, grid, block, 0, stream, b, ratio, md); break;
+    case 8:
+        if (g_match_mfma)
+            hipLaunchKernelGGL(match_mfma_kernel, dim3((b.max_kp + kMmQueries - 1) / kMmQueries, n_active), dim3(kMmThreads), 0,
+                               stream, b, ratio, md);
+        else
+            hipLaunchKernelGGL(match_topk_kernel<8>, grid, block, 0, stream, b, ratio, md);
+        break;
     case 16: hipLaunchKernelGGL(match_topk_kernel<16>, grid, block, 0, stream, b, ratio, md); break;
     default: break;
     }
