@@ -8,6 +8,7 @@
 #include <math/utility.hpp>
 
 #include <cassert>
+#include <iostream>
 
 #include "mvslam-hip-glue.hpp"
 
@@ -29,8 +30,13 @@ VisualFeature::extract(const ImageGrayscale &image)
     int32_t n = 0;
     const mvs_status st = mvs_extract(hip::context(), img.data, 1, img.cols, img.rows, &prm,
                                       reinterpret_cast<mvs_keypoint *>(vf.m_keypoints.data()), vf.m_descriptors.data, &n);
-    if (st != MVS_OK)
+    if (st != MVS_OK) {
+        // the reference's extract cannot fail; an empty feature set alone would hide a device error behind
+        // "valid() == false": say what happened on the reference's own diagnostics channel (std::clog, base/debug.cpp:4-7)
+        std::clog << "[VisualFeature::extract] mvs_extract failed: " << mvs_status_str(st) << " ("
+                  << mvs_last_error(hip::context()) << ")" << std::endl;
         n = 0;
+    }
     vf.m_keypoints.resize(n);
     vf.m_descriptors = vf.m_descriptors.rowRange(0, n).clone();
     vf.m_image_width = image.cols;

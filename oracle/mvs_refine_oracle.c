@@ -291,9 +291,11 @@ static double prior_cost(const ba_problem *P, const double R[2][9], const double
     return c;
 }
 
-/* in-place Cholesky of the lower triangle (packed); returns 0 if not positive definite.  The diagonal holds 1 / l_jj:
- * one division per column, every other "divide by l_jj" (here and in chol_solve) is a multiplication by it -- the
- * kernel's form (a correctly rounded f64 division is ~30 instructions on the device, and there were 90 per solve) */
+/* in-place Cholesky of the lower triangle (packed); returns 0 if not positive definite.  Textbook form: the diagonal
+ * holds l_jj and every "divide by l_jj" is a division.  (The device kernel stores 1 / l_jj and multiplies -- a correctly
+ * rounded f64 division is ~30 instructions there; round 2 had copied that form into this file, which made the checker
+ * follow the implementation.  The two forms differ by an ulp here and there; the refinement tests compare with a stated
+ * tolerance, 1e-10 on poses, not bitwise.) */
 static int chol_packed(double *S, int n)
 {
     for (int j = 0; j < n; ++j) {
@@ -302,13 +304,13 @@ static int chol_packed(double *S, int n)
             d = fma(-S[LIDX(j, k)], S[LIDX(j, k)], d);
         if (!(d > 0.0) || !isfinite(d))
             return 0;
-        double inv = 1.0 / sqrt(d);
-        S[LIDX(j, j)] = inv;
+        const double l = sqrt(d);
+        S[LIDX(j, j)] = l;
         for (int i = j + 1; i < n; ++i) {
             double v = S[LIDX(i, j)];
             for (int k = 0; k < j; ++k)
                 v = fma(-S[LIDX(i, k)], S[LIDX(j, k)], v);
-            S[LIDX(i, j)] = v * inv;
+            S[LIDX(i, j)] = v / l;
         }
     }
     return 1;
@@ -319,13 +321,13 @@ static void chol_solve(const double *Lc, int n, double *b)
         double v = b[i];
         for (int k = 0; k < i; ++k)
             v = fma(-Lc[LIDX(i, k)], b[k], v);
-        b[i] = v * Lc[LIDX(i, i)];
+        b[i] = v / Lc[LIDX(i, i)];
     }
     for (int i = n - 1; i >= 0; --i) {
         double v = b[i];
         for (int k = i + 1; k < n; ++k)
             v = fma(-Lc[LIDX(k, i)], b[k], v);
-        b[i] = v * Lc[LIDX(i, i)];
+        b[i] = v / Lc[LIDX(i, i)];
     }
 }
 
