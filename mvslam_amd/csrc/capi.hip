@@ -240,20 +240,26 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if ((st = dev_alloc(b, &ho, P * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &hc, P * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &xl, P * Hp)) != MVS_OK) return st;
+    uint32_t *cl = nullptr;
+    if ((st = dev_alloc(b, &cl, P * Hp)) != MVS_OK) return st;
     if (!b->d.bound && (st = dev_alloc(b, &b->d.bound, P)) != MVS_OK) return st;
     if (!b->d.box && (st = dev_alloc(b, &b->d.box, P * 8)) != MVS_OK) return st;
     if (!b->d.mode && (st = dev_alloc(b, &b->d.mode, P)) != MVS_OK) return st;
+    if (!b->d.dense_n1 && (st = dev_alloc(b, &b->d.dense_n1, P)) != MVS_OK) return st;
+    if (!b->d.ccount && (st = dev_alloc(b, &b->d.ccount, P)) != MVS_OK) return st;
     if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 2)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
     dev_release(b, b->d.hyp_F);
     dev_release(b, b->d.hyp_okf);
     dev_release(b, b->d.hyp_cnt);
     dev_release(b, b->d.xlist);
+    dev_release(b, b->d.clist);
     b->d.wgbest = p;
     b->d.hyp_F = hf;
     b->d.hyp_okf = ho;
     b->d.hyp_cnt = hc;
     b->d.xlist = xl;
+    b->d.clist = cl;
     b->d.max_groups = G;
     return MVS_OK;
 }
@@ -329,6 +335,12 @@ int mvs_debug_set_ransac_variant(int v)
 }
 
 // diagnostics only: the per-hypothesis F records the solve launch handed to the scoring launch (pair `pair` of a batch)
+int mvs_debug_set_count_dense(int v)
+{
+    set_count_dense(v);
+    return MVS_OK;
+}
+
 int mvs_debug_set_match_mfma(int v)
 {
     set_match_mfma(v);
@@ -577,6 +589,9 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.bound = nullptr;
     d.box = nullptr;
     d.mode = nullptr;
+    d.dense_n1 = nullptr;
+    d.clist = nullptr;
+    d.ccount = nullptr;
     d.xlist = nullptr;
     d.xcount = nullptr;
     d.hyp_count = nullptr;

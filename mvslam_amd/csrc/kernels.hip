@@ -168,7 +168,8 @@ __device__ __forceinline__ v4i unpack16(uint32_t bits)
     return r;
 }
 
-__global__ __launch_bounds__(kMmThreads) void match_mfma_kernel(BatchDev b, double ratio, double max_dist)
+__global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void match_mfma_kernel(BatchDev b, double ratio,
+                                                                                                            double max_dist)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][32 * kMmRowBytes];   // unpacked train tiles (double buffer)
     __shared__ __attribute__((aligned(16))) uint32_t s_key[2][32];                        // (|t| + 256) << 16 | train index
@@ -995,8 +996,10 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
     const int M = min(b.M[pair], b.max_kp);
     if (pair == 0 && tid < 2)
         b.xcount[tid] = 0u;
-    if (tid == 0)
+    if (tid == 0) {
         b.bound[pair] = 0;
+        b.ccount[pair] = 0;
+    }
     if (M < 8) {
         if (tid == 0)
             b.mode[pair] = 0;
@@ -1394,7 +1397,12 @@ __device__ __forceinline__ int count_pair32(const Rec32 &r, const float4 &A, con
     return __popcll(__ballot(__builtin_fabsf(e.x) < thr)) + __popcll(__ballot(__builtin_fabsf(e.y) < thr));
 }
 
-template <int CNT_THREADS, int PPL, int SLOTS, bool STATS = false>
+constexpr int kPilotHyp = 256;   // hypotheses of a pair the pilot counts in full
+// phase: 0 = the PILOT (hypotheses [0, kPilotHyp) counted in full: their best lower bound is the pair's first bound, from
+// which the dense phase derives how many points it has to look at); 2 = the FINISH (every hypothesis resumes behind the
+// points[0, n1) the dense matrix-core phase has already counted: hyp_cnt holds that partial upper-bound count); 1 = everything
+// in one go (no dense phase)
+template <int CNT_THREADS, int PPL, int SLOTS, int phase, bool STATS = false>
 __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b, RunParams rp, int wg_per_pair)
 {
     static_assert(SLOTS == 4 && PPL % 2 == 0, "four records per group; points come in packed pairs");
@@ -1404,11 +1412,19 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
     const int M = min(b.M[pair], b.max_kp);
     if (M < 8 || b.mode[pair] != 1)
         return;
-    const int H = rp.num_hypotheses;
+    const int Hall = rp.num_hypotheses;
+    const int H = phase == 0 ? min(Hall, kPilotHyp) : Hall;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     constexpr int BW = 64 * PPL;                  // points per block
     constexpr int NP = PPL / 2;                   // packed pairs per lane and block
     const int nblk = (M + BW - 1) / BW;
+    // points [0, n1) were counted by the dense phase (n1 = dense_points(M, the pilot's bound), a multiple of 32): the finish
+    // starts in the block that holds point n1 and blanks the points before it
+    const int n1 = phase == 2 ? b.dense_n1[pair] : 0;
+    const int blk0 = n1 / BW;
+    // phase 2 works through the pair's list of hypotheses the dense phase left alive, four list entries per group
+    const uint32_t *clist = b.clist + (size_t)pair * Hp;
+    const int n_list = phase == 2 ? b.ccount[pair] : 0;
     // LDS: [block][pair u][plane A / B][lane] float4; point i = blk * BW + u * 128 + half * 64 + lane sits in half `half`
     float *s_f = reinterpret_cast<float *>(s_cpts);
     {
@@ -1435,7 +1451,7 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
     const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
     int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
     const float4 *L = reinterpret_cast<const float4 *>(s_f) + lane;   // plane stride 64, pair stride 128, block stride 128 NP
-    const int n_groups = (H + SLOTS - 1) / SLOTS;
+    const int n_groups = phase == 2 ? (n_list + SLOTS - 1) / SLOTS : (H + SLOTS - 1) / SLOTS;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_waves = wg_per_pair * (CNT_THREADS / 64);
     int B = 0;
@@ -1444,14 +1460,28 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
         const int h0 = g * SLOTS;
         const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
+        // the four hypotheses of the group: consecutive ones, or (finish) four entries of the list
+        int hq[SLOTS];
+        if (phase == 2) {
+            const uint32_t mine = lane < SLOTS && h0 + lane < n_list ? clist[h0 + lane] : 0u;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q)
+                hq[q] = __builtin_amdgcn_readlane((int)mine, q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q)
+                hq[q] = h0 + q;
+        }
         Rec32 R[SLOTS];
-        const CU64 *f = (const CU64 *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            R[q].q01 = f[q * kHypRec + 0];
-            R[q].q23 = f[q * kHypRec + 1];
-            R[q].q45 = f[q * kHypRec + 2];
-            const unsigned long long q67 = f[q * kHypRec + 3], q8u = f[q * kHypRec + 4], ql = f[q * kHypRec + 5];
+            // (one base + constant offsets when the four records are neighbours: the loads coalesce)
+            const CU64 *f = phase == 2 ? (const CU64 *)(uintptr_t)(Fp + (size_t)hq[q] * kHypRec)
+                                       : (const CU64 *)(uintptr_t)(Fp + (size_t)h0 * kHypRec) + q * kHypRec;
+            R[q].q01 = f[0];
+            R[q].q23 = f[1];
+            R[q].q45 = f[2];
+            const unsigned long long q67 = f[3], q8u = f[4], ql = f[5];
             const float f6 = __uint_as_float((unsigned)q67), f7 = __uint_as_float((unsigned)(q67 >> 32));
             const float f8 = __uint_as_float((unsigned)q8u);
             R[q].f6 = f32x2{f6, f6};
@@ -1460,24 +1490,48 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
             R[q].tu = __uint_as_float((unsigned)(q8u >> 32));
             R[q].tl = __uint_as_float((unsigned)ql);
         }
-        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
         unsigned alive = 0, wait = 0;
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const unsigned st = (ok4 >> (8 * k)) & 0xffu;
-            alive |= (st == kPsApprox && h0 + k < H) ? (1u << k) : 0u;
-            wait |= (st == kPsNeedExact && h0 + k < H) ? (1u << k) : 0u;
-        }
         int c[SLOTS];
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q)
             c[q] = 0;
+        if (phase == 2) {
+            // resume: every listed hypothesis is an approximate record; the dense phase left its upper-bound count over
+            // points [0, n1) in hyp_cnt.  A slot that cannot reach the bound (it may have risen since the list was
+            // written) even if every remaining point were an inlier is dead on arrival
+            const int have = lane < SLOTS && h0 + lane < n_list ? cntp[clist[h0 + lane]] : 0;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                c[q] = __builtin_amdgcn_readlane(have, q);
+                if (h0 + q < n_list && !(c[q] + (M - n1) < B))
+                    alive |= 1u << q;
+            }
+        } else {
+            const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k) {
+                const unsigned st = (ok4 >> (8 * k)) & 0xffu;
+                alive |= (st == kPsApprox && h0 + k < H) ? (1u << k) : 0u;
+                wait |= (st == kPsNeedExact && h0 + k < H) ? (1u << k) : 0u;
+            }
+        }
         float4 pa[PPL], pb[PPL];   // [2 u] = plane A, [2 u + 1] = plane B of packed pair u
         auto load = [&](float4 (&p)[PPL], int blk) {
             const int nb = min(blk, nblk - 1) * (128 * NP);
 #pragma unroll
             for (int u = 0; u < PPL; ++u)
                 p[u] = L[nb + u * 64];
+            if (blk == blk0 && n1 > blk0 * BW) {
+                // the dense phase has already counted the points of this block below n1: blank them (NaN is no inlier).
+                // p[2 u] / p[2 u + 1] hold points blk BW + 128 u + lane (x, z components) and + 64 (y, w components)
+                const float qnan = __builtin_nanf("");
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int i0 = blk * BW + u * 128 + lane;
+                    if (i0 < n1) { p[2 * u].x = qnan; p[2 * u + 1].x = qnan; }
+                    if (i0 + 64 < n1) { p[2 * u].y = qnan; p[2 * u + 1].y = qnan; }
+                }
+            }
         };
         auto process = [&](const float4 (&p)[PPL], int blk) {
             const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
@@ -1512,8 +1566,9 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
                 }
             }
         };
-        load(pa, 0);
-        for (int blk = 0; blk < nblk && alive; blk += 2) {
+        if (alive)
+            load(pa, blk0);
+        for (int blk = blk0; blk < nblk && alive; blk += 2) {
             load(pb, blk + 1);
             process(pa, blk);
             if (!(blk + 1 < nblk && alive))
@@ -1542,12 +1597,14 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
             }
             cm = max(cm, lo[q]);
         }
-        if (lane < SLOTS) {
-            int mine = v[0];
+        if (lane < SLOTS && (phase != 2 || h0 + lane < n_list)) {
+            int mine = v[0], where = hq[0];
 #pragma unroll
-            for (int q = 1; q < SLOTS; ++q)
+            for (int q = 1; q < SLOTS; ++q) {
                 mine = lane == q ? v[q] : mine;
-            cntp[h0 + lane] = mine;
+                where = lane == q ? hq[q] : where;
+            }
+            cntp[where] = mine;
         }
         cm = __builtin_amdgcn_readfirstlane(cm);
         if (cm > B) {
@@ -1561,6 +1618,170 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
     }
     if (STATS && lane == 0 && b.stats)
         atomicAdd(&b.stats[3], visits * (unsigned long long)BW);   // executed single-precision evaluations
+}
+
+// ---- dense counting on the matrix cores --------------------------------------------------------------------------------
+// The residuals of a block of points under a block of hypotheses are one GEMM: r[i][h] = Phi(point i) . F~(h) with the nine
+// monomials Phi = (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1).  v_mfma_f32_32x32x2_f32 (exact binary32, bitwise an fmaf
+// chain over k) does 32 points x 32 hypotheses x 2 monomials per instruction -- five per tile against 84 vector + scalar
+// instructions of ransac_count32_kernel for the same 1024 evaluations, which is bound by instruction issue.  A tile cannot drop
+// single hypotheses, so this phase takes NO exit tests: it counts points [0, n1) for every approximate record, where
+//     n1 = dense_points(M, B0) = the multiple of 256 that covers M - B0 + 32 points, clamped to [0, M rounded down],
+// B0 = the bound the PILOT (the first kPilotHyp hypotheses counted in full by ransac_count32_kernel) has established: a
+// hypothesis cannot be dropped before M - B points have been seen, so nothing is wasted except on the few per cent that go on.
+// ransac_count32_kernel then resumes behind n1 for the hypotheses that can still reach the bound.
+// Wavefront = 32 hypotheses (the B operand: 5 VGPRs, loaded once) x all point tiles (A operand: the lane's point from LDS, its
+// monomials formed in registers); the accumulator tile has the hypothesis on the lane and 16 points in the registers:
+// v_cmp + v_addc count per lane against the hypothesis' own upper threshold.
+constexpr int kDenseThreads = 256;   // 4 wavefronts x 32 hypotheses
+constexpr int kDenseChunk = 512;     // points staged per pass (multiple of 32): 32 KB of monomials
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int dense_points(int M, int B0)
+{
+    const int want = ((M - B0 + 32 + 31) / 32) * 32;
+    return max(0, min(want, (M / 32) * 32));
+}
+
+// the five MFMAs of one 32-point tile against the wavefront's 32 hypotheses; m = the lane's five monomials
+__device__ __forceinline__ v16f dense_tile(const float (&m)[5], const float (&Bf)[5])
+{
+    v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], Bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[1], Bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[2], Bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[3], Bf[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[4], Bf[4], acc, 0, 0, 0);
+    return acc;
+}
+
+// Counting without compares: for a pair of accumulators a, ind = clamp((T2 - a * a) * 2^100) is 1 when a^2 < T2 and 0 when
+// a^2 >= T2 (the product with 2^100 is >= 1 as soon as the difference is one ulp of T2 >= 2^-79), so the per-lane count is a
+// float sum of indicators: v_pk_mul_f32, v_pk_fma_f32 with the clamp bit, v_pk_add_f32 -- three packed instructions per TWO
+// accumulators, no scalar registers, no wait states (v_cmp + v_addc is two per accumulator plus an s_nop each).  T2 =
+// tu^2 (1 + 2^-21): every |a| < tu is counted whatever the rounding of a * a; an |a| a hair above tu may be counted too, which
+// an UPPER bound of the count can afford.  Counts stay below 2^24: exact in binary32.
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_ind(f32x2 sq, f32x2 negH, f32x2 t2H)   // clamp(sq * (-2^100) + T2 * 2^100)
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(sq), "v"(negH), "v"(t2H));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void dense_count(const v16f &acc, f32x2 negH, f32x2 t2H, f32x2 &cnt)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = {acc[r], acc[r + 1]};
+        cnt = pk_add(cnt, pk_ind(pk_mul(a, a), negH, t2H));
+    }
+}
+
+// amdgpu_waves_per_eu(4, 8): with the default register budget of a 256-thread kernel hipcc puts the MFMA results into
+// accumulation registers and reads every one back with v_accvgpr_read before it can be used (16 more vector
+// instructions per tile)
+template <bool STATS>
+__global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_count_mfma_kernel(BatchDev b,
+                                                                                                                    RunParams rp)
+{
+    // LDS: the monomials of points [0, n1), [point][lane half][5 + 3 pad] floats: the lane's A operands of a tile are one
+    // ds_read_b128 + one ds_read_b32, no selects (half 0: x2 x1, x2, y2 y1, x1, 1; half 1: x2 y1, y2 x1, y2, y1, 0)
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8 || b.mode[pair] != 1)
+        return;
+    const int B0 = b.bound[pair];   // final since the pilot launch has completed
+    const int n1 = dense_points(M, B0);
+    if (blockIdx.x == 0 && tid == 0)
+        b.dense_n1[pair] = n1;
+    const int H = rp.num_hypotheses;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    float *s_m = reinterpret_cast<float *>(s_cpts);
+    const int hw = (blockIdx.x * (kDenseThreads / 64) + w) * 32;   // first hypothesis of the wavefront
+    const bool wave_live = hw < H;
+    const int h = hw + col;    // this lane's hypothesis (both lane halves)
+    const size_t rec = (size_t)pair * Hp + (wave_live ? h : 0);
+    const int st = (wave_live && h < H) ? (int)b.hyp_okf[rec] : kPsInvalid;
+    // B operand: F~[k] of the lane's hypothesis for k = 2 s + half, s = 0 .. 4 (k = 9: zero)
+    const float *fr = reinterpret_cast<const float *>(b.hyp_F + rec * kHypRec);
+    float Bf[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+        const int k = 2 * s5 + half;
+        Bf[s5] = (st == kPsApprox && k < 9) ? fr[k] : 0.f;
+    }
+    const float tu = st == kPsApprox ? fr[9] : 0.f;
+    const float t2h = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
+    const f32x2 negH = {-0x1p100f, -0x1p100f}, t2H = {t2h, t2h};
+    f32x2 cntf = {0.f, 0.f};
+    auto monomials = [&](int p0, float (&m)[5]) {
+        const float *q = s_m + ((size_t)(p0 + col) * 2 + half) * 8;
+        const float4 v = *reinterpret_cast<const float4 *>(q);
+        m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+        m[4] = q[4];
+    };
+    const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+    for (int c0 = 0; c0 < n1; c0 += kDenseChunk) {   // the points go through LDS in chunks (32 KB: several workgroups per CU)
+        const int nc = min(kDenseChunk, n1 - c0);
+        __syncthreads();
+        for (int i = tid; i < nc; i += kDenseThreads) {
+            const double4 pd = src[c0 + i];
+            const float x1 = (float)pd.x, y1 = (float)pd.y, x2 = (float)pd.z, y2 = (float)pd.w;
+            float4 *q = reinterpret_cast<float4 *>(s_m + (size_t)i * 16);
+            q[0] = make_float4(x2 * x1, x2, y2 * y1, x1);
+            q[1] = make_float4(1.f, 0.f, 0.f, 0.f);
+            q[2] = make_float4(x2 * y1, y2 * x1, y2, y1);
+            q[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (!wave_live)
+            continue;
+        // software pipeline: the MFMAs of tile t + 1 are issued before tile t's accumulators are counted
+        float m[5];
+        monomials(0, m);
+        v16f cur = dense_tile(m, Bf);
+        for (int p0 = 32; p0 < nc; p0 += 32) {
+            monomials(p0, m);
+            const v16f nxt = dense_tile(m, Bf);
+            dense_count(cur, negH, t2H, cntf);   // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
+            cur = nxt;
+        }
+        dense_count(cur, negH, t2H, cntf);
+    }
+    if (!wave_live)
+        return;
+    int cnt = (int)(cntf.x + cntf.y);
+    cnt += __shfl_xor(cnt, 32);   // the two lane halves hold different points of the same hypothesis
+    if (half == 0 && h < H)
+        b.hyp_cnt[rec] = st == kPsApprox ? cnt : st == kPsNeedExact ? 0x7fffffff : -1;
+    // hypotheses that can still reach the pilot's bound go on the pair's list for the finish
+    const bool go = half == 0 && st == kPsApprox && !(cnt + (M - n1) < B0);
+    const unsigned long long mm = __ballot(go);
+    if (mm) {
+        int base = 0;
+        if (lane == 0)
+            base = atomicAdd(&b.ccount[pair], __popcll(mm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (go)
+            b.clist[(size_t)pair * Hp + base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)h;
+    }
+    if (STATS && b.stats) {
+        const unsigned long long ma = __ballot(st == kPsApprox && half == 0);
+        if (lane == 0 && ma)
+            atomicAdd(&b.stats[3], (unsigned long long)__popcll(ma) * (unsigned long long)n1);
+    }
 }
 
 // approximate records whose upper-bound count reaches the pair's final bound: they may be the winner, so they get their
@@ -2359,10 +2580,16 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.dynamic_lds = count_lds_bytes(max_kp);
         break;
     case kKRansacCount32:
-        d.name = "ransac_count32_kernel<768, 4, 4>";
-        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots>);
+        d.name = "ransac_count32_kernel<768, 4, 4, 1, false>";
+        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>);
         d.threads = kCnt32Threads;
         d.dynamic_lds = count32_lds_bytes(max_kp);
+        break;
+    case kKRansacCountMfma:
+        d.name = "ransac_count_mfma_kernel<false>";
+        d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>);
+        d.threads = kDenseThreads;
+        d.dynamic_lds = (size_t)kDenseChunk * 16 * sizeof(float);
         break;
     case kKRansacSurvivors:
         d.name = "ransac_survivors_kernel";
@@ -2399,8 +2626,14 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl, true>),
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>),
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
-                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots>),
-                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, true>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1, true>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2, true>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
@@ -2486,6 +2719,8 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
+static int g_count_dense = 0;   // diagnostics: 1 = pilot + dense matrix-core phase + finish instead of one counting launch
+void set_count_dense(int v) { g_count_dense = v; }
 static int g_force_mode = -1;   // diagnostics: -1 = the probe decides, 0 / 1 = every pair exact / pre-screened
 void set_prescreen_force(int m) { g_force_mode = m; }
 
@@ -2517,13 +2752,45 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     const size_t lds_cnt = count_lds_bytes(b.max_kp), lds_c32 = count32_lds_bytes(b.max_kp);
     // counting: single precision for the pairs in mode 1, double precision for the others (each launch's workgroups leave
     // at once for the pairs of the other kind)
-    if (lt) lt->mark(kKRansacCount32);
-    if (stats)
-        hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, true>), dim3(wg, n_active), dim3(kCnt32Threads),
-                           lds_c32, stream, b, rp, wg);
-    else
-        hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots>), dim3(wg, n_active), dim3(kCnt32Threads), lds_c32,
-                           stream, b, rp, wg);
+    // single-precision counting of the pairs in mode 1.  Default: ransac_count32_kernel over everything in one go.
+    // g_count_dense (diagnostics library only): three launches instead -- pilot (the first 256 hypotheses in full -> the
+    // pair's first bound) -> dense phase on the matrix cores (every hypothesis x the points that must be seen before anything
+    // can be dropped, no exit tests) -> finish (the listed hypotheses that can still reach the bound, from there on).
+    // Byte-identical results; measured slower on this part (5.1 + 1.3 ms against 5.2: the exact-fp32 MFMA runs at 37 % of its
+    // peak in this loop, profiles/r03_count32_experiments.md), so it is not the default.
+    if (!g_count_dense) {
+        if (lt) lt->mark(kKRansacCount32);
+        if (stats)
+            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1, true>), dim3(wg, n_active),
+                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
+        else
+            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>), dim3(wg, n_active),
+                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
+    } else {
+        const int wg_pilot = std::max(1, std::min(wg, (kPilotHyp / kCnt32Slots) / (kCnt32Threads / 64)));
+        const size_t lds_dense = (size_t)kDenseChunk * 16 * sizeof(float);   // sixteen floats per point: its monomials for both lane halves
+        if (lt) lt->mark(kKRansacCount32);
+        if (stats)
+            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>), dim3(wg_pilot, n_active),
+                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
+        else
+            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>), dim3(wg_pilot, n_active),
+                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
+        if (lt) lt->mark(kKRansacCountMfma);
+        if (stats)
+            hipLaunchKernelGGL(ransac_count_mfma_kernel<true>, dim3((H + 127) / 128, n_active), dim3(kDenseThreads), lds_dense,
+                               stream, b, rp);
+        else
+            hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3((H + 127) / 128, n_active), dim3(kDenseThreads), lds_dense,
+                               stream, b, rp);
+        if (lt) lt->mark(kKRansacCount32);
+        if (stats)
+            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2, true>), dim3(wg, n_active),
+                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
+        else
+            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>), dim3(wg, n_active),
+                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
+    }
     if (lt) lt->mark(kKRansacCount2);
     if (stats)
         hipLaunchKernelGGL((ransac_count2_kernel<kCntThreads, kCntPpl, true>), dim3(wg, n_active), dim3(kCntThreads), lds_cnt,

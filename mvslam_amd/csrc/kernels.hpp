@@ -68,6 +68,9 @@ struct BatchDev {
     double *box;         // [P][8] bounding box of the pair's matches (x1lo, x1hi, y1lo, y1hi, x2lo, x2hi, y2lo, y2hi)
     int32_t *mode;       // [P] 0: every hypothesis is solved exactly; 1: pre-screened, counted in single precision; 2: pre-
                          // screened, counted in double precision
+    uint32_t *clist;     // [P][max_groups * 256] hypotheses of the pair the dense counting phase left alive (for the finish)
+    int32_t *ccount;     // [P] their number
+    int32_t *dense_n1;   // [P] points the dense (matrix-core) counting phase covered for the pair
     uint32_t *xlist;     // [P * max_groups * 256] work list of the list-driven exact solve: flat indices pair * Hp + h
     uint32_t *xcount;    // [2] {entries of the list: flagged by the pre-screen + survivors of the count, unused}
     double *cand_pts;    // [P][4][N][3] triangulation scratch
@@ -272,6 +275,7 @@ enum KernelId : int {
     kKRansacExactList, // exact solve of the listed hypotheses (flagged by the pre-screen / survivors of the count)
     kKRansacCount2,    // pruned counting with per-hypothesis thresholds (upper / lower bounds of the exact count)
     kKRansacCount32,   // the same in single precision (thresholds widened by the binary32 evaluation error)
+    kKRansacCountMfma, // dense single-precision counting of the first points on the matrix cores (no exit tests)
     kKRansacSurvivors, // hypotheses whose upper bound reaches the pair's best lower bound -> work list
     kKFinModel,
     kKTriangulate,
@@ -313,6 +317,7 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
 hipError_t prepare_kernels();
 // diagnostics: pair_prepare + ransac_prescreen only, every pair forced into the pre-screened mode
 void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
+void set_count_dense(int v);      // diagnostics: 1 = single-precision counting as pilot + dense MFMA phase + finish
 void set_match_mfma(int v);       // diagnostics: 1 (default) 256-bit descriptors on the matrix cores, 0 the VALU kernel
 void set_prescreen_force(int m);   // diagnostics: -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened
 void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)

@@ -248,9 +248,11 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     const double n12p = dfma(s1q, dfma(e1x, e1x, e1y * e1y), 1.0) * dfma(s2q, dfma(e2x, e2x, e2y * e2y), 1.0);
     const double band = (dfn * dsqrt(n12) * (1.0 + 1e-9) + 64.0 * kPsU * dsqrt(n12p)) * (1.0 + 1e-9) + 1e-15 * thr;
     band_out = band;
-    // single-precision counting (ransac_count32_kernel): r32 = the residual's fma chain in binary32 on F~ and the point
-    // rounded to binary32.  Every term p2_j F_jk p1_k passes at most 7 roundings (three inputs, four nested fma):
-    // | r32 - r(F~, p) | <= 8 * 2^-24 * T,  T = sum |p2_j| |F_jk| |p1_k| <= [X2 Y2 1] |F~| [X1 Y1 1]^T over the pair's box
+    // single-precision counting: r32 = the residual evaluated in binary32 on F~ and the point rounded to binary32, either as
+    // the nested fma chain of ransac_count32_kernel (a term p2_j F_jk p1_k passes at most 7 roundings: three inputs, four
+    // fma) or as the matrix-core form of ransac_count_mfma_kernel (three inputs, the rounded monomial p2_j p1_k, and an fmaf
+    // chain over the ten k: at most 14):
+    // | r32 - r(F~, p) | <= 16 * 2^-24 * T,  T = sum |p2_j| |F_jk| |p1_k| <= [X2 Y2 1] |F~| [X1 Y1 1]^T over the pair's box
     {
         const double X1 = fmax(dabs(bx.x1lo), dabs(bx.x1hi)), Y1 = fmax(dabs(bx.y1lo), dabs(bx.y1hi));
         const double X2 = fmax(dabs(bx.x2lo), dabs(bx.x2hi)), Y2 = fmax(dabs(bx.y2lo), dabs(bx.y2hi));
@@ -258,7 +260,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         const double t1 = dfma(X2, dabs(F[1]), dfma(Y2, dabs(F[4]), dabs(F[7])));
         const double t2 = dfma(X2, dabs(F[2]), dfma(Y2, dabs(F[5]), dabs(F[8])));
         const double T = dfma(t0, X1, dfma(t1, Y1, t2));
-        e32_out = 8.0 * 0x1p-24 * T * (1.0 + 1e-6) + 1e-30;
+        e32_out = 16.0 * 0x1p-24 * T * (1.0 + 1e-6) + 1e-30;
     }
     // every comparison is written so that a NaN anywhere lands in "needs the exact solve"; the caller adds the band test
     // of its counting precision (band, or band + e32, against kPsBandFrac * thr)

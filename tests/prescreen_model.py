@@ -16,7 +16,7 @@ Per sample (8 point pairs, Hartley-normalised exactly like the exact path):
   delta  = w1 - w2 - eta - 2e-11      gap of the singular value that the rank-2 step removes
   dFn    = (2 + 2 (w2 + 3 eta) / delta) eta + 2e-11                        Wedin's sin-theta theorem
   band   = dFn N1 N2 (1 + 1e-9) + 64 u N1' N2'      N = max over the pair's points of ||T p||, N' with absolute values
-  e32    = 8 * 2^-24 * [X2 Y2 1] |F~| [X1 Y1 1]^T    single-precision evaluation of the residual (added to band there)
+  e32    = 16 * 2^-24 * [X2 Y2 1] |F~| [X1 Y1 1]^T    single-precision evaluation of the residual (added to band there)
 """
 import numpy as np
 
@@ -145,11 +145,12 @@ def prescreen(x1, y1, x2, y2, bbox):
     N2p = np.sqrt(1 + s2 * s2 * (e2x * e2x + e2y * e2y))
     band = dfn * N1 * N2 * (1 + 1e-9) + 64 * U * N1p * N2p
     F = denormalise(Fn, s1, m1x, m1y, s2, m2x, m2y)
-    # single-precision evaluation of the residual (ransac_count32_kernel): <= 8 roundings per term
+    # single-precision evaluation of the residual: <= 7 roundings per term as a nested fma chain (ransac_count32_kernel),
+    # <= 14 in the matrix-core form (rounded monomial + an fmaf chain over ten k, ransac_count_mfma_kernel)
     X1, Y1 = max(abs(x1lo), abs(x1hi)), max(abs(y1lo), abs(y1hi))
     X2, Y2 = max(abs(x2lo), abs(x2hi)), max(abs(y2lo), abs(y2hi))
     T = np.array([X2, Y2, 1.0]) @ np.abs(F) @ np.array([X1, Y1, 1.0])
-    e32 = 8.0 * 2.0 ** -24 * T * (1 + 1e-6) + 1e-30
+    e32 = 16.0 * 2.0 ** -24 * T * (1 + 1e-6) + 1e-30
     out.update(F=F, band=float(band), e32=float(e32), dfn=dfn, N=(N1, N2), Fn=Fn, screenable=bool(np.isfinite(band)))
     return out
 

@@ -40,12 +40,12 @@ def _check(p1, p2, idx, bbox, stats):
     stats["worst"] = max(stats["worst"], d / r["band"])
     sv = np.linalg.svd(r["A"], compute_uv=False)
     assert r["sig8_lb"] <= sv[7] * (1 + 1e-12)                      # a LOWER bound of sigma_8(A)
-    # the single-precision leg: residuals of the binary32-rounded F~ and points stay within band + e32 (the four fma
-    # roundings of the device's binary32 chain are part of e32's eight)
+    # the single-precision leg: residuals of the binary32-rounded F~ and points stay within band + e32 (the arithmetic
+    # roundings of the device's binary32 evaluation are the rest of e32's sixteen)
     F32 = r["F"].astype(np.float32).astype(np.float64)
     q1, q2 = p1.astype(np.float32).astype(np.float64), p2.astype(np.float32).astype(np.float64)
     d32 = float(np.abs(rj - pm.residuals(F32, q1, q2)).max())
-    assert d32 <= r["band"] + 0.5 * r["e32"], (d32, r["band"], r["e32"])
+    assert d32 <= r["band"] + 0.25 * r["e32"], (d32, r["band"], r["e32"])
 
 
 def test_model_band_covers_the_oracle_on_synthetic_pairs():
