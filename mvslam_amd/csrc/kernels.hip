@@ -1690,12 +1690,13 @@ __device__ __forceinline__ void dense_count(const v16f &acc, f32x2 negH, f32x2 t
 
 // amdgpu_waves_per_eu(4, 8): with the default register budget of a 256-thread kernel hipcc puts the MFMA results into
 // accumulation registers and reads every one back with v_accvgpr_read before it can be used (16 more vector
-// instructions per tile)
+// instructions per tile).  A wavefront carries TWO blocks of 32 hypotheses: their MFMA chains are independent (a single
+// chain of five dependent 32x32x2 MFMAs per tile ran at 56 % of the matrix pipe's rate) and share every A operand read.
 template <bool STATS>
 __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_count_mfma_kernel(BatchDev b,
                                                                                                                     RunParams rp)
 {
-    // LDS: the monomials of points [0, n1), [point][lane half][5 + 3 pad] floats: the lane's A operands of a tile are one
+    // LDS: the monomials of a chunk of points, [point][lane half][5 + 3 pad] floats: the lane's A operands of a tile are one
     // ds_read_b128 + one ds_read_b32, no selects (half 0: x2 x1, x2, y2 y1, x1, 1; half 1: x2 y1, y2 x1, y2, y1, 0)
     extern __shared__ __attribute__((aligned(16))) double s_cpts[];
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
@@ -1709,23 +1710,29 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     const int H = rp.num_hypotheses;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     float *s_m = reinterpret_cast<float *>(s_cpts);
-    const int hw = (blockIdx.x * (kDenseThreads / 64) + w) * 32;   // first hypothesis of the wavefront
+    const int hw = (blockIdx.x * (kDenseThreads / 64) + w) * 64;   // first hypothesis of the wavefront (two blocks of 32)
     const bool wave_live = hw < H;
-    const int h = hw + col;    // this lane's hypothesis (both lane halves)
-    const size_t rec = (size_t)pair * Hp + (wave_live ? h : 0);
-    const int st = (wave_live && h < H) ? (int)b.hyp_okf[rec] : kPsInvalid;
-    // B operand: F~[k] of the lane's hypothesis for k = 2 s + half, s = 0 .. 4 (k = 9: zero)
-    const float *fr = reinterpret_cast<const float *>(b.hyp_F + rec * kHypRec);
-    float Bf[5];
+    int h[2], st[2];
+    float Bf[2][5], tu[2];
+    f32x2 t2H[2];
 #pragma unroll
-    for (int s5 = 0; s5 < 5; ++s5) {
-        const int k = 2 * s5 + half;
-        Bf[s5] = (st == kPsApprox && k < 9) ? fr[k] : 0.f;
+    for (int c = 0; c < 2; ++c) {
+        h[c] = hw + 32 * c + col;    // this lane's hypothesis of block c (both lane halves)
+        const size_t rec = (size_t)pair * Hp + (h[c] < (int)Hp ? h[c] : 0);
+        st[c] = (wave_live && h[c] < H) ? (int)b.hyp_okf[rec] : kPsInvalid;
+        // B operand: F~[k] of the lane's hypothesis for k = 2 s + half, s = 0 .. 4 (k = 9: zero)
+        const float *fr = reinterpret_cast<const float *>(b.hyp_F + rec * kHypRec);
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int k = 2 * s5 + half;
+            Bf[c][s5] = (st[c] == kPsApprox && k < 9) ? fr[k] : 0.f;
+        }
+        tu[c] = st[c] == kPsApprox ? fr[9] : 0.f;
+        const float t2h = (tu[c] * tu[c]) * (1.f + 0x1p-21f) * 0x1p100f;
+        t2H[c] = f32x2{t2h, t2h};
     }
-    const float tu = st == kPsApprox ? fr[9] : 0.f;
-    const float t2h = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
-    const f32x2 negH = {-0x1p100f, -0x1p100f}, t2H = {t2h, t2h};
-    f32x2 cntf = {0.f, 0.f};
+    const f32x2 negH = {-0x1p100f, -0x1p100f};
+    f32x2 cntf[2] = {{0.f, 0.f}, {0.f, 0.f}};
     auto monomials = [&](int p0, float (&m)[5]) {
         const float *q = s_m + ((size_t)(p0 + col) * 2 + half) * 8;
         const float4 v = *reinterpret_cast<const float4 *>(q);
@@ -1748,39 +1755,46 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
         __syncthreads();
         if (!wave_live)
             continue;
-        // software pipeline: the MFMAs of tile t + 1 are issued before tile t's accumulators are counted
-        float m[5];
-        monomials(0, m);
-        v16f cur = dense_tile(m, Bf);
-        for (int p0 = 32; p0 < nc; p0 += 32) {
+        for (int p0 = 0; p0 < nc; p0 += 32) {
+            float m[5];
             monomials(p0, m);
-            const v16f nxt = dense_tile(m, Bf);
-            dense_count(cur, negH, t2H, cntf);   // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
-            cur = nxt;
+            // two independent accumulation chains, interleaved
+            v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(m[s5], Bf[0][s5], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(m[s5], Bf[1][s5], a1, 0, 0, 0);
+            }
+            // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
+            dense_count(a0, negH, t2H[0], cntf[0]);
+            dense_count(a1, negH, t2H[1], cntf[1]);
         }
-        dense_count(cur, negH, t2H, cntf);
     }
     if (!wave_live)
         return;
-    int cnt = (int)(cntf.x + cntf.y);
-    cnt += __shfl_xor(cnt, 32);   // the two lane halves hold different points of the same hypothesis
-    if (half == 0 && h < H)
-        b.hyp_cnt[rec] = st == kPsApprox ? cnt : st == kPsNeedExact ? 0x7fffffff : -1;
-    // hypotheses that can still reach the pilot's bound go on the pair's list for the finish
-    const bool go = half == 0 && st == kPsApprox && !(cnt + (M - n1) < B0);
-    const unsigned long long mm = __ballot(go);
-    if (mm) {
-        int base = 0;
-        if (lane == 0)
-            base = atomicAdd(&b.ccount[pair], __popcll(mm));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (go)
-            b.clist[(size_t)pair * Hp + base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)h;
-    }
-    if (STATS && b.stats) {
-        const unsigned long long ma = __ballot(st == kPsApprox && half == 0);
-        if (lane == 0 && ma)
-            atomicAdd(&b.stats[3], (unsigned long long)__popcll(ma) * (unsigned long long)n1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int cnt = (int)(cntf[c].x + cntf[c].y);
+        cnt += __shfl_xor(cnt, 32);   // the two lane halves hold different points of the same hypothesis
+        const size_t rec = (size_t)pair * Hp + h[c];
+        if (half == 0 && h[c] < H)
+            b.hyp_cnt[rec] = st[c] == kPsApprox ? cnt : st[c] == kPsNeedExact ? 0x7fffffff : -1;
+        // hypotheses that can still reach the pilot's bound go on the pair's list for the finish
+        const bool go = half == 0 && st[c] == kPsApprox && !(cnt + (M - n1) < B0);
+        const unsigned long long mm = __ballot(go);
+        if (mm) {
+            int base = 0;
+            if (lane == 0)
+                base = atomicAdd(&b.ccount[pair], __popcll(mm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (go)
+                b.clist[(size_t)pair * Hp + base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)h[c];
+        }
+        if (STATS && b.stats) {
+            const unsigned long long ma = __ballot(st[c] == kPsApprox && half == 0);
+            if (lane == 0 && ma)
+                atomicAdd(&b.stats[3], (unsigned long long)__popcll(ma) * (unsigned long long)n1);
+        }
     }
 }
 
@@ -2778,10 +2792,10 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
         if (lt) lt->mark(kKRansacCountMfma);
         if (stats)
-            hipLaunchKernelGGL(ransac_count_mfma_kernel<true>, dim3((H + 127) / 128, n_active), dim3(kDenseThreads), lds_dense,
+            hipLaunchKernelGGL(ransac_count_mfma_kernel<true>, dim3((H + 255) / 256, n_active), dim3(kDenseThreads), lds_dense,
                                stream, b, rp);
         else
-            hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3((H + 127) / 128, n_active), dim3(kDenseThreads), lds_dense,
+            hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3((H + 255) / 256, n_active), dim3(kDenseThreads), lds_dense,
                                stream, b, rp);
         if (lt) lt->mark(kKRansacCount32);
         if (stats)
