@@ -101,8 +101,10 @@ PER_ROT9 = 172        # rotation angle (14) + 9 x (A rows 10 + V rows 6)
 PER_EVAL = 18         # 8 fma + compare + conditional add
 # the pre-screen of one hypothesis (prescreen.hpp): normalise x2 184, design row products + ||A||_F^2 112,
 # Householder QR of the 9x8 (392 fma + 44 fma for the norms + 8 sqrt + 8 div + 40) 920, null vector 176, triangular inverse
-# + its Frobenius norm 284, a-posteriori residual (second gather) 208, 3x3 SVD + rank-2 800, de-normalise 73, bounds 110
-PER_PRESCREEN = 184 + 112 + 920 + 176 + 284 + 208 + 800 + 73 + 110
+# + its Frobenius norm 284, a-posteriori residual (second gather) 208, rank-2 through one verified singular triplet (G^T G and
+# its characteristic polynomial 58, eight Newton steps 120, cross products + normalisation 66, w / X / sigma / u / eps2 112, second
+# singular value of X from its invariants 111) 467, de-normalise 36, bounds 116
+PER_PRESCREEN = 184 + 112 + 920 + 176 + 284 + 208 + 467 + 36 + 116
 
 
 def solve_flops(stats):

@@ -29,7 +29,8 @@ struct PairBox {
 constexpr double kPsU = 0x1p-53;          // unit roundoff
 constexpr double kPsTauC = 2.0e-12;       // >= 2.001 (8000 u + 8.01 u): <= 1080 Jacobi rotations + forming A^T A
 constexpr double kPsEtaQ = 4.0e-12;       // loss of orthogonality of the accumulated V^T over <= 1080 rotations
-constexpr double kPsSvd3 = 2.0e-11;       // backward error of the 3x3 Jacobi SVD + recomposition, both paths together
+constexpr double kPsSvd3 = 2.0e-11;       // backward error of the exact path's 3x3 Jacobi SVD + recomposition (generous)
+constexpr double kPsTrip = 1.0e-12;       // roundings of the verified singular triplet below (~150 operations on |x| <= 1.01)
 constexpr double kPsBandFrac = 0.125;     // screened only if band <= kPsBandFrac * thr
 constexpr int kPsInvalid = 0, kPsApprox = 1, kPsNeedExact = 2, kPsExact = 3;   // per-hypothesis state byte (hyp_okf)
 
@@ -61,6 +62,121 @@ MVS_DEV bool sample_norm(const double (&px)[8], const double (&py)[8], double &s
     const bool ok = sc > kEps;
     scale = kSqrt2 / sc;
     return ok;
+}
+
+// The rank-2 step of the pre-screen.  G = reshape(n~) (row-major 3x3, ||G||_F = 1).  The exact path takes the 3x3 Jacobi
+// SVD and drops the smallest singular value; all the bound needs of G is ONE verified singular triplet:
+//   v     an approximate right singular vector of the smallest singular value, from the characteristic polynomial of
+//         C = G^T G (Newton from 0: monotone from the left towards the smallest root) and the cross products of the rows of
+//         C - lambda I; HOW it is obtained is immaterial, because what is used of it is checked:
+//   w = G v, sig = ||w||, u = w / sig, eps2 = || G^T u - sig v ||: (sig, u, v) is an exact singular triplet of a matrix G'
+//         with ||G' - G||_F <= eps2 + (roundings), and X = G - w v^T = G (I - v v^T) is within the same distance of T_2(G');
+//   s2lb  a lower bound of the second singular value of X from its invariants (||X||_F^2 and ||X^T X||_F^2).
+// If eps2 is not below sig (a noise-free sample: sig ~ 1e-16, u is rounding noise) the triplet (0, *, v) of X itself is used
+// instead: ||X - G||_F = sig.  Returns e (the distance that enters eta), sigma_e (the triplet's singular value), extra
+// (the distance of X from the rank-2 matrix of the perturbed G), s2lb.  DESIGN.md 4.3e (iv).
+MVS_DEV void prescreen_rank2(const double (&g)[9], double (&X)[9], double &e_out, double &sige_out, double &extra_out,
+                             double &s2lb_out, bool &ok_out)
+{
+    // C = G^T G
+    const double c00 = dfma(g[6], g[6], dfma(g[3], g[3], g[0] * g[0]));
+    const double c01 = dfma(g[6], g[7], dfma(g[3], g[4], g[0] * g[1]));
+    const double c02 = dfma(g[6], g[8], dfma(g[3], g[5], g[0] * g[2]));
+    const double c11 = dfma(g[7], g[7], dfma(g[4], g[4], g[1] * g[1]));
+    const double c12 = dfma(g[7], g[8], dfma(g[4], g[5], g[1] * g[2]));
+    const double c22 = dfma(g[8], g[8], dfma(g[5], g[5], g[2] * g[2]));
+    // lambda^3 - k2 lambda^2 + k1 lambda - k0, k0 = det(G)^2
+    const double k2 = (c00 + c11) + c22;
+    const double k1 = dfma(c00, c11, -(c01 * c01)) + dfma(c00, c22, -(c02 * c02)) + dfma(c11, c22, -(c12 * c12));
+    const double dg = dfma(g[0], dfma(g[4], g[8], -(g[5] * g[7])),
+                           dfma(-g[1], dfma(g[3], g[8], -(g[5] * g[6])), g[2] * dfma(g[3], g[7], -(g[4] * g[6]))));
+    const double k0 = dg * dg;
+    const double m2k2 = -2.0 * k2;
+    double lam = 0.0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const double f = dfma(dfma(lam - k2, lam, k1), lam, -k0);
+        const double fp = dfma(dfma(3.0, lam, m2k2), lam, k1);
+        double r = __builtin_amdgcn_rcp(fp);
+        r = r * dfma(-fp, r, 2.0);
+        lam = dfma(-f, r, lam);
+    }
+    // null vector of C - lambda I: the largest of the three cross products of its rows
+    const double m00 = c00 - lam, m11 = c11 - lam, m22 = c22 - lam;
+    const double ax = dfma(c01, c12, -(c02 * m11)), ay = dfma(c02, c01, -(m00 * c12)), az = dfma(m00, m11, -(c01 * c01));
+    const double bx = dfma(c01, m22, -(c02 * c12)), by = dfma(c02, c02, -(m00 * m22)), bz = dfma(m00, c12, -(c01 * c02));
+    const double cx = dfma(m11, m22, -(c12 * c12)), cy = dfma(c12, c02, -(c01 * m22)), cz = dfma(c01, c12, -(m11 * c02));
+    const double na = dfma(az, az, dfma(ay, ay, ax * ax));
+    const double nb = dfma(bz, bz, dfma(by, by, bx * bx));
+    const double nc = dfma(cz, cz, dfma(cy, cy, cx * cx));
+    const bool ub = nb > na;
+    double vx = ub ? bx : ax, vy = ub ? by : ay, vz = ub ? bz : az, nv = ub ? nb : na;
+    const bool uc = nc > nv;
+    vx = uc ? cx : vx; vy = uc ? cy : vy; vz = uc ? cz : vz; nv = uc ? nc : nv;
+    bool ok = nv >= 0x1p-190;            // (also false for a NaN)
+    double h;
+    (void)sqrt_fast_nz_h(nv, h);
+    h += h;                              // ~ 1 / ||v||
+    vx *= h; vy *= h; vz *= h;
+    // w = G v, X = G - w v^T
+    const double w0 = dfma(g[2], vz, dfma(g[1], vy, g[0] * vx));
+    const double w1 = dfma(g[5], vz, dfma(g[4], vy, g[3] * vx));
+    const double w2 = dfma(g[8], vz, dfma(g[7], vy, g[6] * vx));
+    X[0] = dfma(-w0, vx, g[0]); X[1] = dfma(-w0, vy, g[1]); X[2] = dfma(-w0, vz, g[2]);
+    X[3] = dfma(-w1, vx, g[3]); X[4] = dfma(-w1, vy, g[4]); X[5] = dfma(-w1, vz, g[5]);
+    X[6] = dfma(-w2, vx, g[6]); X[7] = dfma(-w2, vy, g[7]); X[8] = dfma(-w2, vz, g[8]);
+    const double sg2 = dfma(w2, w2, dfma(w1, w1, w0 * w0));
+    const double sig = dsqrt(sg2);
+    // u = w / sig, eps2 = || G^T u - sig v ||  (garbage when sig is tiny: then the other branch is taken)
+    const double rs = div_fast(1.0, fmax(sig, 0x1p-190));
+    const double u0 = w0 * rs, u1 = w1 * rs, u2 = w2 * rs;
+    const double e0 = dfma(g[6], u2, dfma(g[3], u1, dfma(g[0], u0, -(sig * vx))));
+    const double e1 = dfma(g[7], u2, dfma(g[4], u1, dfma(g[1], u0, -(sig * vy))));
+    const double e2 = dfma(g[8], u2, dfma(g[5], u1, dfma(g[2], u0, -(sig * vz))));
+    const double eps2 = dsqrt(dfma(e2, e2, dfma(e1, e1, e0 * e0)));
+    const bool useA = (eps2 < sig) && (sig >= 0x1p-190);
+    e_out = (useA ? eps2 : sig) + kPsTrip;
+    sige_out = useA ? sig : 0.0;
+    extra_out = useA ? eps2 + kPsTrip : kPsTrip;
+    ok = ok && (sig == sig);
+    // second singular value of X from q1 = s1^2 + s2^2 and q2 = s1^4 + s2^4:  P = s1^2 s2^2 = (q1^2 - q2) / 2,
+    // s2^2 = 2 P / (q1 + sqrt(q1^2 - 4 P)); every rounding is pushed towards a smaller result
+    const double q1 = dfma(X[8], X[8], dfma(X[7], X[7], dfma(X[6], X[6], dfma(X[5], X[5], dfma(X[4], X[4],
+                      dfma(X[3], X[3], dfma(X[2], X[2], dfma(X[1], X[1], X[0] * X[0]))))))));
+    const double t00 = dfma(X[6], X[6], dfma(X[3], X[3], X[0] * X[0]));
+    const double t01 = dfma(X[6], X[7], dfma(X[3], X[4], X[0] * X[1]));
+    const double t02 = dfma(X[6], X[8], dfma(X[3], X[5], X[0] * X[2]));
+    const double t11 = dfma(X[7], X[7], dfma(X[4], X[4], X[1] * X[1]));
+    const double t12 = dfma(X[7], X[8], dfma(X[4], X[5], X[1] * X[2]));
+    const double t22 = dfma(X[8], X[8], dfma(X[5], X[5], X[2] * X[2]));
+    const double off = dfma(t12, t12, dfma(t02, t02, t01 * t01));
+    const double q2 = dfma(2.0, off, dfma(t22, t22, dfma(t11, t11, t00 * t00)));
+    const double q1q = q1 * q1;
+    const double Pm = 0.5 * (q1q - q2) - 4e-15;
+    const double disc = fmax(dfma(-4.0, Pm, q1q), 0.0) + 1e-13;
+    const double s2q = (Pm + Pm) / (q1 * (1.0 + 1e-13) + dsqrt(disc));
+    s2lb_out = s2q > 0.0 ? dsqrt(s2q) * (1.0 - 1e-14) : 0.0;
+    ok_out = ok && (q1 <= 1.5);
+}
+
+// F = T2^T Fn T1 with the sample's Hartley transforms (eight_point_back's second half)
+MVS_DEV void prescreen_denormalise(const double (&Fn)[9], const EightNorm &nm, double (&F)[9])
+{
+    const double s1 = nm.s1, s2 = nm.s2;
+    const double tx1 = -nm.m1x * s1, ty1 = -nm.m1y * s1, tx2 = -nm.m2x * s2, ty2 = -nm.m2y * s2;
+    double G[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        G[0][j] = s2 * Fn[j];
+        G[1][j] = s2 * Fn[3 + j];
+        G[2][j] = dfma(tx2, Fn[j], dfma(ty2, Fn[3 + j], Fn[6 + j]));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F[i * 3 + 0] = G[i][0] * s1;
+        F[i * 3 + 1] = G[i][1] * s1;
+        F[i * 3 + 2] = dfma(G[i][0], tx1, dfma(G[i][1], ty1, G[i][2]));
+    }
 }
 
 constexpr int kPsParked = 28;   // strict upper triangle of R, parked in LDS: [kPsParked][64 lanes] doubles per wavefront
@@ -227,12 +343,15 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     const double g = sig8 * sig8;
     const double eta_j = 1.01 * kPsTauC * S / g + kPsEtaQ;
     const double eta_a = 1.5 * (rho + 1.2e-15 * sqrtS) / sig8 + 1e-13;
-    const double eta = (eta_j + eta_a + kPsSvd3) * (1.0 + 1e-12);
-    // rank-2 + de-normalisation: the exact path's code on the approximate null vector
-    double w[3];
-    eight_point_back<VAR>(n, nm, F, bad3, w);
-    const double delta = (w[1] - w[2]) - eta - kPsSvd3;
-    const double dfn = (2.0 + 2.0 * (w[2] + 3.0 * eta) / delta) * eta + kPsSvd3;
+    // rank-2 through one verified singular triplet of reshape(n~), de-normalisation
+    double Fn[9], e3, sige, extra, s2lb;
+    bool ok3;
+    prescreen_rank2(n, Fn, e3, sige, extra, s2lb, ok3);
+    prescreen_denormalise(Fn, nm, F);
+    bad3 = false;
+    const double eta = (eta_j + eta_a + e3 + kPsSvd3) * (1.0 + 1e-12);
+    const double delta = ((s2lb - extra) - sige) - eta;
+    const double dfn = (2.0 + 2.0 * (sige + 3.0 * eta) / delta) * eta + extra + kPsSvd3;
     // N = max over the pair's points of || T p || (T = the sample's Hartley transform), N' with absolute values
     const double d1x = fmax(dabs(nm.m1x - bx.x1lo), dabs(nm.m1x - bx.x1hi));
     const double d1y = fmax(dabs(nm.m1y - bx.y1lo), dabs(nm.m1y - bx.y1hi));
@@ -264,7 +383,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     }
     // every comparison is written so that a NaN anywhere lands in "needs the exact solve"; the caller adds the band test
     // of its counting precision (band, or band + e32, against kPsBandFrac * thr)
-    const bool certified = piv_ok && (z < 0.5) && (sig8 > 0.0) && (delta > 0.0) && (eta < 1e-3) && (band < 0x1p100);
+    const bool certified = piv_ok && ok3 && (z < 0.5) && (sig8 > 0.0) && (delta > 0.0) && (eta < 1e-3) && (band < 0x1p100);
     return certified ? kPsApprox : kPsNeedExact;
 }
 

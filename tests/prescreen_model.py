@@ -12,9 +12,12 @@ Per sample (8 point pairs, Hartley-normalised exactly like the exact path):
   sigma8_lb <= sigma_8(A)             from ||R^-1||_F (explicit triangular inverse, backward-stable solve)
   eta_J  = 1.01 tau' / sigma8_lb^2 + 4e-12,   tau' = 2e-12 ||A||_F^2      exact path's null vector vs the true one
   eta_A  = 1.5 (rho + 1.2e-15 ||A||_F) / sigma8_lb + 1e-13                approximate null vector vs the true one
-  eta    = eta_J + eta_A + 2e-11                                           (+ backward errors of the two 3x3 SVDs)
-  delta  = w1 - w2 - eta - 2e-11      gap of the singular value that the rank-2 step removes
-  dFn    = (2 + 2 (w2 + 3 eta) / delta) eta + 2e-11                        Wedin's sin-theta theorem
+  rank-2 step: ONE verified singular triplet (sig, u, v) of G = reshape(n~): v any approximation of the smallest right singular
+  vector, w = G v, sig = ||w||, u = w / sig, eps2 = ||G^T u - sig v||; X = G - w v^T; s2lb <= sigma_2(X) from X's invariants
+  e, sig_e, extra = (eps2, sig, eps2) if eps2 < sig else (sig, 0, 0)   (+ 1e-12 of roundings each)
+  eta    = eta_J + eta_A + e + 2e-11                                       (+ backward error of the exact path's 3x3 SVD)
+  delta  = s2lb - extra - sig_e - eta      gap of the singular value that the rank-2 step removes
+  dFn    = (2 + 2 (sig_e + 3 eta) / delta) eta + extra + 2e-11             Wedin's sin-theta theorem
   band   = dFn N1 N2 (1 + 1e-9) + 64 u N1' N2'      N = max over the pair's points of ||T p||, N' with absolute values
   e32    = 16 * 2^-24 * [X2 Y2 1] |F~| [X1 Y1 1]^T    single-precision evaluation of the residual (added to band there)
 """
@@ -24,6 +27,7 @@ U = 2.0 ** -53
 TAU_C = 2.0e-12        # >= 2.001 (8000 u + 8.01 u): backward error of <= 1080 rotations + of forming A^T A
 ETA_Q = 4.0e-12        # loss of orthogonality of the accumulated V^T over <= 1080 rotations (3.3e4 u)
 SVD3_E = 2.0e-11       # generous bound on the backward error of a 3x3 Jacobi SVD + recomposition (<= 90 rotations)
+TRIP_E = 1.0e-12       # roundings of the verified singular triplet (~150 operations on |x| <= 1.01)
 BAND_FRAC = 0.125      # a hypothesis is screened only if band <= BAND_FRAC * threshold
 
 
@@ -83,13 +87,36 @@ def tri_inverse_fro(R):
     return np.sqrt((Y * Y).sum()), Y
 
 
-def rank2(f):
-    """(w, Fn): singular values of reshape(f) and its best rank-2 approximation (numpy SVD stands in for the device's
-    3x3 Jacobi; the bound carries SVD3_E for either)"""
+def rank2(f, v=None):
+    """the pre-screen's rank-2 step (prescreen.hpp prescreen_rank2).  v: any approximation of the right singular vector of
+    the smallest singular value of G = reshape(f) (default: numpy's; the device takes it from the characteristic polynomial
+    of G^T G) -- the bound is a-posteriori, so a bad v widens the band instead of breaking it.
+    Returns (X, e, sig_e, extra, s2lb)."""
     G = f.reshape(3, 3)
-    Uu, w, Vt = np.linalg.svd(G)
-    Fn = (Uu[:, :2] * w[:2]) @ Vt[:2]
-    return w, Fn
+    if v is None:
+        v = np.linalg.eigh(G.T @ G)[1][:, 0]
+    v = v / np.sqrt((v * v).sum())
+    w = G @ v
+    X = G - np.outer(w, v)
+    sig = float(np.sqrt((w * w).sum()))
+    if sig >= 2.0 ** -190:
+        u = w / sig
+        r2 = G.T @ u - sig * v
+        eps2 = float(np.sqrt((r2 * r2).sum()))
+    else:
+        eps2 = np.inf
+    if eps2 < sig:
+        e, sig_e, extra = eps2 + TRIP_E, sig, eps2 + TRIP_E
+    else:
+        e, sig_e, extra = sig + TRIP_E, 0.0, TRIP_E
+    q1 = float((X * X).sum())
+    T = X.T @ X
+    q2 = float((T * T).sum())
+    Pm = 0.5 * (q1 * q1 - q2) - 4e-15
+    disc = max(q1 * q1 - 4.0 * Pm, 0.0) + 1e-13
+    s2q = 2.0 * Pm / (q1 * (1 + 1e-13) + np.sqrt(disc))
+    s2lb = float(np.sqrt(s2q)) * (1 - 1e-14) if s2q > 0 else 0.0
+    return X, e, sig_e, extra, s2lb
 
 
 def denormalise(Fn, s1, m1x, m1y, s2, m2x, m2y):
@@ -98,7 +125,7 @@ def denormalise(Fn, s1, m1x, m1y, s2, m2x, m2y):
     return T2.T @ Fn @ T1
 
 
-def prescreen(x1, y1, x2, y2, bbox):
+def prescreen(x1, y1, x2, y2, bbox, v3=None):
     """x1, y1, x2, y2: the 8 sampled ideal-camera points.  bbox = (x1lo, x1hi, y1lo, y1hi, x2lo, x2hi, y2lo, y2hi) of ALL
     matches of the pair.  Returns dict(ok, screenable, F, band, ...)."""
     a1, b1, s1, m1x, m1y, ok1 = hartley(x1, y1)
@@ -123,13 +150,13 @@ def prescreen(x1, y1, x2, y2, bbox):
     g = sig8 * sig8
     eta_j = 1.01 * TAU_C * S / g + ETA_Q
     eta_a = 1.5 * (rho + 1.2e-15 * np.sqrt(S)) / sig8 + 1e-13
-    eta = eta_j + eta_a + SVD3_E
-    w, Fn = rank2(n)
-    delta = w[1] - w[2] - eta - SVD3_E
-    out.update(sig8_lb=sig8, eta=eta, w=w, delta=delta, n=n, A=A)
+    Fn, e3, sig_e, extra, s2lb = rank2(n, v3)
+    eta = eta_j + eta_a + e3 + SVD3_E
+    delta = s2lb - extra - sig_e - eta
+    out.update(sig8_lb=sig8, eta=eta, delta=delta, n=n, A=A, sig_e=sig_e, s2lb=s2lb)
     if not (delta > 0 and eta < 1e-3):
         return out
-    dfn = (2.0 + 2.0 * (w[2] + 3 * eta) / delta) * eta + SVD3_E
+    dfn = (2.0 + 2.0 * (sig_e + 3 * eta) / delta) * eta + extra + SVD3_E
     x1lo, x1hi, y1lo, y1hi, x2lo, x2hi, y2lo, y2hi = bbox
     d1x = max(abs(m1x - x1lo), abs(m1x - x1hi))
     d1y = max(abs(m1y - y1lo), abs(m1y - y1hi))

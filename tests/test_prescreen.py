@@ -26,8 +26,8 @@ def _bbox(p1, p2):
             p2[:, 0].min(), p2[:, 0].max(), p2[:, 1].min(), p2[:, 1].max())
 
 
-def _check(p1, p2, idx, bbox, stats):
-    r = pm.prescreen(p1[idx, 0], p1[idx, 1], p2[idx, 0], p2[idx, 1], bbox)
+def _check(p1, p2, idx, bbox, stats, v3=None):
+    r = pm.prescreen(p1[idx, 0], p1[idx, 1], p2[idx, 0], p2[idx, 1], bbox, v3)
     ok, FJ = o.find_fundamental_matrix(p1[idx], p2[idx])
     assert ok == r["ok"]
     stats["n"] += 1
@@ -90,6 +90,46 @@ def test_model_band_on_adversarial_samples():
         p2 = p2 + rng.normal(scale=1e-3, size=p2.shape)
         _check(p1, p2, np.arange(8), _bbox(p1, p2), stats)
     assert stats["n"] == 300 and stats["cert"] > 100
+
+
+def test_rank2_step_is_a_posteriori():
+    """the rank-2 step takes ANY approximation of the smallest right singular vector: a vector that is off by 1e-9 ... 1e-2
+    must widen the band (or lose the certificate), never break the bound; noise-free samples (sigma_3 ~ 1e-16, where the
+    left vector is rounding noise) take the second branch of the step and keep a small band"""
+    rng = np.random.default_rng(11)
+    d = synth.make_pair(0, n_kp=1000)
+    mt = o.match_visual_features(d["desc1"], d["desc2"], 0.7, 10.0)
+    p1 = o.normalize_points(d["K"], d["kp1"][mt["trainIdx"]].astype(np.float64))
+    p2 = o.normalize_points(d["K"], d["kp2"][mt["queryIdx"]].astype(np.float64))
+    bbox = _bbox(p1, p2)
+    base = dict(n=0, cert=0, worst=0.0)
+    for mag in (1e-9, 1e-6, 1e-4, 1e-2):
+        stats = dict(n=0, cert=0, worst=0.0)
+        for h in range(60):
+            idx = o.sample8(synth.SEED_BASE, h, len(mt))
+            r0 = pm.prescreen(p1[idx, 0], p1[idx, 1], p2[idx, 0], p2[idx, 1], bbox)
+            if not r0["ok"] or "n" not in r0:
+                continue
+            G = r0["n"].reshape(3, 3)
+            v = np.linalg.eigh(G.T @ G)[1][:, 0] + mag * rng.normal(size=3)
+            _check(p1, p2, idx, bbox, stats, v3=v)
+            r1 = pm.prescreen(p1[idx, 0], p1[idx, 1], p2[idx, 0], p2[idx, 1], bbox, v)
+            if r0["screenable"] and r1["screenable"]:
+                assert r1["band"] >= r0["band"] * (1 - 1e-9)
+        assert stats["n"] > 50
+        base[mag] = stats["cert"]
+    assert base[1e-9] > 50 and base[1e-2] <= base[1e-9]
+    # noise-free two-view geometry: exact epipolar constraint up to rounding
+    R = np.array([[0.9998, -0.01, 0.015], [0.0102, 0.9999, -0.004], [-0.0149, 0.0042, 0.9999]])
+    t = np.array([0.3, 0.02, 0.01])
+    stats = dict(n=0, cert=0, worst=0.0)
+    for trial in range(40):
+        X = np.c_[rng.uniform(-1.5, 1.5, 40), rng.uniform(-1.0, 1.0, 40), rng.uniform(2, 10, 40)]
+        q1 = X[:, :2] / X[:, 2:3]
+        X2 = (R @ X.T).T + t
+        q2 = X2[:, :2] / X2[:, 2:3]
+        _check(q1, q2, np.arange(8), _bbox(q1, q2), stats)
+    assert stats["cert"] > 30
 
 
 @pytest.mark.gpu
