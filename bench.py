@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector (v_pk_fma_f32: two FMAs per lane and instruction), MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (= half the 157.3 TF fp32
 #                          vector rate of MI355X_MICROARCH.md; the fp64 MFMA dense peak is the same figure)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; the 2:1-sparsity figure is twice that)
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -99,6 +100,8 @@ PER_HYP = 184 + 32 + 720 + 162 + 171 + 800 + 73   # normalise x2, A, A^T A, W in
 PER_PAIR9 = 21        # dot (9 fma) + threshold test
 PER_ROT9 = 172        # rotation angle (14) + 9 x (A rows 10 + V rows 6)
 PER_EVAL = 18         # 8 fma + compare + conditional add
+PER_EVAL_MFMA = 54    # the same evaluation in split bf16: 27 multiply-adds on the matrix cores
+PILOT_HYP = 256       # kPilotHyp (kernels.hip): hypotheses the pilot launch counts in full per pair
 # the pre-screen of one hypothesis (prescreen.hpp): normalise x2 184, design row products + ||A||_F^2 112,
 # Householder QR of the 9x8 (392 fma + 44 fma for the norms + 8 sqrt + 8 div + 40) 920, null vector 176, triangular inverse
 # + its Frobenius norm 284, a-posteriori residual (second gather) 208, rank-2 through one verified singular triplet (G^T G and
@@ -197,10 +200,26 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
             n_ps = stats["hypotheses"] - stats["pairs_mode"][0] * (stats["hypotheses"] / max(sum(stats["pairs_mode"]), 1))
             fl_exec = fl_alg = n_ps * PER_PRESCREEN
         elif name.startswith("ransac_count32_kernel"):
-            fl_alg = stats["score_evals"] * PER_EVAL
-            fl_exec = stats["score_evals_executed_f32"] * PER_EVAL
-            e["evals_executed_frac"] = round(stats["score_evals_executed_f32"] / max(stats["score_evals"], 1), 4)
+            # phase 0 (pilot: the first PILOT_HYP hypotheses of every mode-1 pair in full), phase 2 (finish: what the dense
+            # phase could not drop, from its last point on), phase 1 (diagnostics: everything in one launch)
+            ev32 = stats["score_evals_executed_f32"]
+            m1 = stats["pairs_mode"][1] / max(sum(stats["pairs_mode"]), 1)
+            ev_pilot = min(int(PILOT_HYP * stats["matches"] * m1), ev32) if stats.get("score_evals_executed_mfma", 0) else 0
+            ev = ev_pilot if ", 0, false>" in name else ev32 - ev_pilot
+            fl_alg = fl_exec = ev * PER_EVAL
+            e["evals_executed"] = int(ev)
+            e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
             peak, bound = FP32_PEAK_TFLOPS, "valu_fp32"
+        elif name.startswith("ransac_count_mfma_kernel"):
+            # dense phase: every evaluation is 27 products of bf16 parts (hi hi + hi lo + lo hi over the nine monomials) on
+            # the matrix cores (two v_mfma_f32_32x32x16_bf16 per 32 x 32 tile, 5 of the 32 K slots are zero padding) plus
+            # three packed vector instructions per two evaluations for the count
+            ev = stats.get("score_evals_executed_mfma", 0)
+            fl_alg = fl_exec = ev * PER_EVAL_MFMA
+            e["evals_executed"] = int(ev)
+            e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
+            e["evals_per_ns"] = round(ev / max(e["ms"] * 1e6, 1e-9), 2)
+            peak, bound = BF16_MFMA_PEAK_TFLOPS, "mfma_bf16"
         elif name.startswith("ransac_count_kernel") or name.startswith("ransac_count2_kernel"):
             ev64 = stats["score_evals_executed"] - stats["score_evals_executed_f32"]
             fl_alg = stats["score_evals"] * PER_EVAL

@@ -266,6 +266,7 @@ typedef struct mvs_work_stats {
     int64_t prescreened;          /* hypotheses that only ever got the pre-screen's approximate F (never solved exactly) */
     int64_t pairs_mode[3];        /* pairs per mode: 0 every hypothesis exact, 1 pre-screened + single-precision counting,
                                      2 pre-screened + double-precision counting */
+    int64_t score_evals_executed_mfma; /* the part of score_evals_executed done by the dense matrix-core phase (split bf16) */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 

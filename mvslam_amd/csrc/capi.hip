@@ -573,7 +573,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     ALLOC(d.mask, P * N);
     ALLOC(d.points, P * N * 3);
     ALLOC(d.point_idx, P * N);
-    ALLOC(d.stats, 4);
+    ALLOC(d.stats, 8);
 #undef ALLOC
     if (st != MVS_OK) {
         mvs_batch_destroy(b);
@@ -1036,21 +1036,22 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     b->d.hyp_count = nullptr;
     b->d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 4 * sizeof(unsigned long long), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 5 * sizeof(unsigned long long), s));
     st = enqueue_pipeline(b, to_run(*params), n_active, true, nullptr);
     if (st != MVS_OK)
         return st;
     HIP_TRY(ctx, sync_stream(ctx));
-    unsigned long long h[4];
+    unsigned long long h[5];
     HIP_TRY(ctx, hipMemcpy(h, b->d.stats, sizeof(h), hipMemcpyDeviceToHost));
     std::vector<mvs_pair_result> res(n_active);
     HIP_TRY(ctx, hipMemcpy(res.data(), b->d.results, n_active * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     out->rotations9 = (int64_t)h[0];
     out->pairs9 = (int64_t)h[1];
-    out->score_evals_executed = (int64_t)(h[2] + h[3]);   // double- + single-precision counting kernels
+    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4]);   // double-, single-precision and matrix-core counting
     out->score_evals_executed_f32 = (int64_t)h[3];
-    if (b->d.mode && b->d.xcount && h[2] + h[3] > 0) {   // the pre-screened stage ran: its bookkeeping
+    out->score_evals_executed_mfma = (int64_t)h[4];
+    if (b->d.mode && b->d.xcount && h[2] + h[3] + h[4] > 0) {   // the pre-screened stage ran: its bookkeeping
         std::vector<int32_t> mode(n_active);
         uint32_t xc[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpy(mode.data(), b->d.mode, n_active * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -1622,20 +1622,29 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
 
 // ---- dense counting on the matrix cores --------------------------------------------------------------------------------
 // The residuals of a block of points under a block of hypotheses are one GEMM: r[i][h] = Phi(point i) . F~(h) with the nine
-// monomials Phi = (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1).  v_mfma_f32_32x32x2_f32 (exact binary32, bitwise an fmaf
-// chain over k) does 32 points x 32 hypotheses x 2 monomials per instruction -- five per tile against 84 vector + scalar
-// instructions of ransac_count32_kernel for the same 1024 evaluations, which is bound by instruction issue.  A tile cannot drop
-// single hypotheses, so this phase takes NO exit tests: it counts points [0, n1) for every approximate record, where
-//     n1 = dense_points(M, B0) = the multiple of 256 that covers M - B0 + 32 points, clamped to [0, M rounded down],
+// monomials Phi = (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1).  ransac_count32_kernel spends 84 vector + scalar
+// instructions on 1024 evaluations and is bound by instruction issue; the matrix cores do the products of a 32 x 32 tile in
+// a handful.  In exact binary32 (v_mfma_f32_32x32x2_f32, five per tile, 320 clocks: the fp32 vector rate) the phase was no
+// faster than the vector kernel; here the product runs in SPLIT bf16: every binary32 operand is hi + lo with
+// hi = bf16(x), lo = bf16(x - hi) (sixteen significant bits), and Phi_k F_k ~ hi hi + hi lo + lo hi: 27 products of bf16
+// numbers (exact in binary32) summed in binary32 by two v_mfma_f32_32x32x16_bf16 (K = 32, five slots zero, 64 clocks).
+// Error of the value against the exact sum on the binary32 inputs: representation 2 x 2^-18, the dropped lo lo 2^-18, the
+// <= 32 additions of the accumulation 2^-23 each (whatever their order and rounding mode), the monomial and the three
+// input roundings 4 x 2^-24 -- together < 2^-15.9 of T = sum |p2_j| |F_jk| |p1_k|; the phase counts against
+// tu' = tu + 2^-15 T(box) (tu already carries the band and the binary32 bound e32), so its count is an UPPER bound of the
+// exact count like every other.  A tile cannot drop single hypotheses, so the phase takes NO exit tests: it counts points
+// [0, n1) for every approximate record,
+//     n1 = dense_points(M, B0) = the multiple of 32 that covers M - B0 + 32 points, clamped to [0, M rounded down],
 // B0 = the bound the PILOT (the first kPilotHyp hypotheses counted in full by ransac_count32_kernel) has established: a
 // hypothesis cannot be dropped before M - B points have been seen, so nothing is wasted except on the few per cent that go on.
 // ransac_count32_kernel then resumes behind n1 for the hypotheses that can still reach the bound.
-// Wavefront = 32 hypotheses (the B operand: 5 VGPRs, loaded once) x all point tiles (A operand: the lane's point from LDS, its
-// monomials formed in registers); the accumulator tile has the hypothesis on the lane and 16 points in the registers:
-// v_cmp + v_addc count per lane against the hypothesis' own upper threshold.
-constexpr int kDenseThreads = 256;   // 4 wavefronts x 32 hypotheses
-constexpr int kDenseChunk = 512;     // points staged per pass (multiple of 32): 32 KB of monomials
+// Wavefront = 2 x 32 hypotheses (the B operands: 16 VGPRs, built once) x all point tiles (A operands: two ds_read_b128 per
+// tile); the accumulator tile has the hypothesis on the lane and 16 points in the registers.
+constexpr int kDenseThreads = 256;   // 4 wavefronts x 64 hypotheses
+constexpr int kDenseChunk = 768;     // points staged per pass (multiple of 32): 48 KB of split monomials
+constexpr int kDenseBatches = 8;     // batches of 256 hypotheses a workgroup takes over the points it has staged
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int dense_points(int M, int B0)
 {
@@ -1643,24 +1652,49 @@ __device__ __forceinline__ int dense_points(int M, int B0)
     return max(0, min(want, (M / 32) * 32));
 }
 
-// the five MFMAs of one 32-point tile against the wavefront's 32 hypotheses; m = the lane's five monomials
-__device__ __forceinline__ v16f dense_tile(const float (&m)[5], const float (&Bf)[5])
+// bf16 (round to nearest even) of a finite binary32 number, as its 16 bits; x = hi + lo + (<= 2^-18 |x|)
+__device__ __forceinline__ uint32_t bf16_bits(float x)
 {
-    v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], Bf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[1], Bf[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[2], Bf[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[3], Bf[3], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m[4], Bf[4], acc, 0, 0, 0);
-    return acc;
+    uint32_t u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void bf16_split(float x, uint32_t &hi, uint32_t &lo)
+{
+    hi = bf16_bits(x);
+    lo = bf16_bits(x - __uint_as_float(hi << 16));   // the difference is exact
+}
+// K slot s = 0 .. 31 of the two MFMAs carries term (k, part) = (s % 9, s / 9) for s < 27: part 0 = hi hi, 1 = hi(Phi) lo(F),
+// 2 = lo(Phi) hi(F); slot s sits in MFMA j = s / 16, lane half (s / 8) & 1, element s & 7 -- for BOTH operands, so the sum does
+// not depend on how the instruction numbers its k.
+__device__ __forceinline__ uint32_t dense_slot(const uint32_t (&hi)[9], const uint32_t (&lo)[9], int s, int lo_part)
+{
+    return s >= 27 ? 0u : (s / 9 == lo_part ? lo[s % 9] : hi[s % 9]);
+}
+// the sixteen slots of one lane half as two 128-bit operands (j = 0, 1); lo_part: 2 for the points, 1 for the hypotheses
+__device__ __forceinline__ void dense_operands(const uint32_t (&hi)[9], const uint32_t (&lo)[9], int half, int lo_part,
+                                               uint4 (&op)[2])
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        uint32_t wd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s0 = j * 16 + 2 * e, s1 = j * 16 + 8 + 2 * e;   // half 0 / half 1
+            const uint32_t v0 = dense_slot(hi, lo, s0, lo_part) | (dense_slot(hi, lo, s0 + 1, lo_part) << 16);
+            const uint32_t v1 = dense_slot(hi, lo, s1, lo_part) | (dense_slot(hi, lo, s1 + 1, lo_part) << 16);
+            wd[e] = half ? v1 : v0;
+        }
+        op[j] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
 }
 
 // Counting without compares: for a pair of accumulators a, ind = clamp((T2 - a * a) * 2^100) is 1 when a^2 < T2 and 0 when
 // a^2 >= T2 (the product with 2^100 is >= 1 as soon as the difference is one ulp of T2 >= 2^-79), so the per-lane count is a
 // float sum of indicators: v_pk_mul_f32, v_pk_fma_f32 with the clamp bit, v_pk_add_f32 -- three packed instructions per TWO
 // accumulators, no scalar registers, no wait states (v_cmp + v_addc is two per accumulator plus an s_nop each).  T2 =
-// tu^2 (1 + 2^-21): every |a| < tu is counted whatever the rounding of a * a; an |a| a hair above tu may be counted too, which
-// an UPPER bound of the count can afford.  Counts stay below 2^24: exact in binary32.
+// tu'^2 (1 + 2^-21): every |a| < tu' is counted whatever the rounding of a * a; an |a| a hair above tu' may be counted too,
+// which an UPPER bound of the count can afford.  Counts stay below 2^24: exact in binary32.
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
 {
     f32x2 d;
@@ -1690,111 +1724,194 @@ __device__ __forceinline__ void dense_count(const v16f &acc, f32x2 negH, f32x2 t
 
 // amdgpu_waves_per_eu(4, 8): with the default register budget of a 256-thread kernel hipcc puts the MFMA results into
 // accumulation registers and reads every one back with v_accvgpr_read before it can be used (16 more vector
-// instructions per tile).  A wavefront carries TWO blocks of 32 hypotheses: their MFMA chains are independent (a single
-// chain of five dependent 32x32x2 MFMAs per tile ran at 56 % of the matrix pipe's rate) and share every A operand read.
+// instructions per tile).  A wavefront carries TWO blocks of 32 hypotheses: their MFMA chains are independent and share
+// every A operand read.
+// Grid (ceil(G / kDenseBatches), P), G = the pair's batches of 256 hypotheses: a workgroup stages the pair's points ONCE and
+// takes kDenseBatches batches over them, and the records of batch g + 1 are in flight while batch g is multiplied -- with
+// one batch per workgroup the kernel spent 60 % of its time waiting for its records (1 GB per 256 pairs behind a full
+// memory latency per wavefront: 2.04 ms, 0.81 without the loads).
+// The 64 records of a wavefront's batch are one contiguous 5 KB span: it is read as five fully coalesced 128-bit loads (lane l
+// takes bytes [1024 j + 16 l, + 16)) and transposed through a 5 KB LDS window of the wavefront -- a lane reading "its" record
+// directly touches 64 records x 80 bytes with 16-byte pieces, 44 cache-line requests per instruction (1.83 ms -> see DESIGN).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct DenseRaw {
+    u32x4 p0, p1, p2, p3, p4;
+    int st0, st1;
+};
+constexpr int kDenseRecWin = 64 * kHypRec * 8 / 16;   // uint4 words of one wavefront's window (320)
+
 template <bool STATS>
 __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_count_mfma_kernel(BatchDev b,
                                                                                                                     RunParams rp)
 {
-    // LDS: the monomials of a chunk of points, [point][lane half][5 + 3 pad] floats: the lane's A operands of a tile are one
-    // ds_read_b128 + one ds_read_b32, no selects (half 0: x2 x1, x2, y2 y1, x1, 1; half 1: x2 y1, y2 x1, y2, y1, 0)
+    // LDS: the split monomials of a chunk of points as MFMA operands, [tile of 32 points][j][lane half][point] x 16 bytes:
+    // the lanes of a wavefront read consecutive 16-byte words (no bank conflicts), two ds_read_b128 per tile
     extern __shared__ __attribute__((aligned(16))) double s_cpts[];
+    __shared__ uint32_t s_list[kDenseBatches * kDenseThreads];   // the workgroup's survivors
+    __shared__ int s_nlist, s_base;
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
     const int M = min(b.M[pair], b.max_kp);
     if (M < 8 || b.mode[pair] != 1)
         return;
+    if (tid == 0)
+        s_nlist = 0;   // (the first barrier of the chunk loop orders it)
     const int B0 = b.bound[pair];   // final since the pilot launch has completed
     const int n1 = dense_points(M, B0);
     if (blockIdx.x == 0 && tid == 0)
         b.dense_n1[pair] = n1;
     const int H = rp.num_hypotheses;
+    const int G = (H + kDenseThreads - 1) / kDenseThreads;
+    const int g0 = blockIdx.x * kDenseBatches, g1 = min(g0 + kDenseBatches, G);
+    if (g0 >= G)
+        return;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    float *s_m = reinterpret_cast<float *>(s_cpts);
-    const int hw = (blockIdx.x * (kDenseThreads / 64) + w) * 64;   // first hypothesis of the wavefront (two blocks of 32)
-    const bool wave_live = hw < H;
-    int h[2], st[2];
-    float Bf[2][5], tu[2];
-    f32x2 t2H[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        h[c] = hw + 32 * c + col;    // this lane's hypothesis of block c (both lane halves)
-        const size_t rec = (size_t)pair * Hp + (h[c] < (int)Hp ? h[c] : 0);
-        st[c] = (wave_live && h[c] < H) ? (int)b.hyp_okf[rec] : kPsInvalid;
-        // B operand: F~[k] of the lane's hypothesis for k = 2 s + half, s = 0 .. 4 (k = 9: zero)
-        const float *fr = reinterpret_cast<const float *>(b.hyp_F + rec * kHypRec);
-#pragma unroll
-        for (int s5 = 0; s5 < 5; ++s5) {
-            const int k = 2 * s5 + half;
-            Bf[c][s5] = (st[c] == kPsApprox && k < 9) ? fr[k] : 0.f;
-        }
-        tu[c] = st[c] == kPsApprox ? fr[9] : 0.f;
-        const float t2h = (tu[c] * tu[c]) * (1.f + 0x1p-21f) * 0x1p100f;
-        t2H[c] = f32x2{t2h, t2h};
-    }
+    uint4 *s_op = reinterpret_cast<uint4 *>(s_cpts);
+    // the pair's largest coordinates, rounded up to binary32
+    const PairBox bx = load_box(b, pair);
+    const float X1 = (float)fmax(dabs(bx.x1lo), dabs(bx.x1hi)) * (1.f + 0x1p-22f);
+    const float Y1 = (float)fmax(dabs(bx.y1lo), dabs(bx.y1hi)) * (1.f + 0x1p-22f);
+    const float X2 = (float)fmax(dabs(bx.x2lo), dabs(bx.x2hi)) * (1.f + 0x1p-22f);
+    const float Y2 = (float)fmax(dabs(bx.y2lo), dabs(bx.y2hi)) * (1.f + 0x1p-22f);
     const f32x2 negH = {-0x1p100f, -0x1p100f};
-    f32x2 cntf[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    auto monomials = [&](int p0, float (&m)[5]) {
-        const float *q = s_m + ((size_t)(p0 + col) * 2 + half) * 8;
-        const float4 v = *reinterpret_cast<const float4 *>(q);
-        m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
-        m[4] = q[4];
-    };
     const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
-    for (int c0 = 0; c0 < n1; c0 += kDenseChunk) {   // the points go through LDS in chunks (32 KB: several workgroups per CU)
-        const int nc = min(kDenseChunk, n1 - c0);
+    uint4 *s_rec = s_op + (size_t)kDenseChunk * 4 + w * kDenseRecWin;
+    auto fetch = [&](int g, DenseRaw &r) __attribute__((always_inline)) {
+        const int hw = (g * (kDenseThreads / 64) + w) * 64;
+        const size_t rec0 = (size_t)pair * Hp + (hw + 64 <= (int)Hp ? hw : 0);
+        const u32x4 *span = reinterpret_cast<const u32x4 *>(b.hyp_F + rec0 * kHypRec) + lane;
+        r.p0 = span[0];
+        r.p1 = span[64];
+        r.p2 = span[128];
+        r.p3 = span[192];
+        r.p4 = span[256];
+        const int ha = hw + col, hb = hw + 32 + col;
+        r.st0 = ha < H ? (int)b.hyp_okf[(size_t)pair * Hp + ha] : kPsInvalid;
+        r.st1 = hb < H ? (int)b.hyp_okf[(size_t)pair * Hp + hb] : kPsInvalid;
+    };
+    int c0 = 0;
+    do {   // the points go through LDS in chunks (one for nearly every pair); n1 = 0 still takes one pass (counts of zero)
+        const int nc = max(0, min(kDenseChunk, n1 - c0));
+        const bool first = c0 == 0, last = c0 + kDenseChunk >= n1;
         __syncthreads();
         for (int i = tid; i < nc; i += kDenseThreads) {
             const double4 pd = src[c0 + i];
             const float x1 = (float)pd.x, y1 = (float)pd.y, x2 = (float)pd.z, y2 = (float)pd.w;
-            float4 *q = reinterpret_cast<float4 *>(s_m + (size_t)i * 16);
-            q[0] = make_float4(x2 * x1, x2, y2 * y1, x1);
-            q[1] = make_float4(1.f, 0.f, 0.f, 0.f);
-            q[2] = make_float4(x2 * y1, y2 * x1, y2, y1);
-            q[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float ph[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.f};
+            uint32_t mh[9], ml[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                bf16_split(ph[k], mh[k], ml[k]);
+            uint4 o0[2], o1[2];
+            dense_operands(mh, ml, 0, 2, o0);
+            dense_operands(mh, ml, 1, 2, o1);
+            uint4 *q = s_op + (size_t)(i >> 5) * 128 + (i & 31);
+            q[0] = o0[0];     // j = 0, half 0
+            q[32] = o1[0];    // j = 0, half 1
+            q[64] = o0[1];    // j = 1, half 0
+            q[96] = o1[1];    // j = 1, half 1
         }
+        DenseRaw raw;
+        fetch(g0, raw);
         __syncthreads();
-        if (!wave_live)
-            continue;
-        for (int p0 = 0; p0 < nc; p0 += 32) {
-            float m[5];
-            monomials(p0, m);
-            // two independent accumulation chains, interleaved
-            v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+        for (int g = g0; g < g1; ++g) {
+            const int hw = (g * (kDenseThreads / 64) + w) * 64;   // first hypothesis of the wavefront (two blocks of 32)
+            int h[2], st[2];
+            v8bf Bop[2][2];
+            f32x2 t2H[2];
+            u32x4 *wr = reinterpret_cast<u32x4 *>(s_rec) + lane;
+            wr[0] = raw.p0;
+            wr[64] = raw.p1;
+            wr[128] = raw.p2;
+            wr[192] = raw.p3;
+            wr[256] = raw.p4;
 #pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(m[s5], Bf[0][s5], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(m[s5], Bf[1][s5], a1, 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+                h[c] = hw + 32 * c + col;    // this lane's hypothesis of block c (both lane halves)
+                st[c] = c ? raw.st1 : raw.st0;
+                // the record's first twelve floats: F~[9], tu, tl, -
+                const float4 *rq = reinterpret_cast<const float4 *>(s_rec + (32 * c + col) * 5);
+                const float4 q0 = rq[0], q1 = rq[1], q2 = rq[2];
+                const float fr[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+                const bool on = st[c] == kPsApprox;
+                float Ff[9];
+                uint32_t fh[9], fl[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    Ff[k] = on ? fr[k] : 0.f;
+                    bf16_split(Ff[k], fh[k], fl[k]);
+                }
+                uint4 op[2];
+                dense_operands(fh, fl, half, 1, op);
+                Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
+                Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
+                // tu' = tu + 2^-15 T,  T = [X2 Y2 1] |F~| [X1 Y1 1]^T (every rounding upwards)
+                const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
+                const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
+                const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
+                const float T = fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f);
+                const float tu = on ? (fr[9] + 0x1p-15f * T) * (1.f + 0x1p-22f) : 0.f;
+                const float t2h = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
+                t2H[c] = f32x2{t2h, t2h};
             }
-            // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
-            dense_count(a0, negH, t2H[0], cntf[0]);
-            dense_count(a1, negH, t2H[1], cntf[1]);
-        }
-    }
-    if (!wave_live)
-        return;
+            if (g + 1 < g1)
+                fetch(g + 1, raw);   // in flight during this batch's tiles
+            if (hw >= H)
+                continue;
+            f32x2 cntf[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            for (int p0 = 0; p0 < nc; p0 += 32) {
+                const uint4 *q = s_op + (size_t)(p0 >> 5) * 128 + half * 32 + col;
+                const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
+                // two independent accumulation chains, interleaved
+                v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
+                // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
+                dense_count(a0, negH, t2H[0], cntf[0]);
+                dense_count(a1, negH, t2H[1], cntf[1]);
+            }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        int cnt = (int)(cntf[c].x + cntf[c].y);
-        cnt += __shfl_xor(cnt, 32);   // the two lane halves hold different points of the same hypothesis
-        const size_t rec = (size_t)pair * Hp + h[c];
-        if (half == 0 && h[c] < H)
-            b.hyp_cnt[rec] = st[c] == kPsApprox ? cnt : st[c] == kPsNeedExact ? 0x7fffffff : -1;
-        // hypotheses that can still reach the pilot's bound go on the pair's list for the finish
-        const bool go = half == 0 && st[c] == kPsApprox && !(cnt + (M - n1) < B0);
-        const unsigned long long mm = __ballot(go);
-        if (mm) {
-            int base = 0;
-            if (lane == 0)
-                base = atomicAdd(&b.ccount[pair], __popcll(mm));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (go)
-                b.clist[(size_t)pair * Hp + base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)h[c];
+            for (int c = 0; c < 2; ++c) {
+                int cnt = (int)(cntf[c].x + cntf[c].y);
+                cnt += __shfl_xor(cnt, 32);   // the two lane halves hold different points of the same hypothesis
+                const size_t rec = (size_t)pair * Hp + h[c];
+                const bool mine = half == 0 && h[c] < H;
+                if (mine && st[c] == kPsApprox && !first)
+                    cnt += b.hyp_cnt[rec];    // the earlier chunks' share (written by this lane)
+                if (mine)
+                    b.hyp_cnt[rec] = st[c] == kPsApprox ? cnt : st[c] == kPsNeedExact ? 0x7fffffff : -1;
+                // hypotheses that can still reach the pilot's bound go on the pair's list for the finish
+                const bool go = last && mine && st[c] == kPsApprox && !(cnt + (M - n1) < B0);
+                // collected in LDS first: one atomic on the pair's counter per workgroup, not one per wavefront and block
+                // (1568 returning atomics on the same address per pair cost more than the counting itself)
+                const unsigned long long mm = __ballot(go);
+                if (mm) {
+                    int base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&s_nlist, __popcll(mm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (go)
+                        s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)h[c];
+                }
+                if (STATS && b.stats) {
+                    const unsigned long long ma = __ballot(st[c] == kPsApprox && mine);
+                    if (lane == 0 && ma)
+                        atomicAdd(&b.stats[4], (unsigned long long)__popcll(ma) * (unsigned long long)nc);
+                }
+            }
         }
-        if (STATS && b.stats) {
-            const unsigned long long ma = __ballot(st[c] == kPsApprox && half == 0);
-            if (lane == 0 && ma)
-                atomicAdd(&b.stats[3], (unsigned long long)__popcll(ma) * (unsigned long long)n1);
-        }
+        c0 += kDenseChunk;
+    } while (c0 < n1);
+    __syncthreads();
+    const int nl = s_nlist;
+    if (nl > 0) {
+        if (tid == 0)
+            s_base = atomicAdd(&b.ccount[pair], nl);
+        __syncthreads();
+        uint32_t *dst = b.clist + (size_t)pair * Hp + s_base;
+        for (int i = tid; i < nl; i += kDenseThreads)
+            dst[i] = s_list[i];
     }
 }
 
@@ -2599,11 +2716,23 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.threads = kCnt32Threads;
         d.dynamic_lds = count32_lds_bytes(max_kp);
         break;
+    case kKRansacCountPilot:
+        d.name = "ransac_count32_kernel<768, 4, 4, 0, false>";
+        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>);
+        d.threads = kCnt32Threads;
+        d.dynamic_lds = count32_lds_bytes(max_kp);
+        break;
+    case kKRansacCountFinish:
+        d.name = "ransac_count32_kernel<768, 4, 4, 2, false>";
+        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>);
+        d.threads = kCnt32Threads;
+        d.dynamic_lds = count32_lds_bytes(max_kp);
+        break;
     case kKRansacCountMfma:
         d.name = "ransac_count_mfma_kernel<false>";
         d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>);
         d.threads = kDenseThreads;
-        d.dynamic_lds = (size_t)kDenseChunk * 16 * sizeof(float);
+        d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * 64 * kHypRec * 8;
         break;
     case kKRansacSurvivors:
         d.name = "ransac_survivors_kernel";
@@ -2733,7 +2862,7 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
-static int g_count_dense = 0;   // diagnostics: 1 = pilot + dense matrix-core phase + finish instead of one counting launch
+static int g_count_dense = 1;   // 1 = pilot + dense matrix-core phase + finish; 0 (diagnostics) = one ransac_count32 launch
 void set_count_dense(int v) { g_count_dense = v; }
 static int g_force_mode = -1;   // diagnostics: -1 = the probe decides, 0 / 1 = every pair exact / pre-screened
 void set_prescreen_force(int m) { g_force_mode = m; }
@@ -2766,12 +2895,11 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     const size_t lds_cnt = count_lds_bytes(b.max_kp), lds_c32 = count32_lds_bytes(b.max_kp);
     // counting: single precision for the pairs in mode 1, double precision for the others (each launch's workgroups leave
     // at once for the pairs of the other kind)
-    // single-precision counting of the pairs in mode 1.  Default: ransac_count32_kernel over everything in one go.
-    // g_count_dense (diagnostics library only): three launches instead -- pilot (the first 256 hypotheses in full -> the
-    // pair's first bound) -> dense phase on the matrix cores (every hypothesis x the points that must be seen before anything
-    // can be dropped, no exit tests) -> finish (the listed hypotheses that can still reach the bound, from there on).
-    // Byte-identical results; measured slower on this part (5.1 + 1.3 ms against 5.2: the exact-fp32 MFMA runs at 37 % of its
-    // peak in this loop, profiles/r03_count32_experiments.md), so it is not the default.
+    // single-precision counting of the pairs in mode 1, three launches: pilot (the first 256 hypotheses in full -> the pair's
+    // first bound) -> dense phase on the matrix cores in split bf16 (every hypothesis x the points that must be seen before
+    // anything can be dropped, no exit tests) -> finish (the listed hypotheses that can still reach the bound, from there on).
+    // g_count_dense = 0 (diagnostics library only): ransac_count32_kernel over everything in one launch -- byte-identical
+    // results, 5.2 ms against 0.2 + 2.0 + 1.4 per 512 pairs (profiles/r03_count32_experiments.md).
     if (!g_count_dense) {
         if (lt) lt->mark(kKRansacCount32);
         if (stats)
@@ -2782,8 +2910,8 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
     } else {
         const int wg_pilot = std::max(1, std::min(wg, (kPilotHyp / kCnt32Slots) / (kCnt32Threads / 64)));
-        const size_t lds_dense = (size_t)kDenseChunk * 16 * sizeof(float);   // sixteen floats per point: its monomials for both lane halves
-        if (lt) lt->mark(kKRansacCount32);
+        const size_t lds_dense = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * 64 * kHypRec * 8;
+        if (lt) lt->mark(kKRansacCountPilot);
         if (stats)
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>), dim3(wg_pilot, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
@@ -2792,12 +2920,12 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
         if (lt) lt->mark(kKRansacCountMfma);
         if (stats)
-            hipLaunchKernelGGL(ransac_count_mfma_kernel<true>, dim3((H + 255) / 256, n_active), dim3(kDenseThreads), lds_dense,
+            hipLaunchKernelGGL(ransac_count_mfma_kernel<true>, dim3(((H + 255) / 256 + kDenseBatches - 1) / kDenseBatches, n_active), dim3(kDenseThreads), lds_dense,
                                stream, b, rp);
         else
-            hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3((H + 255) / 256, n_active), dim3(kDenseThreads), lds_dense,
+            hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3(((H + 255) / 256 + kDenseBatches - 1) / kDenseBatches, n_active), dim3(kDenseThreads), lds_dense,
                                stream, b, rp);
-        if (lt) lt->mark(kKRansacCount32);
+        if (lt) lt->mark(kKRansacCountFinish);
         if (stats)
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2, true>), dim3(wg, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);

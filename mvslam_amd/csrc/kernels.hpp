@@ -274,8 +274,12 @@ enum KernelId : int {
     kKRansacPrescreen, // approximate F + certified band per hypothesis
     kKRansacExactList, // exact solve of the listed hypotheses (flagged by the pre-screen / survivors of the count)
     kKRansacCount2,    // pruned counting with per-hypothesis thresholds (upper / lower bounds of the exact count)
-    kKRansacCount32,   // the same in single precision (thresholds widened by the binary32 evaluation error)
-    kKRansacCountMfma, // dense single-precision counting of the first points on the matrix cores (no exit tests)
+    kKRansacCount32,   // the same in single precision (thresholds widened by the binary32 evaluation error), everything in one
+                       // launch (A/B only: mvs_debug_set_count_dense(0))
+    kKRansacCountPilot,  // ransac_count32_kernel, phase 0: the first kPilotHyp hypotheses in full -> the pair's first bound
+    kKRansacCountMfma,   // dense counting of the points that must be seen before anything can be dropped: split bf16 on the
+                         // matrix cores, no exit tests
+    kKRansacCountFinish, // ransac_count32_kernel, phase 2: the listed hypotheses that can still reach the bound, from there on
     kKRansacSurvivors, // hypotheses whose upper bound reaches the pair's best lower bound -> work list
     kKFinModel,
     kKTriangulate,

@@ -224,10 +224,11 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
             // a fresh gather: the first one's values must not stay alive across the QR, and the scheduler must not hoist the
             // later columns above the earlier reflectors (it would rebuild the whole matrix in registers): the index is
             // made opaque AND tied to the previous reflector's scale
-            if (j == 0)
+            // ... of the column before the previous one: the gather of column j is in flight while column j - 1 is reduced
+            if (j < 2)
                 asm volatile("" : "+v"(idx[j]));
             else
-                asm volatile("" : "+v"(idx[j]) : "v"(beta[j > 0 ? j - 1 : 0]));
+                asm volatile("" : "+v"(idx[j]) : "v"(beta[j > 1 ? j - 2 : 0]));
             const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[j] * 4);
             const double a1 = (p.x - nm.m1x) * nm.s1, b1 = (p.y - nm.m1y) * nm.s1;   // normalise8's own operations
             const double a2 = (p.z - nm.m2x) * nm.s2, b2 = (p.w - nm.m2y) * nm.s2;
@@ -240,10 +241,14 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         }
 #pragma unroll
         for (int k = 0; k < j; ++k) {
-            double d = 0.0;
+            double d = 0.0, d1 = 0.0;   // two partial sums: half the length of the dependent chain
 #pragma unroll
-            for (int i = k; i < 9; ++i)
+            for (int i = k; i < 9; i += 2) {
                 d = dfma(v[k][i], col[i], d);
+                if (i + 1 < 9)
+                    d1 = dfma(v[k][i + 1], col[i + 1], d1);
+            }
+            d += d1;
             const double t = beta[k] * d;
 #pragma unroll
             for (int i = k; i < 9; ++i)
@@ -276,10 +281,14 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         n[i] = i == 8 ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 7; k >= 0; --k) {
-        double d = 0.0;
+        double d = 0.0, d1 = 0.0;
 #pragma unroll
-        for (int i = k; i < 9; ++i)
+        for (int i = k; i < 9; i += 2) {
             d = dfma(v[k][i], n[i], d);
+            if (i + 1 < 9)
+                d1 = dfma(v[k][i + 1], n[i + 1], d1);
+        }
+        d += d1;
         const double t = beta[k] * d;
 #pragma unroll
         for (int i = k; i < 9; ++i)

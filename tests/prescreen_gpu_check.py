@@ -126,7 +126,9 @@ def main():
                         stats["count_viol"] += 1
         # the whole stage: every pair exact / every pair pre-screened / the probe decides
         outs = []
-        for mode in (0, 1, 2, -1, 101):   # 101: mode 1 with the counting as pilot + dense matrix-core phase + finish
+        # 101: mode 1 with the counting as pilot + dense matrix-core phase + finish (the default); the others count with one
+        # ransac_count32 / ransac_count2 launch
+        for mode in (0, 1, 2, -1, 101):
             lib.mvs_debug_set_count_dense(C.c_int(1 if mode == 101 else 0))
             mode = 1 if mode == 101 else mode
             lib.mvs_debug_set_prescreen_force(C.c_int(mode))
@@ -137,7 +139,7 @@ def main():
             lib.mvs_debug_read_hyp_rec(b._h, C.c_int(0), C.c_int(1), None, None, None, info)
             stats["mode%d_list" % mode if mode >= 0 else "auto_list"] = [int(info[2]), int(info[3])]
         lib.mvs_debug_set_prescreen_force(C.c_int(-1))
-        lib.mvs_debug_set_count_dense(C.c_int(0))
+        lib.mvs_debug_set_count_dense(C.c_int(1))
         for k in ("results", "mask", "points", "point_idx", "matches"):
             assert (outs[0][k].tobytes() == outs[1][k].tobytes() == outs[2][k].tobytes() == outs[3][k].tobytes()
                     == outs[4][k].tobytes()), ("modes differ", thr, k)

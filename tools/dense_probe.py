@@ -15,3 +15,10 @@ for dense in (0, 1, 0, 1):
     for n, ms in b.time_kernels(prm, steps=3):
         t[n] = t.get(n, 0) + ms
     print(dense, {k: round(v, 3) for k, v in t.items() if 'count' in k}, flush=True)
+for dense in (0, 1):
+    lib.mvs_debug_set_count_dense(C.c_int(dense))
+    ws = b.stats(prm)
+    print(dense, {k: ws[k] for k in ("score_evals", "score_evals_executed", "score_evals_executed_f32", "exact_solves", "hypotheses")}, flush=True)
+for k, v in ctx.kernel_info(2000, 32).items():
+    if "mfma" in k or "count32" in k:
+        print(k, v, flush=True)
