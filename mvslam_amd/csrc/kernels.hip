@@ -1119,16 +1119,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         Fo[9] = flag == kPsApprox ? thr + band : thr;
     }
     b.hyp_okf[rec] = (uint8_t)flag;
-    // hypotheses without a certificate: append to the work list of the exact solve (one atomic per wavefront)
-    const unsigned long long need = __ballot(flag == kPsNeedExact);
-    if (need) {
-        unsigned base = 0;
-        if (lane == 0)
-            base = atomicAdd(&b.xcount[0], (unsigned)__popcll(need));
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (flag == kPsNeedExact)
-            b.xlist[base + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)rec;
-    }
+    // hypotheses without a certificate (flag kPsNeedExact) are put on the work list of the exact solve by
+    // ransac_survivors_kernel together with the survivors of the counting: an append here was one returning atomic on a
+    // single address per wavefront with a flagged lane (70 k per 512 pairs)
 }
 
 // exact solve of the hypotheses on the work list (flat indices pair * Hp + h; list `which`).  Persistent grid: wavefront
@@ -1915,32 +1908,64 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
-// approximate records whose upper-bound count reaches the pair's final bound: they may be the winner, so they get their
-// exact F (work list 1 -> ransac_exact_list_kernel) before ransac_select_kernel scores everything at or above the bound
+// The work list of the exact solve (-> ransac_exact_list_kernel): records the pre-screen could not certify, and approximate
+// records whose upper-bound count reaches the pair's final bound -- they may be the winner, so they get their exact F before
+// ransac_select_kernel scores everything at or above the bound.  Entries are collected per workgroup in LDS and appended
+// with one atomic per flush: a returning atomic per wavefront on the list's single counter stalls every wavefront for a
+// memory round trip and serialises in the L2.
+constexpr int kSurvList = 2048;
 __global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunParams rp, int n_active)
 {
+    __shared__ uint32_t s_l[kSurvList];
+    __shared__ int s_n;
+    __shared__ unsigned s_base;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     const size_t total = (size_t)n_active * Hp;
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0)
+        s_n = 0;
+    __syncthreads();
+    auto flush = [&]() {   // called by the whole workgroup
+        const int n = s_n;
+        if (n > 0) {
+            if (tid == 0)
+                s_base = atomicAdd(&b.xcount[0], (unsigned)n);
+            __syncthreads();
+            for (int i = tid; i < n; i += 256)
+                b.xlist[s_base + i] = s_l[i];
+            __syncthreads();
+            if (tid == 0)
+                s_n = 0;
+        }
+        __syncthreads();
+    };
     for (size_t base0 = (size_t)blockIdx.x * 256; base0 < total; base0 += (size_t)gridDim.x * 256) {
-        const size_t rec = base0 + threadIdx.x;
+        const size_t rec = base0 + tid;
         bool take = false;
         if (rec < total) {
             const int pair = (int)(rec / Hp);
             const uint32_t h = (uint32_t)(rec - (size_t)pair * Hp);
-            take = h < (uint32_t)rp.num_hypotheses && b.M[pair] >= 8 && b.mode[pair] != 0 && b.hyp_okf[rec] == kPsApprox &&
-                   b.hyp_cnt[rec] >= b.bound[pair];
+            if (h < (uint32_t)rp.num_hypotheses && b.M[pair] >= 8 && b.mode[pair] != 0) {
+                const int okf = b.hyp_okf[rec];
+                take = okf == kPsNeedExact || (okf == kPsApprox && b.hyp_cnt[rec] >= b.bound[pair]);
+            }
         }
         const unsigned long long m = __ballot(take);
         if (m) {
-            unsigned base = 0;
+            int base = 0;
             if (lane == 0)
-                base = atomicAdd(&b.xcount[0], (unsigned)__popcll(m));   // behind the entries the pre-screen flagged
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                base = atomicAdd(&s_n, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
             if (take)
-                b.xlist[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)rec;
+                s_l[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)rec;
         }
+        __syncthreads();           // every append of this round is in
+        const int n_now = s_n;
+        __syncthreads();           // ... and read by everyone before the next round appends: the decision is uniform
+        if (n_now > kSurvList - 256)
+            flush();
     }
+    flush();
 }
 
 // grid P, 256 threads.  bound[pair] is now the largest full count (every surviving hypothesis went through the
@@ -2941,7 +2966,7 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
         hipLaunchKernelGGL((ransac_count2_kernel<kCntThreads, kCntPpl>), dim3(wg, n_active), dim3(kCntThreads), lds_cnt, stream,
                            b, rp, wg);
     const size_t total = (size_t)n_active * b.max_groups * kHypPerBlock;
-    const int sg = (int)std::min<size_t>((total + 255) / 256, 8192);
+    const int sg = (int)std::min<size_t>((total + 255) / 256, 2048);
     if (lt) lt->mark(kKRansacSurvivors);
     hipLaunchKernelGGL(ransac_survivors_kernel, dim3(sg), dim3(256), 0, stream, b, rp, n_active);
     // one exact solve over the whole work list: what the pre-screen flagged + the survivors of the counting
