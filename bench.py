@@ -205,11 +205,21 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
             ev32 = stats["score_evals_executed_f32"]
             m1 = stats["pairs_mode"][1] / max(sum(stats["pairs_mode"]), 1)
             ev_pilot = min(int(PILOT_HYP * stats["matches"] * m1), ev32) if stats.get("score_evals_executed_mfma", 0) else 0
-            ev = ev_pilot if ", 0, false>" in name else ev32 - ev_pilot
+            ev = ev_pilot if ", 0, false>" in name and stats.get("score_evals_executed_mfma_finish", 0) == 0 else \
+                ev32 if ", 0, false>" in name else ev32 - ev_pilot
             fl_alg = fl_exec = ev * PER_EVAL
             e["evals_executed"] = int(ev)
             e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
             peak, bound = FP32_PEAK_TFLOPS, "valu_fp32"
+        elif name.startswith("ransac_finish_mfma_kernel"):
+            # the same tile product for the few per cent of the hypotheses the dense phase leaves: every point against the lower
+            # threshold, the points behind the dense phase against the upper one as well
+            ev = stats.get("score_evals_executed_mfma_finish", 0)
+            fl_alg = fl_exec = ev * PER_EVAL_MFMA
+            e["evals_executed"] = int(ev)
+            e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
+            e["evals_per_ns"] = round(ev / max(e["ms"] * 1e6, 1e-9), 2)
+            peak, bound = BF16_MFMA_PEAK_TFLOPS, "mfma_bf16"
         elif name.startswith("ransac_count_mfma_kernel"):
             # dense phase: every evaluation is 27 products of bf16 parts (hi hi + hi lo + lo hi over the nine monomials) on
             # the matrix cores (two v_mfma_f32_32x32x16_bf16 per 32 x 32 tile, 5 of the 32 K slots are zero padding) plus

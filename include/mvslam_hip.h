@@ -267,6 +267,7 @@ typedef struct mvs_work_stats {
     int64_t pairs_mode[3];        /* pairs per mode: 0 every hypothesis exact, 1 pre-screened + single-precision counting,
                                      2 pre-screened + double-precision counting */
     int64_t score_evals_executed_mfma; /* the part of score_evals_executed done by the dense matrix-core phase (split bf16) */
+    int64_t score_evals_executed_mfma_finish; /* ... and by the matrix-core finish (upper and lower bound per evaluation) */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 

@@ -106,7 +106,8 @@ class WorkStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("hypotheses", "rotations9", "pairs9", "score_evals", "matches", "inliers",
                                               "score_evals_executed", "score_evals_executed_f32", "exact_solves",
                                               "prescreened")] + [("pairs_mode", C.c_int64 * 3),
-                                                                 ("score_evals_executed_mfma", C.c_int64)]
+                                                                 ("score_evals_executed_mfma", C.c_int64),
+                                                                 ("score_evals_executed_mfma_finish", C.c_int64)]
 
 
 class KernelInfo(C.Structure):

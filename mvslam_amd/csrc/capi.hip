@@ -241,7 +241,7 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if ((st = dev_alloc(b, &hc, P * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &xl, P * Hp)) != MVS_OK) return st;
     uint32_t *cl = nullptr;
-    if ((st = dev_alloc(b, &cl, P * Hp)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &cl, 2 * P * Hp)) != MVS_OK) return st;   // the list + its sorted copy
     if (!b->d.bound && (st = dev_alloc(b, &b->d.bound, P)) != MVS_OK) return st;
     if (!b->d.box && (st = dev_alloc(b, &b->d.box, P * 8)) != MVS_OK) return st;
     if (!b->d.mode && (st = dev_alloc(b, &b->d.mode, P)) != MVS_OK) return st;
@@ -1036,22 +1036,23 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     b->d.hyp_count = nullptr;
     b->d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 5 * sizeof(unsigned long long), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 6 * sizeof(unsigned long long), s));
     st = enqueue_pipeline(b, to_run(*params), n_active, true, nullptr);
     if (st != MVS_OK)
         return st;
     HIP_TRY(ctx, sync_stream(ctx));
-    unsigned long long h[5];
+    unsigned long long h[6];
     HIP_TRY(ctx, hipMemcpy(h, b->d.stats, sizeof(h), hipMemcpyDeviceToHost));
     std::vector<mvs_pair_result> res(n_active);
     HIP_TRY(ctx, hipMemcpy(res.data(), b->d.results, n_active * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     out->rotations9 = (int64_t)h[0];
     out->pairs9 = (int64_t)h[1];
-    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4]);   // double-, single-precision and matrix-core counting
+    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4] + h[5]);   // double-, single-precision and matrix-core counting
     out->score_evals_executed_f32 = (int64_t)h[3];
     out->score_evals_executed_mfma = (int64_t)h[4];
-    if (b->d.mode && b->d.xcount && h[2] + h[3] + h[4] > 0) {   // the pre-screened stage ran: its bookkeeping
+    out->score_evals_executed_mfma_finish = (int64_t)h[5];
+    if (b->d.mode && b->d.xcount && h[2] + h[3] + h[4] + h[5] > 0) {   // the pre-screened stage ran: its bookkeeping
         std::vector<int32_t> mode(n_active);
         uint32_t xc[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpy(mode.data(), b->d.mode, n_active * sizeof(int32_t), hipMemcpyDeviceToHost));

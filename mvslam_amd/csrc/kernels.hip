@@ -1908,6 +1908,250 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
+// The pair's list in the order of the dense phase's counts, largest first (counting sort on the count, one workgroup per
+// pair; the sorted list is the second half of clist).  The finish then meets the likely winners in its first batches.
+constexpr int kSortBins = kMaxKp + 1;
+__global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
+{
+    __shared__ int s_hist[kSortBins];
+    __shared__ int s_scan[256];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8 || b.mode[pair] != 1)
+        return;
+    const int n = b.ccount[pair];
+    if (n <= 0)
+        return;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const uint32_t *in = b.clist + (size_t)pair * Hp;
+    uint32_t *out = b.clist + ((size_t)b.n_pairs + pair) * Hp;
+    const int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
+    for (int i = tid; i < kSortBins; i += 256)
+        s_hist[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < n; e += 256)
+        atomicAdd(&s_hist[min(max(cntp[in[e]], 0), kSortBins - 1)], 1);
+    __syncthreads();
+    // exclusive prefix over the bins in DESCENDING order of the count: thread t owns a run of consecutive bins from the top
+    constexpr int per = (kSortBins + 255) / 256;
+    int run = 0;
+    for (int k = 0; k < per; ++k) {
+        const int bin = kSortBins - 1 - (tid * per + k);
+        run += bin >= 0 ? s_hist[bin] : 0;
+    }
+    s_scan[tid] = run;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? s_scan[tid - o] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int off = s_scan[tid] - run;
+    for (int k = 0; k < per; ++k) {
+        const int bin = kSortBins - 1 - (tid * per + k);
+        if (bin >= 0) {
+            const int c = s_hist[bin];
+            s_hist[bin] = off;
+            off += c;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const uint32_t h = in[e];
+        out[atomicAdd(&s_hist[min(max(cntp[h], 0), kSortBins - 1)], 1)] = h;
+    }
+}
+
+// The FINISH on the matrix cores.  What the dense phase could not drop against the PILOT's bound (a quarter of the
+// hypotheses) is worked off in batches of 256 list entries, best partial counts first, grid (P, batches): the same tile
+// product, indicators against tl' = tl - 2^-15 T for every point (the lower-bound count L) and against tu' = tu + 2^-15 T for
+// the points from n1 on (added to the dense phase's count in hyp_cnt: the upper bound U).  max L raises the pair's bound (one
+// atomic per workgroup); a batch starts by dropping the entries that can no longer reach the bound as it stands, and leaves
+// at once if none can -- after the first batches of a pair that is the usual case (the winner is among the largest
+// partial counts).  An entry that is dropped can never matter: its upper bound is below a lower bound of another hypothesis.
+// ransac_survivors_kernel compares U with the final bound as before.  The points past M in the last tile are staged as zero
+// monomials: their residual is exactly 0, so each is counted once by every positive threshold and subtracted again.
+template <bool STATS>
+__global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_mfma_kernel(BatchDev b,
+                                                                                                                     RunParams rp,
+                                                                                                                     int batch0)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
+    __shared__ int s_lmax;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8 || b.mode[pair] != 1)
+        return;
+    const int n_list = b.ccount[pair];
+    const int e0 = (batch0 + blockIdx.y) * kDenseThreads;   // first list entry of the workgroup
+    if (e0 >= n_list)
+        return;
+    if (tid == 0)
+        s_lmax = -1;
+    const int n1 = b.dense_n1[pair];
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const uint32_t *clist = b.clist + ((size_t)b.n_pairs + pair) * Hp;   // sorted by ransac_list_sort_kernel
+    const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ew = e0 + w * 64;   // first list entry of the wavefront (two blocks of 32)
+    int h[2], ucnt0[2];
+    bool on[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int e = ew + 32 * c + col;
+        h[c] = e < n_list ? (int)clist[e] : 0;
+        ucnt0[c] = b.hyp_cnt[(size_t)pair * Hp + h[c]];   // the dense phase's count over [0, n1)
+        // still able to reach the bound as it stands now?
+        on[c] = e < n_list && !(ucnt0[c] + (M - n1) < Bnow);
+    }
+    if (!__syncthreads_or(on[0] || on[1]))
+        return;   // (also orders s_lmax)
+    bool wave_live = __ballot(on[0] || on[1]) != 0ull;
+    bool wave_dead = false;   // left by the exit test: upper counts stay partial, no lower bound
+    int ntile = 0;
+    uint4 *s_op = reinterpret_cast<uint4 *>(s_cpts);
+    const PairBox bx = load_box(b, pair);
+    const float X1 = (float)fmax(dabs(bx.x1lo), dabs(bx.x1hi)) * (1.f + 0x1p-22f);
+    const float Y1 = (float)fmax(dabs(bx.y1lo), dabs(bx.y1hi)) * (1.f + 0x1p-22f);
+    const float X2 = (float)fmax(dabs(bx.x2lo), dabs(bx.x2hi)) * (1.f + 0x1p-22f);
+    const float Y2 = (float)fmax(dabs(bx.y2lo), dabs(bx.y2hi)) * (1.f + 0x1p-22f);
+    const f32x2 negH = {-0x1p100f, -0x1p100f};
+    bool lpos[2];
+    v8bf Bop[2][2];
+    f32x2 tuH[2], tlH[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_F + ((size_t)pair * Hp + h[c]) * kHypRec);
+        const float4 q0 = fr4[0], q1 = fr4[1], q2 = fr4[2];
+        const float fr[11] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
+        float Ff[9];
+        uint32_t fh[9], fl[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            Ff[k] = on[c] ? fr[k] : 0.f;
+            bf16_split(Ff[k], fh[k], fl[k]);
+        }
+        uint4 op[2];
+        dense_operands(fh, fl, half, 1, op);
+        Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
+        Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
+        const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
+        const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
+        const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
+        const float ebf = 0x1p-15f * (fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f));
+        const float tu = on[c] ? (fr[9] + ebf) * (1.f + 0x1p-22f) : 0.f;
+        // the lower threshold only shrinks; every |a| < tl' must be counted by an UPPER count and none above it by this
+        // LOWER one: T2 = tl'^2 (1 - 2^-21)
+        const float tl = on[c] ? (fr[10] - ebf) * (1.f - 0x1p-22f) : 0.f;
+        lpos[c] = tl > 0.f;
+        const float tuh = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
+        const float tlh = lpos[c] ? (tl * tl) * (1.f - 0x1p-21f) * 0x1p100f : 0.f;
+        tuH[c] = f32x2{tuh, tuh};
+        tlH[c] = f32x2{tlh, tlh};
+    }
+    f32x2 cu[2] = {{0.f, 0.f}, {0.f, 0.f}}, cl[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+    const int Mr = (M + 31) & ~31;
+    for (int c0 = 0; c0 < Mr; c0 += kDenseChunk) {
+        const int nc = min(kDenseChunk, Mr - c0);
+        __syncthreads();
+        for (int i = tid; i < nc; i += kDenseThreads) {
+            uint4 o0[2], o1[2];
+            if (c0 + i < M) {
+                const double4 pd = src[c0 + i];
+                const float x1 = (float)pd.x, y1 = (float)pd.y, x2 = (float)pd.z, y2 = (float)pd.w;
+                const float ph[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.f};
+                uint32_t mh[9], ml[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    bf16_split(ph[k], mh[k], ml[k]);
+                dense_operands(mh, ml, 0, 2, o0);
+                dense_operands(mh, ml, 1, 2, o1);
+            } else {
+                o0[0] = o0[1] = o1[0] = o1[1] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            uint4 *q = s_op + (size_t)(i >> 5) * 128 + (i & 31);
+            q[0] = o0[0];
+            q[32] = o1[0];
+            q[64] = o0[1];
+            q[96] = o1[1];
+        }
+        __syncthreads();
+        if (!wave_live || wave_dead)
+            continue;
+        for (int p0 = 0; p0 < nc; p0 += 32) {
+            if (c0 + p0 > n1 && ((c0 + p0) & 255) == 0) {
+                // exit test of the wavefront, every 256 points behind the dense phase: the list is sorted, so the 64
+                // entries of a wavefront are of one quality and die together.  A dead entry keeps an upper-bound count
+                // below the bound (what it has + what is left < the bound), its lower bound cannot matter
+                const int bn = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool any = false;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    int U = (int)(cu[c].x + cu[c].y);
+                    U += __shfl_xor(U, 32);
+                    any = any || (on[c] && !(ucnt0[c] + U + (M - (c0 + p0)) < bn));
+                }
+                if (__ballot(any) == 0ull) {
+                    wave_dead = true;
+                    break;
+                }
+            }
+            const uint4 *q = s_op + (size_t)(p0 >> 5) * 128 + half * 32 + col;
+            const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
+            v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
+            ++ntile;
+            if (c0 + p0 >= n1) {   // (wave-uniform) behind the dense phase: both counts
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 x0 = {a0[r], a0[r + 1]}, x1 = {a1[r], a1[r + 1]};
+                    const f32x2 s0 = pk_mul(x0, x0), s1 = pk_mul(x1, x1);
+                    cu[0] = pk_add(cu[0], pk_ind(s0, negH, tuH[0]));
+                    cl[0] = pk_add(cl[0], pk_ind(s0, negH, tlH[0]));
+                    cu[1] = pk_add(cu[1], pk_ind(s1, negH, tuH[1]));
+                    cl[1] = pk_add(cl[1], pk_ind(s1, negH, tlH[1]));
+                }
+            } else {
+                dense_count(a0, negH, tlH[0], cl[0]);
+                dense_count(a1, negH, tlH[1], cl[1]);
+            }
+        }
+    }
+    const int npad = Mr - M;   // zero rows of the last tile: counted once by every positive threshold
+    int lbest = -1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int U = (int)(cu[c].x + cu[c].y), L = (int)(cl[c].x + cl[c].y);
+        U += __shfl_xor(U, 32);
+        L += __shfl_xor(L, 32);
+        U -= wave_dead ? 0 : npad;
+        L -= lpos[c] ? npad : 0;
+        if (half == 0 && on[c]) {
+            const size_t rec = (size_t)pair * Hp + h[c];
+            b.hyp_cnt[rec] = ucnt0[c] + U;   // + the dense phase's count over [0, n1)
+            if (!wave_dead)
+                lbest = max(lbest, L);
+        }
+        if (STATS && b.stats) {
+            const unsigned long long ma = __ballot(wave_live && half == 0);   // a live wavefront computes all its columns
+            if (lane == 0 && ma)
+                atomicAdd(&b.stats[5], (unsigned long long)__popcll(ma) * (unsigned long long)(32 * ntile));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        lbest = max(lbest, __shfl_xor(lbest, o));
+    if (lane == 0 && lbest >= 0)
+        atomicMax(&s_lmax, lbest);
+    __syncthreads();
+    if (tid == 0 && s_lmax >= 0)
+        __hip_atomic_fetch_max(b.bound + pair, s_lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The work list of the exact solve (-> ransac_exact_list_kernel): records the pre-screen could not certify, and approximate
 // records whose upper-bound count reaches the pair's final bound -- they may be the winner, so they get their exact F before
 // ransac_select_kernel scores everything at or above the bound.  Entries are collected per workgroup in LDS and appended
@@ -2748,10 +2992,10 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.dynamic_lds = count32_lds_bytes(max_kp);
         break;
     case kKRansacCountFinish:
-        d.name = "ransac_count32_kernel<768, 4, 4, 2, false>";
-        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>);
-        d.threads = kCnt32Threads;
-        d.dynamic_lds = count32_lds_bytes(max_kp);
+        d.name = "ransac_finish_mfma_kernel<false>";
+        d.fn = reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>);
+        d.threads = kDenseThreads;
+        d.dynamic_lds = (size_t)kDenseChunk * 64;
         break;
     case kKRansacCountMfma:
         d.name = "ransac_count_mfma_kernel<false>";
@@ -2802,6 +3046,8 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2, true>),
                          reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_count_mfma_kernel<true>),
+                         reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
+                         reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
@@ -2887,7 +3133,8 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
-static int g_count_dense = 1;   // 1 = pilot + dense matrix-core phase + finish; 0 (diagnostics) = one ransac_count32 launch
+static int g_count_dense = 1;   // 1 = pilot + dense matrix-core phase + matrix-core finish; diagnostics: 0 = one
+                                // ransac_count32 launch, 2 = pilot + dense phase + the vector finish (ransac_count32, phase 2)
 void set_count_dense(int v) { g_count_dense = v; }
 static int g_force_mode = -1;   // diagnostics: -1 = the probe decides, 0 / 1 = every pair exact / pre-screened
 void set_prescreen_force(int m) { g_force_mode = m; }
@@ -2951,12 +3198,28 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
             hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3(((H + 255) / 256 + kDenseBatches - 1) / kDenseBatches, n_active), dim3(kDenseThreads), lds_dense,
                                stream, b, rp);
         if (lt) lt->mark(kKRansacCountFinish);
-        if (stats)
-            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2, true>), dim3(wg, n_active),
-                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
-        else
+        const dim3 fin_grid(n_active, (H + kDenseThreads - 1) / kDenseThreads);   // workgroups past the list's end leave at once
+        if (g_count_dense != 2)
+            hipLaunchKernelGGL(ransac_list_sort_kernel, dim3(n_active), dim3(256), 0, stream, b);
+        if (g_count_dense == 2) {   // diagnostics: the vector finish (ransac_count32_kernel, phase 2)
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>), dim3(wg, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
+        } else {
+            // two launches: the first batch of every pair (the 256 largest partial counts: the winner is nearly always among
+            // them, so the pair's bound is final afterwards), then the rest -- whose workgroups mostly find nothing left
+            const int nb = (int)fin_grid.y;
+            for (int part = 0; part < 2; ++part) {
+                const dim3 g(n_active, part == 0 ? 1 : nb - 1);
+                if (g.y == 0)
+                    break;
+                if (stats)
+                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<true>, g, dim3(kDenseThreads), (size_t)kDenseChunk * 64, stream,
+                                       b, rp, part);
+                else
+                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, g, dim3(kDenseThreads), (size_t)kDenseChunk * 64, stream,
+                                       b, rp, part);
+            }
+        }
     }
     if (lt) lt->mark(kKRansacCount2);
     if (stats)

@@ -279,7 +279,7 @@ enum KernelId : int {
     kKRansacCountPilot,  // ransac_count32_kernel, phase 0: the first kPilotHyp hypotheses in full -> the pair's first bound
     kKRansacCountMfma,   // dense counting of the points that must be seen before anything can be dropped: split bf16 on the
                          // matrix cores, no exit tests
-    kKRansacCountFinish, // ransac_count32_kernel, phase 2: the listed hypotheses that can still reach the bound, from there on
+    kKRansacCountFinish, // the listed hypotheses that can still reach the bound: upper and lower count bounds, matrix cores
     kKRansacSurvivors, // hypotheses whose upper bound reaches the pair's best lower bound -> work list
     kKFinModel,
     kKTriangulate,

@@ -126,11 +126,11 @@ def main():
                         stats["count_viol"] += 1
         # the whole stage: every pair exact / every pair pre-screened / the probe decides
         outs = []
-        # 101: mode 1 with the counting as pilot + dense matrix-core phase + finish (the default); the others count with one
-        # ransac_count32 / ransac_count2 launch
-        for mode in (0, 1, 2, -1, 101):
-            lib.mvs_debug_set_count_dense(C.c_int(1 if mode == 101 else 0))
-            mode = 1 if mode == 101 else mode
+        # 101: mode 1 with the counting as pilot + dense matrix-core phase + matrix-core finish (the default), 102: the same
+        # with the vector finish; the others count with one ransac_count32 / ransac_count2 launch
+        for mode in (0, 1, 2, -1, 101, 102):
+            lib.mvs_debug_set_count_dense(C.c_int(mode - 100 if mode > 100 else 0))
+            mode = 1 if mode > 100 else mode
             lib.mvs_debug_set_prescreen_force(C.c_int(mode))
             b.run(prm)
             b.sync()
@@ -141,8 +141,7 @@ def main():
         lib.mvs_debug_set_prescreen_force(C.c_int(-1))
         lib.mvs_debug_set_count_dense(C.c_int(1))
         for k in ("results", "mask", "points", "point_idx", "matches"):
-            assert (outs[0][k].tobytes() == outs[1][k].tobytes() == outs[2][k].tobytes() == outs[3][k].tobytes()
-                    == outs[4][k].tobytes()), ("modes differ", thr, k)
+            assert all(outs[0][k].tobytes() == o_[k].tobytes() for o_ in outs[1:]), ("modes differ", thr, k)
         for p in range(P):
             ref = o.image_pair(data["desc1"][p], data["kp1"][p], data["desc2"][p], data["kp2"][p], data["K"][p].reshape(3, 3),
                                o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(data["global_index"][p]), thr), 0.7, 10.0)

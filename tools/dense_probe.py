@@ -8,7 +8,7 @@ ctx = capi.Context(0); b = capi.Batch(ctx, P, 2000, 32)
 b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
 prm = capi.default_params(num_hypotheses=50000, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
 lib = capi.lib()
-for dense in (0, 1, 0, 1):
+for dense in ((1, 1, 1) if os.environ.get('DENSE_ONLY') else (0, 1, 0, 1)):
     lib.mvs_debug_set_count_dense(C.c_int(dense))
     b.run(prm); b.sync()
     t = {}
