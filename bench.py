@@ -104,10 +104,10 @@ PER_EVAL_MFMA = 54    # the same evaluation in split bf16: 27 multiply-adds on t
 PILOT_HYP = 256       # kPilotHyp (kernels.hip): hypotheses the pilot launch counts in full per pair
 # the pre-screen of one hypothesis (prescreen.hpp): normalise x2 184, design row products + ||A||_F^2 112,
 # Householder QR of the 9x8 (392 fma + 44 fma for the norms + 8 sqrt + 8 div + 40) 920, null vector 176, triangular inverse
-# + its Frobenius norm 284, a-posteriori residual (second gather) 208, rank-2 through one verified singular triplet (G^T G and
-# its characteristic polynomial 58, eight Newton steps 120, cross products + normalisation 66, w / X / sigma / u / eps2 112, second
-# singular value of X from its invariants 111) 467, de-normalise 36, bounds 116
-PER_PRESCREEN = 184 + 112 + 920 + 176 + 284 + 208 + 467 + 36 + 116
+# + its Frobenius norm 284, rank-2 through one verified singular triplet (G^T G and its characteristic polynomial 58, eight
+# Newton steps 120, cross products + normalisation 66, w / X / sigma / u / eps2 112, second singular value of X from its
+# invariants 111) 467, de-normalise 36, bounds 116
+PER_PRESCREEN = 184 + 112 + 920 + 176 + 284 + 467 + 36 + 116
 
 
 def solve_flops(stats):

@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_prescreen_kernel(BatchDev b, RunParams rp)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void ransac_prescreen_kernel(BatchDev b, RunParams rp)
 {
     __shared__ double s_park[kPsParked * 64];   // this wavefront's parked R entries: [entry][lane]
     const int pair = blockIdx.y, lane = threadIdx.x;

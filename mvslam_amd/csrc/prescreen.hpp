@@ -179,7 +179,9 @@ MVS_DEV void prescreen_denormalise(const double (&Fn)[9], const EightNorm &nm, d
     }
 }
 
-constexpr int kPsParked = 28;   // strict upper triangle of R, parked in LDS: [kPsParked][64 lanes] doubles per wavefront
+constexpr int kPsTri = 28;      // strict upper triangle of R
+constexpr int kPsParked = 26;   // ... of which this many are parked in LDS, [kPsParked][64 lanes] doubles per wavefront (13 KB:
+                                // twelve wavefronts per CU); the last two (R_57, R_67, produced last) stay in registers
 MVS_DEV constexpr int ps_tri(int i, int k) { return k * (k - 1) / 2 + i; }   // (i, k), i < k  ->  0 .. 27
 
 // flag (kPs*), F~ and band for one sample.  P: the pair's points [M][4]; idx: the sample; park: this lane's column of the
@@ -214,6 +216,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         return kPsInvalid;
     }
     double v[8][9];   // v[k][k..8]: reflector k (entries below k are never touched)
+    double rlast[kPsTri - kPsParked];
     double rd[8], beta[8];
     double S = 0.0;   // ||A||_F^2
     bool piv_ok = !tiny;
@@ -253,7 +256,10 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
 #pragma unroll
             for (int i = k; i < 9; ++i)
                 col[i] = dfma(-t, v[k][i], col[i]);
-            park[ps_tri(k, j) * 64] = col[k];   // R_kj
+            if (ps_tri(k, j) < kPsParked)
+                park[ps_tri(k, j) * 64] = col[k];   // R_kj
+            else
+                rlast[ps_tri(k, j) - kPsParked] = col[k];
         }
         double ss = 0.0;
 #pragma unroll
@@ -298,10 +304,10 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     // reflectors are dead by now)
     double y2sum = 0.0;
     {
-        double R[kPsParked];
+        double R[kPsTri];
 #pragma unroll
-        for (int q = 0; q < kPsParked; ++q)
-            R[q] = park[q * 64];
+        for (int q = 0; q < kPsTri; ++q)
+            R[q] = q < kPsParked ? park[q * 64] : rlast[q - kPsParked];
         double inv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -323,35 +329,18 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         }
     }
     const double yf = dsqrt(y2sum) * (1.0 + 1e-12);
-    // a-posteriori residual of n~ against the ORIGINAL rows of A, rebuilt from a second gather of the sample (the indices
-    // are made opaque so that the compiler does not keep the first gather's values alive across the QR instead)
-    double rho2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        // opaque index, tied to the result of the previous stage: hoisted above the triangular inverse these sixteen loads
-        // were spilled to scratch memory as they arrived
-        asm volatile("" : "+v"(idx[i]) : "v"(yf));
-        const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[i] * 4);
-        const double a1 = (p.x - nm.m1x) * nm.s1, b1 = (p.y - nm.m1y) * nm.s1;   // normalise8's own operations: same bits
-        const double a2 = (p.z - nm.m2x) * nm.s2, b2 = (p.w - nm.m2y) * nm.s2;
-        double r = n[8];
-        r = dfma(a1, n[6], r);
-        r = dfma(b1, n[7], r);
-        r = dfma(a2, n[2], r);
-        r = dfma(b2, n[5], r);
-        r = dfma(a2 * a1, n[0], r);
-        r = dfma(a2 * b1, n[1], r);
-        r = dfma(b2 * a1, n[3], r);
-        r = dfma(b2 * b1, n[4], r);
-        rho2 = dfma(r, r, rho2);
-    }
-    const double rho = dsqrt(rho2) * (1.0 + 1e-12);
+    // residual of n~ against the rows of A -- a priori: with A^T + E = Q~ [R^; 0] (||E||_F <= 176 u ||A||_F, Q~ within 250 u of
+    // orthogonal: DESIGN.md 4.3e (iii)) and n~ = the computed Q~ e_9 (eight reflector applications, <= 176 u of rounding),
+    // A n~ = [R^T 0] Q~^T n~ - E^T n~ and Q~^T n~ = e_9 up to 500 u + 176 u, so || A n~ || <= 852 u ||A||_F + 176 u ||A||_F.
+    // (The first version measured it from a second gather of the sample: 208 flop and eight loads per hypothesis for a term
+    // that is five orders of magnitude below eta_J.)
+    const double rho = 1.2e-13 * sqrtS;
     // sigma_8(A) >= (1 - z) / ||R^-1||_F (1 - 250 u) - 176 u ||A||_F
     const double z = 12.0 * kPsU * sqrtS * yf;
     const double sig8 = (1.0 - z) / yf * (1.0 - 1e-13) - 4e-14 * sqrtS;
     const double g = sig8 * sig8;
     const double eta_j = 1.01 * kPsTauC * S / g + kPsEtaQ;
-    const double eta_a = 1.5 * (rho + 1.2e-15 * sqrtS) / sig8 + 1e-13;
+    const double eta_a = 1.5 * rho / sig8 + 1e-13;
     // rank-2 through one verified singular triplet of reshape(n~), de-normalisation
     double Fn[9], e3, sige, extra, s2lb;
     bool ok3;

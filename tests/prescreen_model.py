@@ -8,10 +8,10 @@ samples.  The product path never imports this file.
 
 Per sample (8 point pairs, Hartley-normalised exactly like the exact path):
   A (8 x 9)  ->  Householder QR of A^T (9 x 8)  ->  n~ = Q e_9 (unit null vector), R (8 x 8 upper triangular)
-  rho = ||A n~||                      a-posteriori residual of the approximate null vector
+  rho = 1.2e-13 ||A||_F >= ||A n~||   a-priori residual of the Householder null vector (the model asserts it)
   sigma8_lb <= sigma_8(A)             from ||R^-1||_F (explicit triangular inverse, backward-stable solve)
   eta_J  = 1.01 tau' / sigma8_lb^2 + 4e-12,   tau' = 2e-12 ||A||_F^2      exact path's null vector vs the true one
-  eta_A  = 1.5 (rho + 1.2e-15 ||A||_F) / sigma8_lb + 1e-13                approximate null vector vs the true one
+  eta_A  = 1.5 rho / sigma8_lb + 1e-13                                     approximate null vector vs the true one
   rank-2 step: ONE verified singular triplet (sig, u, v) of G = reshape(n~): v any approximation of the smallest right singular
   vector, w = G v, sig = ||w||, u = w / sig, eps2 = ||G^T u - sig v||; X = G - w v^T; s2lb <= sigma_2(X) from X's invariants
   e, sig_e, extra = (eps2, sig, eps2) if eps2 < sig else (sig, 0, 0)   (+ 1e-12 of roundings each)
@@ -136,7 +136,8 @@ def prescreen(x1, y1, x2, y2, bbox, v3=None):
     A = design(a1, b1, a2, b2)
     S = float((A * A).sum()) * (1 + 1e-12)
     n, R = householder_null(A)
-    rho = float(np.sqrt(((A @ n) ** 2).sum()))
+    rho = 1.2e-13 * np.sqrt(S)     # a-priori bound of ||A n~|| for the Householder null vector (1028 u ||A||_F)
+    assert float(np.sqrt(((A @ n) ** 2).sum())) <= rho
     yf, _ = tri_inverse_fro(R)
     rf = float(np.sqrt((R * R).sum()))
     if not np.isfinite(yf):
@@ -149,7 +150,7 @@ def prescreen(x1, y1, x2, y2, bbox, v3=None):
         return out
     g = sig8 * sig8
     eta_j = 1.01 * TAU_C * S / g + ETA_Q
-    eta_a = 1.5 * (rho + 1.2e-15 * np.sqrt(S)) / sig8 + 1e-13
+    eta_a = 1.5 * rho / sig8 + 1e-13
     Fn, e3, sig_e, extra, s2lb = rank2(n, v3)
     eta = eta_j + eta_a + e3 + SVD3_E
     delta = s2lb - extra - sig_e - eta
