@@ -231,7 +231,8 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
             e["evals_per_ns"] = round(ev / max(e["ms"] * 1e6, 1e-9), 2)
             peak, bound = BF16_MFMA_PEAK_TFLOPS, "mfma_bf16"
         elif name.startswith("ransac_count_kernel") or name.startswith("ransac_count2_kernel"):
-            ev64 = stats["score_evals_executed"] - stats["score_evals_executed_f32"]
+            ev64 = stats["score_evals_executed"] - stats["score_evals_executed_f32"] - \
+                stats.get("score_evals_executed_mfma", 0) - stats.get("score_evals_executed_mfma_finish", 0)
             fl_alg = stats["score_evals"] * PER_EVAL
             fl_exec = ev64 * PER_EVAL
             e["evals_executed_frac"] = round(ev64 / max(stats["score_evals"], 1), 4)
@@ -263,7 +264,8 @@ def roofline_object(table, stats, traffic, traffic_src):
         "bound": dom.get("bound", "valu_fp64"), "kernel": dom_name,
         "bound_detail": "vector FMA rate of the kernel's arithmetic type: fp64 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = "
                         "78.6 TFLOP/s (v_mfma_f64 shares the pipe: profiles/r02_mfma_coissue_microbench.txt), fp32 157.3 "
-                        "TFLOP/s (v_pk_fma_f32)",
+                        "TFLOP/s (v_pk_fma_f32); mfma_bf16: 2500 TFLOP/s dense (the split-bf16 counting kernels, whose "
+                        "three packed vector instructions per two evaluations bound them well below that: DESIGN.md 4.3e)",
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
         "frac_definition": "EXECUTED algorithmic flops of the dominant kernel / its launch time (HIP events) / the vector "
                            "peak of its arithmetic type",
@@ -281,7 +283,9 @@ def roofline_object(table, stats, traffic, traffic_src):
         "work": {"hypotheses": int(stats["hypotheses"]), "exact_solves": int(stats["exact_solves"]),
                  "prescreened_only": int(stats["prescreened"]), "pairs_mode": stats["pairs_mode"],
                  "evals_possible": int(stats["score_evals"]), "evals_executed": int(stats["score_evals_executed"]),
-                 "evals_executed_f32": int(stats["score_evals_executed_f32"])},
+                 "evals_executed_f32": int(stats["score_evals_executed_f32"]),
+                 "evals_executed_mfma_dense": int(stats.get("score_evals_executed_mfma", 0)),
+                 "evals_executed_mfma_finish": int(stats.get("score_evals_executed_mfma_finish", 0))},
         "per_kernel": table,
         "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
                            "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"}

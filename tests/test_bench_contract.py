@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, "profiles", "bench_r02_default.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "bench_r03_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -16,16 +16,29 @@ def test_committed_bench_line_has_every_contract_field():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "valu_fp64" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] in ("valu_fp64", "valu_fp32", "mfma_bf16") and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # executed-work table per kernel, registers / LDS / occupancy from the runtime (mvs_kernel_info_get)
+    pk = r["per_kernel"]
+    assert r["kernel"] in pk and abs(pk[r["kernel"]]["ms"] - r["launch_ms"]) < 1e-6
+    for name in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel<false>", "ransac_finish_mfma_kernel<false>",
+                 "ransac_exact_list_kernel<1264>", "match_mfma_kernel"):
+        assert name in pk and pk[name]["ms"] > 0 and pk[name]["registers_runtime"] > 0, name
+    w = r["work"]
+    assert w["evals_executed"] == w["evals_executed_f32"] + w["evals_executed_mfma_dense"] + w["evals_executed_mfma_finish"]
+    assert w["exact_solves"] + w["prescreened_only"] == w["hypotheses"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "single_thread_pairs_per_s"):
         assert k in c, k
     assert c["kind"] == "port"            # the reference itself cannot be built here
     assert abs(d["value"] - 512 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
-    assert "reference_threshold" in d and "ransac_ms" in d["reference_threshold"]
+    rt = d["reference_threshold"]
+    assert rt["steps"] >= 10 and "wall clock" in rt["timing"] and "roofline" in rt and rt["pairs_per_s"] > 0
+    for k in ("sequence", "refine", "extract"):
+        assert k in d and d[k]["value"] > 0 and ("roofline" in d[k] or "pnp_roofline" in d[k]), k
 
 
 def test_bench_source_prints_the_same_fields():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for k in ('"metric"', '"roofline"', '"cpu_baseline"', '"traffic"', '"bound": "valu_fp64"', '"gather_us"', '"reference_threshold"'):
+    for k in ('"metric"', '"roofline"', '"cpu_baseline"', '"traffic"', '"bound"', '"gather_us"', '"reference_threshold"'):
         assert k in src, k

@@ -17,7 +17,7 @@ done
 PB="python3 bench.py --no-cpu-baseline --no-single-pair --no-ref-threshold --sections main"
 for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
          "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
-         "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_MFMA SQ_INSTS_BRANCH" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"; do
+         "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_MFMA SQ_INSTS_BRANCH SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"; do
   D=$O/pmc_$(echo $G | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D -o p -- $PB --steps 1 --warmup 0 --pairs 128 > $D.json 2> $D.err || { echo "pmc pass failed: $G"; tail -3 $D.err; }
 done
