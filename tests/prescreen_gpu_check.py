@@ -138,6 +138,36 @@ def main():
             info = (C.c_int32 * 4)()
             lib.mvs_debug_read_hyp_rec(b._h, C.c_int(0), C.c_int(1), None, None, None, info)
             stats["mode%d_list" % mode if mode >= 0 else "auto_list"] = [int(info[2]), int(info[3])]
+        # the matrix-core counts themselves (default variant, every pair pre-screened): the pair's bound is a maximum of LOWER
+        # bounds L' <= count_J, so it cannot exceed the winner's exact count; and every approximate record that reached the
+        # exact solve carries its UPPER bound U' >= count_J in hyp_cnt (the record now holds the exact F: count it)
+        lib.mvs_debug_set_count_dense(C.c_int(1))
+        lib.mvs_debug_set_prescreen_force(C.c_int(1))
+        b.run(prm)
+        b.sync()
+        chk = b.download()
+        for p in range(P):
+            M = int(chk["results"][p]["n_matches"])
+            if M < 8:
+                continue
+            mt = chk["matches"][p][:M]
+            K = data["K"][p].reshape(3, 3)
+            p1 = o.normalize_points(K, data["kp1"][p][mt["trainIdx"]].astype(np.float64))
+            p2 = o.normalize_points(K, data["kp2"][p][mt["queryIdx"]].astype(np.float64))
+            rec = np.zeros((H, 10))
+            state = np.zeros(H, dtype=np.uint8)
+            cnt = np.zeros(H, dtype=np.int32)
+            info = (C.c_int32 * 4)()
+            st = lib.mvs_debug_read_hyp_rec(b._h, C.c_int(p), C.c_int(H), rec.ctypes.data_as(C.POINTER(C.c_double)),
+                                            state.ctypes.data_as(C.POINTER(C.c_ubyte)), cnt.ctypes.data_as(C.POINTER(C.c_int32)), info)
+            assert st == 0 and info[0] == 1
+            if chk["results"][p]["valid"]:
+                assert info[1] <= chk["results"][p]["best_count"], (p, thr, info[1], int(chk["results"][p]["best_count"]))
+            for h in np.nonzero((state == 3) & (cnt >= 0) & (cnt < 2 ** 31 - 1))[0]:
+                cj_lo = int((pm.residuals(rec[h, :9].reshape(3, 3), p1, p2) < thr * (1 - 1e-9)).sum())
+                stats["mfma_checked"] = stats.get("mfma_checked", 0) + 1
+                if cnt[h] < cj_lo:
+                    stats["count_viol"] += 1
         lib.mvs_debug_set_prescreen_force(C.c_int(-1))
         lib.mvs_debug_set_count_dense(C.c_int(1))
         for k in ("results", "mask", "points", "point_idx", "matches"):

@@ -142,3 +142,4 @@ def test_device_prescreen_against_the_oracle_hypothesis_by_hypothesis():
     assert st["viol"] == 0 and st["count_viol"] == 0 and st["certified"] > 0.5 * st["hyp"]
     assert st["mode0_list"] == [0, 0]                 # forced exact: nothing on the work list
     assert st["mode1_list"][0] > 0 and st["auto_list"][0] > 0
+    assert st["mfma_checked"] > 20       # upper bounds of the matrix-core counting checked against exact counts
