@@ -341,6 +341,30 @@ int mvs_debug_set_count_dense(int v)
     return MVS_OK;
 }
 
+// one 32 x 32 x 32 bf16 tile through the counting kernels' two MFMAs: a, b = [32][32] bf16 bit patterns on the host,
+// out = [32][32] binary32 (point x hypothesis)
+int mvs_debug_mfma_probe(mvs_ctx *ctx, const uint16_t *a, const uint16_t *b, float *out)
+{
+    if (!ctx || !a || !b || !out)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint16_t *da = nullptr, *db = nullptr;
+    float *dout = nullptr;
+    HIP_TRY(ctx, hipMalloc(&da, 1024 * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&db, 1024 * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&dout, 1024 * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpy(da, a, 1024 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(db, b, 1024 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    launch_mfma_probe(da, db, dout, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, sync_stream(ctx));
+    HIP_TRY(ctx, hipMemcpy(out, dout, 1024 * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    return MVS_OK;
+}
+
 int mvs_debug_set_match_mfma(int v)
 {
     set_match_mfma(v);

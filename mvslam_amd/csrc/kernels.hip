@@ -966,6 +966,18 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
 //                                bounds of the hypotheses that finish raise the pair's bound
 // survivors      flat            approximate records whose upper bound reaches the final bound -> work list (-> exact_list)
 // select         grid P          exact count + residual of everything at or above the bound (ransac_select_kernel)
+// bf16 (round to nearest even) of a finite binary32 number, as its 16 bits; x = hi + lo + (<= 2^-18 |x|)
+__device__ __forceinline__ uint32_t bf16_bits(float x)
+{
+    uint32_t u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void bf16_split(float x, uint32_t &hi, uint32_t &lo)
+{
+    hi = bf16_bits(x);
+    lo = bf16_bits(x - __uint_as_float(hi << 16));   // the difference is exact
+}
 __device__ __forceinline__ PairBox load_box(const BatchDev &b, int pair)
 {
     const double *q = b.box + (size_t)pair * 8;
@@ -1108,10 +1120,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             q[k] = (float)F[k];
         q[9] = (float)((thr + btot) * (1.0 + 0x1p-22));
         q[10] = (float)((thr - btot) * (1.0 - 0x1p-22));
-        q[11] = 0.f;
+        // words 11 .. 19: the nine coefficients once more as bf16 parts, hi[9] then lo[9] (the matrix-core counting
+        // kernels multiply in split bf16: splitting here, once per hypothesis, instead of once per lane and batch there)
+        uint32_t hl[18];
 #pragma unroll
-        for (int k = 0; k < 12; k += 4)
-            *reinterpret_cast<float4 *>(fo + k) = make_float4(q[k], q[k + 1], q[k + 2], q[k + 3]);
+        for (int k = 0; k < 9; ++k)
+            bf16_split(q[k], hl[k], hl[9 + k]);
+        uint32_t wd[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            wd[j] = hl[2 * j] | (hl[2 * j + 1] << 16);
+        q[11] = __uint_as_float(wd[0]);
+        *reinterpret_cast<float4 *>(fo + 0) = make_float4(q[0], q[1], q[2], q[3]);
+        *reinterpret_cast<float4 *>(fo + 4) = make_float4(q[4], q[5], q[6], q[7]);
+        *reinterpret_cast<float4 *>(fo + 8) = make_float4(q[8], q[9], q[10], q[11]);
+        *reinterpret_cast<uint4 *>(fo + 12) = make_uint4(wd[1], wd[2], wd[3], wd[4]);
+        *reinterpret_cast<uint4 *>(fo + 16) = make_uint4(wd[5], wd[6], wd[7], wd[8]);
     } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -1645,18 +1669,6 @@ __device__ __forceinline__ int dense_points(int M, int B0)
     return max(0, min(want, (M / 32) * 32));
 }
 
-// bf16 (round to nearest even) of a finite binary32 number, as its 16 bits; x = hi + lo + (<= 2^-18 |x|)
-__device__ __forceinline__ uint32_t bf16_bits(float x)
-{
-    uint32_t u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ void bf16_split(float x, uint32_t &hi, uint32_t &lo)
-{
-    hi = bf16_bits(x);
-    lo = bf16_bits(x - __uint_as_float(hi << 16));   // the difference is exact
-}
 // K slot s = 0 .. 31 of the two MFMAs carries term (k, part) = (s % 9, s / 9) for s < 27: part 0 = hi hi, 1 = hi(Phi) lo(F),
 // 2 = lo(Phi) hi(F); slot s sits in MFMA j = s / 16, lane half (s / 8) & 1, element s & 7 -- for BOTH operands, so the sum does
 // not depend on how the instruction numbers its k.
@@ -1824,14 +1836,20 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
                 // the record's first twelve floats: F~[9], tu, tl, -
                 const float4 *rq = reinterpret_cast<const float4 *>(s_rec + (32 * c + col) * 5);
                 const float4 q0 = rq[0], q1 = rq[1], q2 = rq[2];
+                const uint4 q3 = *reinterpret_cast<const uint4 *>(rq + 3), q4 = *reinterpret_cast<const uint4 *>(rq + 4);
                 const float fr[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+                // words 11 .. 19 of the record: the bf16 parts the pre-screen has split off, hi[9] then lo[9]
+                const uint32_t wd[9] = {__float_as_uint(q2.w), q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
                 const bool on = st[c] == kPsApprox;
                 float Ff[9];
                 uint32_t fh[9], fl[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     Ff[k] = on ? fr[k] : 0.f;
-                    bf16_split(Ff[k], fh[k], fl[k]);
+                    const uint32_t hk = (wd[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                    const uint32_t lk = (wd[(9 + k) >> 1] >> (16 * ((9 + k) & 1))) & 0xffffu;
+                    fh[k] = on ? hk : 0u;
+                    fl[k] = on ? lk : 0u;
                 }
                 uint4 op[2];
                 dense_operands(fh, fl, half, 1, op);
@@ -1906,6 +1924,39 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
         for (int i = tid; i < nl; i += kDenseThreads)
             dst[i] = s_list[i];
     }
+}
+
+// diagnostics: one 32 x 32 x 32 tile through the two MFMAs exactly as the counting kernels issue them.  A, B: [32][32] bf16
+// bit patterns (row = point / hypothesis, column = K slot); out[point][hypothesis] (binary32).  Pins the K slot mapping, the
+// accumulator layout and the accumulation error the bound assumes (tests/test_prescreen.py).
+__global__ __launch_bounds__(64) void mfma_probe_kernel(const uint16_t *A, const uint16_t *B, float *out)
+{
+    const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+    v8bf a[2], bb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        uint32_t wa[4], wb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s0 = j * 16 + half * 8 + 2 * e;
+            wa[e] = (uint32_t)A[col * 32 + s0] | ((uint32_t)A[col * 32 + s0 + 1] << 16);
+            wb[e] = (uint32_t)B[col * 32 + s0] | ((uint32_t)B[col * 32 + s0 + 1] << 16);
+        }
+        a[j] = __builtin_bit_cast(v8bf, make_uint4(wa[0], wa[1], wa[2], wa[3]));
+        bb[j] = __builtin_bit_cast(v8bf, make_uint4(wb[0], wb[1], wb[2], wb[3]));
+    }
+    v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // the point
+        out[row * 32 + col] = acc[r];
+    }
+}
+void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, stream, A, B, out);
 }
 
 // The pair's list in the order of the dense phase's counts, largest first (counting sort on the count, one workgroup per

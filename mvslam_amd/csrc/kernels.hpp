@@ -321,6 +321,7 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
 hipError_t prepare_kernels();
 // diagnostics: pair_prepare + ransac_prescreen only, every pair forced into the pre-screened mode
 void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
+void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStream_t stream);   // diagnostics
 void set_count_dense(int v);      // diagnostics: 1 = single-precision counting as pilot + dense MFMA phase + finish
 void set_match_mfma(int v);       // diagnostics: 1 (default) 256-bit descriptors on the matrix cores, 0 the VALU kernel
 void set_prescreen_force(int m);   // diagnostics: -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened

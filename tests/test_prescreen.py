@@ -132,6 +132,66 @@ def test_rank2_step_is_a_posteriori():
     assert stats["cert"] > 30
 
 
+def _bf16_bits(x):
+    """round-to-nearest-even bf16 of finite binary32 values, as uint16 bit patterns (bf16_bits of kernels.hip)"""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = u + 0x7FFF + ((u >> 16) & 1)
+    return (u >> 16).astype(np.uint16)
+
+
+def _bf16_value(b):
+    return (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+@pytest.mark.gpu
+def test_matrix_core_tile_layout_and_accumulation_error():
+    """the counting kernels sum 27 (+5 zero) products of bf16 numbers per evaluation with two
+    v_mfma_f32_32x32x16_bf16; the bound assumes (A2) that every addition of the accumulation is off by at most 2^-23 of the sum
+    of magnitudes.  One 32 x 32 x 32 tile through the same two instructions (diagnostics hook): out[point][hypothesis] must be
+    the dot product of row `point` of A and row `hypothesis` of B -- which pins the K slot mapping and the accumulator layout
+    -- to within 32 * 2^-23 * sum |terms| on operands of mixed magnitude and sign (heavy cancellation included); the worst
+    ratio seen is printed."""
+    import ctypes as C
+    from mvslam_amd import capi
+
+    dbg = C.CDLL(capi.DBG_LIB_PATH)
+    h = C.c_void_p()
+    assert dbg.mvs_ctx_create(C.c_int(0), C.byref(h)) == 0
+    dbg.mvs_ctx_destroy.argtypes = [C.c_void_p]
+    dbg.mvs_debug_mfma_probe.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    try:
+        for trial in range(64):
+            kind = trial % 4
+            a = rng.normal(size=(32, 32)) * 10.0 ** rng.uniform(-3, 3, size=(32, 32) if kind != 1 else (32, 1))
+            b = rng.normal(size=(32, 32)) * 10.0 ** rng.uniform(-3, 3, size=(32, 32) if kind != 1 else (32, 1))
+            if kind == 2:      # cancellation: second half of the slots repeats the first with the opposite sign (nearly)
+                a[:, 16:] = a[:, :16]
+                b[:, 16:] = -b[:, :16] * (1 + 2.0 ** -7 * rng.normal(size=(32, 16)))
+            if kind == 3:      # the kernels' own shape: hi / lo parts, five zero slots
+                x, y = rng.normal(size=(32, 9)).astype(np.float32), rng.normal(size=(32, 9)).astype(np.float32)
+                xh, yh = _bf16_value(_bf16_bits(x)), _bf16_value(_bf16_bits(y))
+                xl, yl = (x - xh.astype(np.float32)), (y - yh.astype(np.float32))
+                a = np.concatenate([xh, xh, xl, np.zeros((32, 5))], axis=1)
+                b = np.concatenate([yh, yl, yh, np.zeros((32, 5))], axis=1)
+            A, B = _bf16_bits(a.astype(np.float32)), _bf16_bits(b.astype(np.float32))
+            out = np.zeros((32, 32), dtype=np.float32)
+            st = dbg.mvs_debug_mfma_probe(h, A.ctypes.data_as(C.POINTER(C.c_uint16)), B.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                          out.ctypes.data_as(C.POINTER(C.c_float)))
+            assert st == 0
+            av, bv = _bf16_value(A), _bf16_value(B)
+            exact = av @ bv.T                              # [point][hypothesis], binary64: products of bf16 are exact
+            mag = np.abs(av) @ np.abs(bv).T
+            err = np.abs(out.astype(np.float64) - exact)
+            assert np.all(err <= 32 * 2.0 ** -23 * mag + 1e-300), (trial, float((err / mag).max()))
+            worst = max(worst, float((err / np.maximum(mag, 1e-300)).max()))
+    finally:
+        dbg.mvs_ctx_destroy(h)
+    print("worst accumulation error / sum of magnitudes: %.3g = %.2f * 2^-24" % (worst, worst * 2.0 ** 24))
+    assert worst <= 32 * 2.0 ** -23
+
+
 @pytest.mark.gpu
 def test_device_prescreen_against_the_oracle_hypothesis_by_hypothesis():
     env = dict(os.environ, MVS_USE_DEBUG_LIB="1")

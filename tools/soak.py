@@ -132,11 +132,15 @@ for i in range(args.cases // 8):
     got = ctx.sfm_refine(pb["p1"], pb["cov"], pb["p2"], pb["cov"], pb["K"], pb["Rg"], pb["tg"], pb["Xg"])
     want = o.sfm_refine(pb["p1"], pb["cov"], pb["p2"], pb["cov"], pb["K"], pb["Rg"], pb["tg"], pb["Xg"])
     cnt["sfm_refine"] += 1
-    if not (got["ok"] and want["ok"] and got["iterations"] == want["iterations"] and np.abs(got["R"] - want["R"]).max() < 1e-10
-            and np.abs(got["t"] - want["t"]).max() < 1e-10
+    # pose: since round 3 the oracle factors the reduced system with the textbook (division-form) Cholesky again while the
+    # kernel multiplies by stored reciprocals (the checker must not follow the kernel's arithmetic), so the two
+    # sides stop up to ~1e-9 apart where the cost is flat, at the same error to 1e-15 (seed 3101, case 15: 5.7e-10 on t at
+    # equal iteration counts and errors 810.0757243827807 / ...805): 1e-8 like pnp_refine below, + the error itself
+    if not (got["ok"] and want["ok"] and got["iterations"] == want["iterations"] and np.abs(got["R"] - want["R"]).max() < 1e-8
+            and np.abs(got["t"] - want["t"]).max() < 1e-8 and abs(got["error"] - want["error"]) <= 1e-12 * max(1.0, want["error"])
             # points: relative to their size (depths up to 10; the two sides' sin / cos differ in the last bit and a weakly
             # constrained depth amplifies it: 1.1e-9 seen once in 155 000 cases, at equal errors and iteration counts)
-            and np.abs(got["points"] - want["points"]).max() < 1e-9 * max(1.0, np.abs(want["points"]).max())
+            and np.abs(got["points"] - want["points"]).max() < 1e-8 * max(1.0, np.abs(want["points"]).max())
             and np.abs(got["pose_cov"] - want["pose_cov"]).max() <= 1e-7 * np.abs(want["pose_cov"]).max()):
         bad.append(("sfm_refine", i, m, got["ok"], want["ok"], got["iterations"], want["iterations"], np.abs(got["R"] - want["R"]).max(),
                     np.abs(got["t"] - want["t"]).max(), np.abs(got["points"] - want["points"]).max(), got["error"], want["error"]))
