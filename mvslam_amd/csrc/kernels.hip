@@ -1120,22 +1120,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             q[k] = (float)F[k];
         q[9] = (float)((thr + btot) * (1.0 + 0x1p-22));
         q[10] = (float)((thr - btot) * (1.0 - 0x1p-22));
-        // words 11 .. 19: the nine coefficients once more as bf16 parts, hi[9] then lo[9] (the matrix-core counting
-        // kernels multiply in split bf16: splitting here, once per hypothesis, instead of once per lane and batch there)
-        uint32_t hl[18];
+        q[11] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-            bf16_split(q[k], hl[k], hl[9 + k]);
-        uint32_t wd[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            wd[j] = hl[2 * j] | (hl[2 * j + 1] << 16);
-        q[11] = __uint_as_float(wd[0]);
-        *reinterpret_cast<float4 *>(fo + 0) = make_float4(q[0], q[1], q[2], q[3]);
-        *reinterpret_cast<float4 *>(fo + 4) = make_float4(q[4], q[5], q[6], q[7]);
-        *reinterpret_cast<float4 *>(fo + 8) = make_float4(q[8], q[9], q[10], q[11]);
-        *reinterpret_cast<uint4 *>(fo + 12) = make_uint4(wd[1], wd[2], wd[3], wd[4]);
-        *reinterpret_cast<uint4 *>(fo + 16) = make_uint4(wd[5], wd[6], wd[7], wd[8]);
+        for (int k = 0; k < 12; k += 4)
+            *reinterpret_cast<float4 *>(fo + k) = make_float4(q[k], q[k + 1], q[k + 2], q[k + 3]);
     } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -1836,20 +1824,14 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
                 // the record's first twelve floats: F~[9], tu, tl, -
                 const float4 *rq = reinterpret_cast<const float4 *>(s_rec + (32 * c + col) * 5);
                 const float4 q0 = rq[0], q1 = rq[1], q2 = rq[2];
-                const uint4 q3 = *reinterpret_cast<const uint4 *>(rq + 3), q4 = *reinterpret_cast<const uint4 *>(rq + 4);
                 const float fr[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
-                // words 11 .. 19 of the record: the bf16 parts the pre-screen has split off, hi[9] then lo[9]
-                const uint32_t wd[9] = {__float_as_uint(q2.w), q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
                 const bool on = st[c] == kPsApprox;
                 float Ff[9];
                 uint32_t fh[9], fl[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     Ff[k] = on ? fr[k] : 0.f;
-                    const uint32_t hk = (wd[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                    const uint32_t lk = (wd[(9 + k) >> 1] >> (16 * ((9 + k) & 1))) & 0xffffu;
-                    fh[k] = on ? hk : 0u;
-                    fl[k] = on ? lk : 0u;
+                    bf16_split(Ff[k], fh[k], fl[k]);
                 }
                 uint4 op[2];
                 dense_operands(fh, fl, half, 1, op);
