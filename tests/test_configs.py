@@ -116,6 +116,51 @@ def test_config3_batch512(ctx):
         assert np.abs(r["R"] - ref["R"]).max() <= 1e-12 and np.abs(r["t"] - ref["t"]).max() <= 1e-12
 
 
+def test_low_inlier_pairs_through_the_multi_chunk_counting(ctx):
+    """Pairs with many matches and few inliers: the dense matrix-core phase must look at more points than one LDS chunk holds
+    (n1 = M - B0 + 32 > 768, several staging passes with partial counts carried in hyp_cnt), the finish walks long lists.
+    Plus ragged small pairs in the same batch (M below one tile, below eight).  Oracle parity of winner, count, residual sum,
+    mask on every pair."""
+    from mvslam_amd import capi
+
+    specs = [(2000, 0.6), (2000, 0.75), (1800, 0.5), (2000, 0.3), (40, 0.3), (24, 0.0), (9, 0.0), (300, 0.6)]
+    P, N, H, THR = len(specs), 2000, 6144, 1e-2
+    pairs = [synth.make_pair(7000 + i, n_kp=n, outlier_frac=f) for i, (n, f) in enumerate(specs)]
+    pad = lambda a: np.concatenate([a, np.zeros((N - len(a),) + a.shape[1:], a.dtype)])
+    b = capi.Batch(ctx, P, N, 32)
+    sizes = np.array([n for n, _ in specs], dtype=np.int32)
+    gidx = np.arange(7000, 7000 + P, dtype=np.int64)
+    b.upload(0, np.stack([pad(p["desc1"]) for p in pairs]), np.stack([pad(p["kp1"]) for p in pairs]), sizes,
+             np.stack([pad(p["desc2"]) for p in pairs]), np.stack([pad(p["kp2"]) for p in pairs]), sizes,
+             np.stack([p["K"].reshape(9) for p in pairs]), gidx)
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=THR)
+    b.run(prm)
+    b.sync()
+    out = b.download()
+    st = b.stats(prm)
+    b.close()
+    assert st["pairs_mode"][1] >= 4 and st["score_evals_executed_mfma"] > 0 and st["score_evals_executed_mfma_finish"] > 0
+
+    def ref(i):
+        p = pairs[i]
+        return o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"],
+                            o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(gidx[i]), THR), 0.7, 10.0)
+
+    refs = _threads(ref, list(range(P)))
+    multi_chunk = 0
+    for i, r in enumerate(refs):
+        g = out["results"][i]
+        M = r["n_matches"]
+        assert g["n_matches"] == M and bool(g["valid"]) == bool(r["ok"]), i
+        if not r["ok"]:
+            continue
+        assert g["best_hyp"] == r["best_hyp"] and g["best_count"] == r["best_count"], (i, int(g["best_hyp"]), r["best_hyp"])
+        assert g["best_residual"] == r["best_residual"], i
+        assert np.array_equal(out["mask"][i][:M], r["mask"]), i
+        multi_chunk += int(M - r["best_count"] + 32 > 768)
+    assert multi_chunk >= 1      # at least one pair needed more than one chunk of points in the dense phase
+
+
 def test_config3_batch512_reference_threshold(ctx):
     """configs[2] at SURVEY 8(d)'s own threshold: max_error_sq = 0 selects the reference formula 5e-2 / K00 / K11
     (sfm-solve.cpp:18-19,311).  Best counts are ~5-10, hundreds of hypotheses tie at the maximum and the winner is decided
