@@ -189,7 +189,7 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
     for name, e in table.items():
         fl_exec = fl_alg = None
         peak, bound = FP64_PEAK_TFLOPS, "valu_fp64"
-        if name.startswith("ransac_solve_kernel"):      # every hypothesis of the pairs in mode 0
+        if name.startswith("ransac_solve_kernel") or name.startswith("ransac_solve_list_kernel"):   # every hypothesis of the pairs in mode 0
             fl_alg = solve_flops(stats)
             fl_exec = per_solve * stats["pairs_mode"][0] * (stats["hypotheses"] / max(sum(stats["pairs_mode"]), 1)) \
                 if sum(stats["pairs_mode"]) else fl_alg

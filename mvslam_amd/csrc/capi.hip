@@ -247,6 +247,7 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if (!b->d.mode && (st = dev_alloc(b, &b->d.mode, P)) != MVS_OK) return st;
     if (!b->d.dense_n1 && (st = dev_alloc(b, &b->d.dense_n1, P)) != MVS_OK) return st;
     if (!b->d.ccount && (st = dev_alloc(b, &b->d.ccount, P)) != MVS_OK) return st;
+    if (!b->d.m0list && (st = dev_alloc(b, &b->d.m0list, P + 1)) != MVS_OK) return st;
     if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 2)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
     dev_release(b, b->d.hyp_F);
@@ -616,6 +617,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.dense_n1 = nullptr;
     d.clist = nullptr;
     d.ccount = nullptr;
+    d.m0list = nullptr;
     d.xlist = nullptr;
     d.xcount = nullptr;
     d.hyp_count = nullptr;

@@ -567,17 +567,11 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
 // loop costs a full fp64 issue slot (profiles/r01_fp64_issue_microbench.txt).  Scoring needs 18 registers of state: as
 // its own kernel it runs at 4 waves/SIMD and the compare / count / mask instructions overlap with other waves' FMAs.
 // Price: F of every hypothesis goes through HBM once (72 B x 50 000 x 512 pairs = 1.8 GB written + read per batch).
+// one hypothesis per lane: exact solve, record, state byte
 template <int VAR>
-__global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp, int respect_mode)
+__device__ __forceinline__ void solve_record(const BatchDev &b, const RunParams &rp, int pair, int M, uint32_t h)
 {
-    const int pair = blockIdx.y, tid = threadIdx.x;
-    const int M = b.M[pair];
-    if (M < 8)
-        return;
-    if (respect_mode && b.mode[pair] != 0)
-        return;   // this pair's hypotheses are pre-screened (ransac_prescreen_kernel)
     const int H = rp.num_hypotheses;
-    const uint32_t h = blockIdx.x * blockDim.x + tid;   // any block size that divides 256 (the launch picks it)
     const uint32_t hh = h < (uint32_t)H ? h : (uint32_t)(H - 1);
     const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
     const double *P = b.pts + (size_t)pair * b.max_kp * 4;
@@ -599,6 +593,62 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunPar
     b.hyp_okf[(size_t)pair * Hp + h] = ok ? kPsExact : kPsInvalid;
     if (h == 0)
         b.bound[pair] = 0;   // pruning bound of the scoring launch that follows on the stream
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp, int respect_mode)
+{
+    const int pair = blockIdx.y, tid = threadIdx.x;
+    const int M = b.M[pair];
+    if (M < 8)
+        return;
+    if (respect_mode && b.mode[pair] != 0)
+        return;   // this pair's hypotheses are pre-screened (ransac_prescreen_kernel)
+    solve_record<VAR>(b, rp, pair, M, blockIdx.x * blockDim.x + tid);   // any block size that divides 256 (the launch picks it)
+}
+
+// The pairs the probe left in mode 0, in pair order: m0list[0] = their number, then the pairs (one workgroup; the pre-screened
+// stage's exact-solve launch walks this list instead of sending a workgroup per (pair, 64 hypotheses) that leaves at once --
+// 401 k of them, 0.13 ms, when every pair is pre-screened).
+__global__ __launch_bounds__(256) void mode0_list_kernel(BatchDev b, int n_active)
+{
+    __shared__ int s_cnt[4];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0)
+        s_total = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < n_active; p0 += 256) {
+        const int pair = p0 + tid;
+        const bool take = pair < n_active && b.M[pair] >= 8 && b.mode[pair] == 0;
+        const unsigned long long m = __ballot(take);
+        if (lane == 0)
+            s_cnt[w] = __popcll(m);
+        __syncthreads();
+        int base = s_total;
+        for (int k = 0; k < w; ++k)
+            base += s_cnt[k];
+        if (take)
+            b.m0list[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = pair;
+        __syncthreads();
+        if (tid == 0)
+            s_total += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0)
+        b.m0list[0] = s_total;
+}
+
+// exact solve of every hypothesis of the listed pairs: persistent single-wavefront workgroups striding over
+// (listed pair, block of 64 hypotheses); the list length is fixed before the launch
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void ransac_solve_list_kernel(BatchDev b, RunParams rp, int blocks_per_pair)
+{
+    const int n_items = b.m0list[0] * blocks_per_pair;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int pair = b.m0list[1 + item / blocks_per_pair];
+        solve_record<VAR>(b, rp, pair, b.M[pair], (uint32_t)(item % blocks_per_pair) * 64u + threadIdx.x);
+    }
 }
 
 constexpr int kScoreChunk = 1024;   // points staged per pass: 32 KB of LDS -> 4 workgroups per CU
@@ -2970,8 +3020,8 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.threads = kHypPerBlock;
         break;
     case kKRansacSolve:
-        d.name = "ransac_solve_kernel<1264>";
-        d.fn = reinterpret_cast<const void *>(ransac_solve_kernel<240 + 1024>);
+        d.name = "ransac_solve_list_kernel<1264>";   // (+ the one-workgroup mode0_list_kernel in front of it)
+        d.fn = reinterpret_cast<const void *>(ransac_solve_list_kernel<240 + 1024>);
         d.threads = kSolveBlock;
         break;
     case kKRansacScore:
@@ -3188,10 +3238,12 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, g_force_mode);
     if (lt) lt->mark(kKRansacPrescreen);
     hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((H + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
-    // pairs the probe did not certify: every hypothesis through the exact solve (its workgroups leave at once for the others)
+    // pairs the probe did not certify: every hypothesis through the exact solve, a persistent grid over the list of those pairs
     if (lt) lt->mark(kKRansacSolve);
-    hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active), dim3(kSolveBlock),
-                       0, stream, b, rp, 1);
+    hipLaunchKernelGGL(mode0_list_kernel, dim3(1), dim3(256), 0, stream, b, n_active);
+    static_assert(kSolveBlock == 64, "ransac_solve_list_kernel takes blocks of 64 hypotheses");
+    hipLaunchKernelGGL((ransac_solve_list_kernel<240 + 1024>), dim3(2048), dim3(64), 0, stream, b, rp,
+                       G * (kHypPerBlock / kSolveBlock));
     const int n_groups4 = (H + kCntSlots - 1) / kCntSlots;
     const int wpw = kCntThreads / 64;
     int wg = (512 + n_active - 1) / n_active;

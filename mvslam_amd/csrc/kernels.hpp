@@ -70,6 +70,7 @@ struct BatchDev {
                          // screened, counted in double precision
     uint32_t *clist;     // [P][max_groups * 256] hypotheses of the pair the dense counting phase left alive (for the finish)
     int32_t *ccount;     // [P] their number
+    int32_t *m0list;     // [1 + P] number of pairs in mode 0, then those pairs (mode0_list_kernel -> ransac_solve_list_kernel)
     int32_t *dense_n1;   // [P] points the dense (matrix-core) counting phase covered for the pair
     uint32_t *xlist;     // [P * max_groups * 256] work list of the list-driven exact solve: flat indices pair * Hp + h
     uint32_t *xcount;    // [2] {entries of the list: flagged by the pre-screen + survivors of the count, unused}
