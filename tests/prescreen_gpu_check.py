@@ -103,7 +103,7 @@ def main():
                     cj = int((rj < thr).sum())
                     if pmode == 2:
                         band = rec[h, 9] - thr
-                        assert 0 < band <= 0.125 * thr * (1 + 1e-12), (p, h, band)
+                        assert 0 < band <= pm.BAND_FRAC * thr * (1 + 1e-12), (p, h, band)
                         ra = pm.residuals(rec[h, :9].reshape(3, 3), p1, p2)
                         d = float(np.abs(rj - ra).max())
                         cu, cl = int((ra < thr + band).sum()), int((ra < thr - band).sum())
@@ -111,7 +111,7 @@ def main():
                         F32 = rec32[h, :9].astype(np.float64).reshape(3, 3)
                         tu, tl = float(rec32[h, 9]), float(rec32[h, 10])
                         band = min(tu - thr, thr - tl)
-                        assert 0 < band <= 0.125 * thr * (1 + 1e-5), (p, h, band)
+                        assert 0 < band <= pm.BAND_FRAC * thr * (1 + 1e-5), (p, h, band)
                         ra = pm.residuals(F32, q1, q2)      # binary64 evaluation of the binary32 operands ...
                         T = np.einsum("ij,jk,ik->i", a2, np.abs(F32), a1)
                         # ... + the arithmetic roundings of binary32: four nested fma, or (matrix cores) the rounded
