@@ -3,7 +3,7 @@ os.environ["MVS_USE_DEBUG_LIB"]="1"
 sys.path.insert(0,'/root/repo')
 from mvslam_amd import capi, synth
 import numpy as np
-F=33
+F=int(os.environ.get("SEQ_F","33"))
 seq = synth.make_sequence(F, n_kp=2000)
 P=F-1
 ctx = capi.Context(0); b = capi.Batch(ctx, P, 2000, 32)
