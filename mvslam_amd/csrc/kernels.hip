@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
             flag = kPsNeedExact;
         const bool live = lane < H;
         const int n_ok = __popcll(__ballot(live && flag != kPsInvalid));
-        const int n_s64 = __popcll(__ballot(live && flag == kPsApprox && band <= kPsBandFrac * thr));
-        const int n_s32 = __popcll(__ballot(live && flag == kPsApprox && band + e32 <= kPsBandFrac * thr));
+        const int n_s64 = __popcll(__ballot(live && flag == kPsApprox && band <= kPsProbeFrac * thr));
+        const int n_s32 = __popcll(__ballot(live && flag == kPsApprox && band + e32 <= kPsProbeFrac * thr));
         // 1: pre-screened, counted in single precision; 2: pre-screened, counted in double precision (the band is useful
         // at this threshold but single-precision evaluation is too coarse for it); 0: every hypothesis solved exactly
         // the pre-screen costs about a tenth of an exact solve, so it pays as soon as a fair share of the hypotheses gets

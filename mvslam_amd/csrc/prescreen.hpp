@@ -31,7 +31,11 @@ constexpr double kPsTauC = 2.0e-12;       // >= 2.001 (8000 u + 8.01 u): <= 1080
 constexpr double kPsEtaQ = 4.0e-12;       // loss of orthogonality of the accumulated V^T over <= 1080 rotations
 constexpr double kPsSvd3 = 2.0e-11;       // backward error of the exact path's 3x3 Jacobi SVD + recomposition (generous)
 constexpr double kPsTrip = 1.0e-12;       // roundings of the verified singular triplet below (~150 operations on |x| <= 1.01)
-constexpr double kPsBandFrac = 0.9375;      // screened only if band <= kPsBandFrac * thr
+constexpr double kPsBandFrac = 0.9375;    // a hypothesis is certified only if band <= kPsBandFrac * thr (the lower threshold stays
+                                          // positive; a certificate can only help, so the limit is as wide as that allows)
+constexpr double kPsProbeFrac = 0.125;    // ... but a PAIR is pre-screened only if a third of its probe gets bands within this
+                                          // fraction of the threshold: with bands near the threshold nothing is pruned, every
+                                          // hypothesis ends in the exact solve anyway and the pre-screen is pure overhead
 constexpr int kPsInvalid = 0, kPsApprox = 1, kPsNeedExact = 2, kPsExact = 3;   // per-hypothesis state byte (hyp_okf)
 
 // 1 / x for 2^-190 <= |x| <= 2^190 (div_fast's guarded range), correctly rounded like the compiler's division
