@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         for (int k = 0; k < 9; ++k)
             q[k] = (float)F[k];
         q[9] = (float)((thr + btot) * (1.0 + 0x1p-22));
-        q[10] = (float)((thr - btot) * (1.0 - 0x1p-22));
+        q[10] = (float)(fmax(thr - btot, 0.0) * (1.0 - 0x1p-22));   // (0: nothing is below it, the lower count bound is 0)
         q[11] = 0.f;
 #pragma unroll
         for (int k = 0; k < 12; k += 4)

@@ -31,8 +31,12 @@ constexpr double kPsTauC = 2.0e-12;       // >= 2.001 (8000 u + 8.01 u): <= 1080
 constexpr double kPsEtaQ = 4.0e-12;       // loss of orthogonality of the accumulated V^T over <= 1080 rotations
 constexpr double kPsSvd3 = 2.0e-11;       // backward error of the exact path's 3x3 Jacobi SVD + recomposition (generous)
 constexpr double kPsTrip = 1.0e-12;       // roundings of the verified singular triplet below (~150 operations on |x| <= 1.01)
-constexpr double kPsBandFrac = 0.9375;    // a hypothesis is certified only if band <= kPsBandFrac * thr (the lower threshold stays
-                                          // positive; a certificate can only help, so the limit is as wide as that allows)
+constexpr double kPsBandFrac = 4.0;       // a hypothesis is certified only if band <= kPsBandFrac * thr.  A certificate can only
+                                          // help (a certified hypothesis is counted and then dropped or solved exactly, an
+                                          // uncertified one is solved exactly in any case), and the UPPER count bound prunes
+                                          // whenever the points within thr + band of the hypothesis are fewer than the pair's
+                                          // bound -- also with a band beyond the threshold, where the lower threshold thr - band
+                                          // is clamped to 0 and the lower count bound is 0
 constexpr double kPsProbeFrac = 0.125;    // ... but a PAIR is pre-screened only if a third of its probe gets bands within this
                                           // fraction of the threshold: with bands near the threshold nothing is pruned, every
                                           // hypothesis ends in the exact solve anyway and the pre-screen is pure overhead

@@ -110,7 +110,7 @@ def main():
                     else:
                         F32 = rec32[h, :9].astype(np.float64).reshape(3, 3)
                         tu, tl = float(rec32[h, 9]), float(rec32[h, 10])
-                        band = min(tu - thr, thr - tl)
+                        band = tu - thr if tl <= 0.0 else min(tu - thr, thr - tl)   # (tl is clamped at 0 for bands beyond thr)
                         assert 0 < band <= pm.BAND_FRAC * thr * (1 + 1e-5), (p, h, band)
                         ra = pm.residuals(F32, q1, q2)      # binary64 evaluation of the binary32 operands ...
                         T = np.einsum("ij,jk,ik->i", a2, np.abs(F32), a1)

@@ -28,7 +28,7 @@ TAU_C = 2.0e-12        # >= 2.001 (8000 u + 8.01 u): backward error of <= 1080 r
 ETA_Q = 4.0e-12        # loss of orthogonality of the accumulated V^T over <= 1080 rotations (3.3e4 u)
 SVD3_E = 2.0e-11       # generous bound on the backward error of a 3x3 Jacobi SVD + recomposition (<= 90 rotations)
 TRIP_E = 1.0e-12       # roundings of the verified singular triplet (~150 operations on |x| <= 1.01)
-BAND_FRAC = 0.9375     # a hypothesis is screened only if band <= BAND_FRAC * threshold
+BAND_FRAC = 4.0        # a hypothesis is screened only if band <= BAND_FRAC * threshold (kPsBandFrac)
 
 
 def hartley(px, py):
