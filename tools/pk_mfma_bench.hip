@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     uint4 ua = make_uint4(threadIdx.x, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
     v8bf A = __builtin_bit_cast(v8bf, ua), B = A;
     f2 cnt0 = {0.f, 0.f}, cnt1 = {0.f, 0.f};
+    int icnt = 0;
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {
 #pragma unroll
@@ -51,6 +52,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 asm volatile("v_pk_fma_f32 %0, %0, %1, %2 clamp" : "+v"(q) : "v"(c), "v"(d));
                 asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(cnt0) : "v"(q));
             }
+        } else if (MODE == 7) {
+            // compare + add-with-carry counting: eight compares into eight SGPR pairs, then eight v_addc, twice
+            unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+#pragma unroll
+            for (int r = 0; r < 16; r += 8) {
+                asm volatile("v_cmp_lt_f32_e64 %0, |%8|, %16\n v_cmp_lt_f32_e64 %1, |%9|, %16\n v_cmp_lt_f32_e64 %2, |%10|, %16\n"
+                             "v_cmp_lt_f32_e64 %3, |%11|, %16\n v_cmp_lt_f32_e64 %4, |%12|, %16\n v_cmp_lt_f32_e64 %5, |%13|, %16\n"
+                             "v_cmp_lt_f32_e64 %6, |%14|, %16\n v_cmp_lt_f32_e64 %7, |%15|, %16\n"
+                             : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3), "=s"(m4), "=s"(m5), "=s"(m6), "=s"(m7)
+                             : "v"(s[r]), "v"(s[r + 1]), "v"(s[r + 2]), "v"(s[r + 3]), "v"(s[r + 4]), "v"(s[r + 5]), "v"(s[r + 6]),
+                               "v"(s[r + 7]), "v"(c.x));
+                asm volatile("v_addc_co_u32_e64 %0, %1, %0, 0, %1\n v_addc_co_u32_e64 %0, %2, %0, 0, %2\n"
+                             "v_addc_co_u32_e64 %0, %3, %0, 0, %3\n v_addc_co_u32_e64 %0, %4, %0, 0, %4\n"
+                             "v_addc_co_u32_e64 %0, %5, %0, 0, %5\n v_addc_co_u32_e64 %0, %6, %0, 0, %6\n"
+                             "v_addc_co_u32_e64 %0, %7, %0, 0, %7\n v_addc_co_u32_e64 %0, %8, %0, 0, %8\n"
+                             : "+v"(icnt), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3), "+s"(m4), "+s"(m5), "+s"(m6), "+s"(m7));
+            }
         } else if (MODE == 3) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -74,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             asm volatile("" : "+v"(A));   // keep the MFMAs inside the loop
         }
     }
-    float r = cnt0.x + cnt0.y + cnt1.x + cnt1.y;
+    float r = cnt0.x + cnt0.y + cnt1.x + cnt1.y + icnt;
     for (int i = 0; i < 16; ++i)
         r += a[i].x + a[i].y + s[i];
     for (int j = 0; j < 4; ++j)
@@ -117,6 +135,7 @@ int main()
         } else {
             run<0>("v_pk_fma_f32 x16", 16, 4, out); run<1>("v_fma_f32 x16", 16, 4, out); run<2>("count triple x8 (24 packed)", 24, 4, out);
             run<3>("mfma_f32_32x32x16_bf16 x4", 4, 4, out); run<4>("tile pair: 4 mfma + 48 packed (per 52)", 52, 4, out);
+            run<7>("16 x (v_cmp_lt_f32 |a| + v_addc) (per 32)", 32, 4, out);
         }
     }
     return 0;
