@@ -3140,7 +3140,7 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
-static int g_match_mfma = 1;   // diagnostics: 0 = the VALU kernel for 256-bit descriptors too
+static int g_match_mfma = 1;   // 1 = by batch size (below); diagnostics: 0 = always the VALU kernel, 2 = always the matrix-core one
 void set_match_mfma(int v) { g_match_mfma = v; }
 
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt)
@@ -3150,13 +3150,18 @@ void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hip
     if (lt) lt->mark(kKMatchTopk);
     switch (b.desc_words) {
     case 4: hipLaunchKernelGGL(match_topk_kernel<4>, grid, block, 0, stream, b, ratio, md); break;
-    case 8:
-        if (g_match_mfma)
+    case 8: {
+        // the matrix-core kernel takes 256 queries per workgroup over all trains: throughput for a batch (0.55 against 1.05 ms
+        // per 512 pairs), but a long serial walk when there are only a handful of workgroups -- one pair: 60 us against 22 for
+        // the vector kernel with its 64 queries per workgroup.  Below two workgroups per CU the vector kernel runs.
+        const int mm_groups = ((b.max_kp + kMmQueries - 1) / kMmQueries) * n_active;
+        if (g_match_mfma == 2 || (g_match_mfma == 1 && mm_groups >= 512))
             hipLaunchKernelGGL(match_mfma_kernel, dim3((b.max_kp + kMmQueries - 1) / kMmQueries, n_active), dim3(kMmThreads), 0,
                                stream, b, ratio, md);
         else
             hipLaunchKernelGGL(match_topk_kernel<8>, grid, block, 0, stream, b, ratio, md);
         break;
+    }
     case 16: hipLaunchKernelGGL(match_topk_kernel<16>, grid, block, 0, stream, b, ratio, md); break;
     default: break;
     }

@@ -40,6 +40,48 @@ def test_match_random_bit_exact(ctx, n_train, n_query, nbytes):
         assert got.tobytes() == ref.tobytes()
 
 
+def test_match_matrix_core_kernel_batch_bit_exact(ctx):
+    """The int8-GEMM matcher (match_mfma_kernel) serves 256-bit descriptors once a batch has enough workgroups for it
+    (>= 512: two per CU); the single-shot tests above run the vector kernel.  A batch of 64 ragged pairs (64 x 8 = 512
+    workgroups): random descriptors with planted near-duplicates, exact duplicates in the train set (ties: the smaller
+    train index must win), distances at the ratio boundary -- match lists byte-identical to the oracle for every pair."""
+    rng = np.random.default_rng(4242)
+    P, N = 64, 2000
+    n1 = rng.integers(2, N + 1, size=P).astype(np.int32)
+    n2 = rng.integers(1, N + 1, size=P).astype(np.int32)
+    n1[:4] = [N, 2, 33, 257]
+    n2[:4] = [N, N, 31, 1]
+    d1 = rng.integers(0, 256, size=(P, N, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, size=(P, N, 32), dtype=np.uint8)
+    for p in range(P):
+        k = int(min(n1[p], n2[p])) // 2
+        src = (np.arange(k) * 3) % n1[p]
+        d2[p, :k] = d1[p, src]
+        flips = rng.integers(0, 4, size=k)                       # 0 .. 3 flipped bits: distances 0 .. 3, many ties
+        for j in range(k):
+            for _ in range(flips[j]):
+                d2[p, j, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+        if n1[p] > 50:
+            d1[p, 40] = d1[p, 3]                                  # duplicate train rows
+            d1[p, 17] = d1[p, 3]
+    kp = np.zeros((P, N, 2), dtype=np.float32)
+    kp[..., 0] = rng.uniform(0, 640, size=(P, N))
+    kp[..., 1] = rng.uniform(0, 480, size=(P, N))
+    K = np.tile(synth.K_DEFAULT.reshape(1, 9), (P, 1))
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, d1, kp, n1, d2, kp, n2, K, np.arange(P, dtype=np.int64))
+    prm = capi.default_params(num_hypotheses=64, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-2)
+    b.run(prm)
+    b.sync()
+    out = b.download(mask=False, points=False)
+    b.close()
+    for p in range(P):
+        ref = o.match_visual_features(d1[p, :n1[p]], d2[p, :n2[p]], prm.ratio, prm.max_dist)
+        m = int(out["results"][p]["n_matches"])
+        assert m == len(ref), (p, m, len(ref))
+        assert out["matches"][p][:m].tobytes() == ref.tobytes(), p
+
+
 def test_match_ties_canonical_order(ctx):
     """Constructed ties: equal distances must resolve to the smaller train index; equal-distance matches are
     ordered by queryIdx (SURVEY 8(c) KAT 5)."""
