@@ -1016,7 +1016,8 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
 //                                bounds of the hypotheses that finish raise the pair's bound
 // survivors      flat            approximate records whose upper bound reaches the final bound -> work list (-> exact_list)
 // select         grid P          exact count + residual of everything at or above the bound (ransac_select_kernel)
-// bf16 (round to nearest even) of a finite binary32 number, as its 16 bits; x = hi + lo + (<= 2^-18 |x|)
+// bf16 (round to nearest even, 8 significant bits: unit roundoff 2^-8) of a finite binary32 number, as its 16 bits;
+// x = hi + lo + (<= 2^-16 |x|)
 __device__ __forceinline__ uint32_t bf16_bits(float x)
 {
     uint32_t u = __float_as_uint(x);
@@ -1683,10 +1684,11 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
 // faster than the vector kernel; here the product runs in SPLIT bf16: every binary32 operand is hi + lo with
 // hi = bf16(x), lo = bf16(x - hi) (sixteen significant bits), and Phi_k F_k ~ hi hi + hi lo + lo hi: 27 products of bf16
 // numbers (exact in binary32) summed in binary32 by two v_mfma_f32_32x32x16_bf16 (K = 32, five slots zero, 64 clocks).
-// Error of the value against the exact sum on the binary32 inputs: representation 2 x 2^-18, the dropped lo lo 2^-18, the
-// <= 32 additions of the accumulation 2^-23 each (whatever their order and rounding mode), the monomial and the three
-// input roundings 4 x 2^-24 -- together < 2^-15.9 of T = sum |p2_j| |F_jk| |p1_k|; the phase counts against
-// tu' = tu + 2^-15 T(box) (tu already carries the band and the binary32 bound e32), so its count is an UPPER bound of the
+// Error of the value against the exact sum on the binary32 inputs, per term |Phi_k F_k|: the two representation errors
+// 2 x 2^-16 (|x - hi| <= 2^-8 |x|, |x - hi - lo| <= 2^-8 |x - hi|), the dropped lo lo 2^-16, the <= 32 additions of the
+// accumulation 2^-23 each (whatever their order and rounding mode: 2^-18), the monomial and the three input roundings
+// 4 x 2^-24 -- together < 3.3 x 2^-16 = 0.82 x 2^-14 of T = sum |p2_j| |F_jk| |p1_k|; the phase counts against
+// tu' = tu + 2^-14 T(box) (tu already carries the band and the binary32 bound e32), so its count is an UPPER bound of the
 // exact count like every other.  A tile cannot drop single hypotheses, so the phase takes NO exit tests: it counts points
 // [0, n1) for every approximate record,
 //     n1 = dense_points(M, B0) = the multiple of 32 that covers M - B0 + 32 points, clamped to [0, M rounded down],
@@ -1887,12 +1889,12 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
                 dense_operands(fh, fl, half, 1, op);
                 Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
                 Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
-                // tu' = tu + 2^-15 T,  T = [X2 Y2 1] |F~| [X1 Y1 1]^T (every rounding upwards)
+                // tu' = tu + 2^-14 T,  T = [X2 Y2 1] |F~| [X1 Y1 1]^T (every rounding upwards)
                 const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
                 const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
                 const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
                 const float T = fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f);
-                const float tu = on ? (fr[9] + 0x1p-15f * T) * (1.f + 0x1p-22f) : 0.f;
+                const float tu = on ? (fr[9] + 0x1p-14f * T) * (1.f + 0x1p-22f) : 0.f;
                 const float t2h = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
                 t2H[c] = f32x2{t2h, t2h};
             }
@@ -2048,7 +2050,7 @@ __global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
 
 // The FINISH on the matrix cores.  What the dense phase could not drop against the PILOT's bound (a quarter of the
 // hypotheses) is worked off in batches of 256 list entries, best partial counts first, grid (P, batches): the same tile
-// product, indicators against tl' = tl - 2^-15 T for every point (the lower-bound count L) and against tu' = tu + 2^-15 T for
+// product, indicators against tl' = tl - 2^-14 T for every point (the lower-bound count L) and against tu' = tu + 2^-14 T for
 // the points from n1 on (added to the dense phase's count in hyp_cnt: the upper bound U).  max L raises the pair's bound (one
 // atomic per workgroup); a batch starts by dropping the entries that can no longer reach the bound as it stands, and leaves
 // at once if none can -- after the first batches of a pair that is the usual case (the winner is among the largest
@@ -2121,7 +2123,7 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
         const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
         const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
         const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
-        const float ebf = 0x1p-15f * (fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f));
+        const float ebf = 0x1p-14f * (fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f));
         const float tu = on[c] ? (fr[9] + ebf) * (1.f + 0x1p-22f) : 0.f;
         // the lower threshold only shrinks; every |a| < tl' must be counted by an UPPER count and none above it by this
         // LOWER one: T2 = tl'^2 (1 - 2^-21)

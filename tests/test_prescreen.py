@@ -143,6 +143,35 @@ def _bf16_value(b):
     return (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
 
 
+def test_bf16_split_error_bound():
+    """x = hi + lo + d with |d| <= 2^-16 |x| for the round-to-nearest-even bf16 split the counting kernels
+    use, x - hi exact in binary32, and the three kept products of two split operands within 3 x 2^-16 of the full product --
+    on random operands, on operands just below a rounding boundary (the worst case), and on powers of two."""
+    rng = np.random.default_rng(3)
+    x = (rng.normal(size=200000) * 10.0 ** rng.uniform(-6, 6, size=200000)).astype(np.float32)
+    # the worst case of round-to-nearest: just below the midpoint between two bf16 numbers, at both levels
+    worst = np.float32(1.0) + np.float32(2.0 ** -8) - np.float32(2.0 ** -23) + np.float32(2.0 ** -16) - np.float32(2.0 ** -22)
+    x = np.concatenate([x, worst * np.float32(2.0) ** rng.integers(-20, 20, size=1000).astype(np.float32),
+                        np.float32(2.0) ** np.arange(-30, 30, dtype=np.float32)]).astype(np.float32)
+    hi = _bf16_value(_bf16_bits(x))
+    r = (x - hi.astype(np.float32))
+    assert np.all(r.astype(np.float64) == x.astype(np.float64) - hi)          # the difference is exact in binary32
+    lo = _bf16_value(_bf16_bits(r))
+    xd = x.astype(np.float64)
+    assert np.all(np.abs(xd - hi) <= 2.0 ** -8 * np.abs(xd))
+    d = np.abs(xd - hi - lo)
+    assert np.all(d <= 2.0 ** -16 * np.abs(xd))
+    y = rng.permutation(x)
+    yh = _bf16_value(_bf16_bits(y))
+    yl = _bf16_value(_bf16_bits(y - yh.astype(np.float32)))
+    yd = y.astype(np.float64)
+    kept = hi * yh + hi * yl + lo * yh
+    err = np.abs(xd * yd - kept)
+    assert np.all(err <= 3 * 2.0 ** -16 * np.abs(xd * yd) * (1 + 1e-9))
+    print("worst split error %.3f x 2^-16, worst three-product error %.3f x 2^-16"
+          % (float((d / np.abs(xd)).max() * 2 ** 16), float((err / np.abs(xd * yd)).max() * 2 ** 16)))
+
+
 @pytest.mark.gpu
 def test_matrix_core_tile_layout_and_accumulation_error():
     """the counting kernels sum 27 (+5 zero) products of bf16 numbers per evaluation with two
