@@ -614,7 +614,10 @@ def main():
                 "pairs_per_gpu": n_local, "keypoints": args.kp, "hypotheses": args.hyp, "noise_px": args.noise_px,
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world,
                 "threshold_note": "headline threshold 1e-2 (a consensus set exists: ~1100 inliers per pair, every stage "
-                                  "runs); SURVEY 8(d)'s literal 5e-2/K00/K11 is timed in `reference_threshold`"},
+                                  "runs); SURVEY 8(d)'s literal 5e-2/K00/K11 is timed in `reference_threshold`",
+                "arithmetic_note": "results are the f64 contract's, bit for bit; the pre-screen's approximate F and the inlier "
+                                   "COUNT BOUNDS that decide which hypotheses are solved exactly are computed in f64 / binary32 "
+                                   "/ split bf16 (matrix cores) with certified error terms (DESIGN.md 4.3e)"},
             "roofline": roofline_object(table, stats, traffic, traffic_src),
             "hbm_roofline": {
                 "achieved": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9, 3), "peak": HBM_PEAK_GBS,
