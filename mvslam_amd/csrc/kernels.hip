@@ -595,6 +595,7 @@ __device__ __forceinline__ void solve_record(const BatchDev &b, const RunParams 
         b.bound[pair] = 0;   // pruning bound of the scoring launch that follows on the stream
 }
 
+#ifdef MVS_DEBUG_HOOKS   // experiment ladder (variants 632 / 760 / 1656 / 1784): diagnostics build only
 template <int VAR>
 __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp, int respect_mode)
 {
@@ -606,6 +607,8 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunPar
         return;   // this pair's hypotheses are pre-screened (ransac_prescreen_kernel)
     solve_record<VAR>(b, rp, pair, M, blockIdx.x * blockDim.x + tid);   // any block size that divides 256 (the launch picks it)
 }
+
+#endif  // MVS_DEBUG_HOOKS
 
 // The pairs the probe left in mode 0, in pair order: m0list[0] = their number, then the pairs (one workgroup; the pre-screened
 // stage's exact-solve launch walks this list instead of sending a workgroup per (pair, 64 hypotheses) that leaves at once --
@@ -651,6 +654,11 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_list_kernel(BatchDev b, R
     }
 }
 
+constexpr int kCntSlots = 4;   // hypotheses a wavefront of the point-per-lane counting kernels carries at a time
+typedef __attribute__((address_space(4))) double CDouble;
+
+#ifdef MVS_DEBUG_HOOKS   // experiment ladder: hypothesis-per-lane scoring of stored records, A / V wavefront pairs, round 2's pruned
+// counting without per-hypothesis thresholds -- diagnostics build only (tools/ab_ransac.py)
 constexpr int kScoreChunk = 1024;   // points staged per pass: 32 KB of LDS -> 4 workgroups per CU
 __global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams rp)
 {
@@ -846,8 +854,6 @@ __global__ __launch_bounds__(512, 1) void ransac_solve_av_kernel(BatchDev b, Run
 // with the load issued a group ahead).  Which hypotheses get dropped depends on timing; the winner does not.
 // Residual sums are not accumulated here: ransac_select_kernel computes them, in the reference's index order, for the
 // hypotheses that tie at the final maximum only.
-constexpr int kCntSlots = 4;
-typedef __attribute__((address_space(4))) double CDouble;
 
 __device__ __forceinline__ int count_block(const double (&F)[9], const double4 &p, double thr)
 {
@@ -1005,6 +1011,8 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
     if (STATS && lane == 0 && b.stats)
         atomicAdd(&b.stats[2], visits * (unsigned long long)BW);   // executed (hypothesis, point) evaluations incl. padding
 }
+
+#endif  // MVS_DEBUG_HOOKS
 
 // ---- sound pre-screen of the hypotheses (prescreen.hpp) -------------------------------------------------
 // pair_prepare   grid P          bounding box of the pair's matches; probe of the first 64 hypotheses: a pair is pre-screened
@@ -1960,6 +1968,7 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
+#ifdef MVS_DEBUG_HOOKS   // diagnostics build only
 // diagnostics: one 32 x 32 x 32 tile through the two MFMAs exactly as the counting kernels issue them.  A, B: [32][32] bf16
 // bit patterns (row = point / hypothesis, column = K slot); out[point][hypothesis] (binary32).  Pins the K slot mapping, the
 // accumulator layout and the accumulation error the bound assumes (tests/test_prescreen.py).
@@ -1992,6 +2001,8 @@ void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStre
 {
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, stream, A, B, out);
 }
+
+#endif  // MVS_DEBUG_HOOKS
 
 // The pair's list in the order of the dense phase's counts, largest first (counting sort on the count, one workgroup per
 // pair; the sorted list is the second half of clist).  The finish then meets the likely winners in its first batches.
@@ -2518,6 +2529,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
     }
 }
 
+#ifdef MVS_DEBUG_HOOKS   // diagnostics build only
 // diagnostics: compare the unscaled sqrt / div sequences with the compiler's IEEE ones on caller-supplied operands.
 // out[0] = sqrt mismatches among operands that pass sqrt_fast_ok, out[1] = div mismatches among operand pairs
 // inside the guarded range, out[2] / out[3] = number of operands / pairs that were inside the guards.
@@ -2541,6 +2553,8 @@ __global__ __launch_bounds__(256) void fastmath_check_kernel(const double *x, co
             atomicAdd(&out[1], 1ull);
     }
 }
+
+#endif  // MVS_DEBUG_HOOKS
 
 // find_fundamental_matrix on one explicit sample (single lane); diagnostics / API parity only.
 __global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, const double *p2, double *Fout, int *okout)
@@ -3026,17 +3040,6 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.fn = reinterpret_cast<const void *>(ransac_solve_list_kernel<240 + 1024>);
         d.threads = kSolveBlock;
         break;
-    case kKRansacScore:
-        d.name = "ransac_score_kernel";
-        d.fn = reinterpret_cast<const void *>(ransac_score_kernel);
-        d.threads = kHypPerBlock;
-        break;
-    case kKRansacCount:
-        d.name = "ransac_count_kernel<768, 2>";
-        d.fn = reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>);
-        d.threads = kCntThreads;
-        d.dynamic_lds = count_lds_bytes(max_kp);
-        break;
     case kKRansacSelect:
         d.name = "ransac_select_kernel";
         d.fn = reinterpret_cast<const void *>(ransac_select_kernel);
@@ -3063,12 +3066,6 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.fn = reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>);
         d.threads = kCntThreads;
         d.dynamic_lds = count_lds_bytes(max_kp);
-        break;
-    case kKRansacCount32:
-        d.name = "ransac_count32_kernel<768, 4, 4, 1, false>";
-        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>);
-        d.threads = kCnt32Threads;
-        d.dynamic_lds = count32_lds_bytes(max_kp);
         break;
     case kKRansacCountPilot:
         d.name = "ransac_count32_kernel<768, 4, 4, 0, false>";
@@ -3108,6 +3105,25 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.fn = reinterpret_cast<const void *>(finalize_select_kernel);
         d.threads = kFinThreads;
         break;
+#ifdef MVS_DEBUG_HOOKS   // kernels of the experiment ladder: ids behind kKernelCountProduct, diagnostics build only
+    case kKRansacScore:
+        d.name = "ransac_score_kernel";
+        d.fn = reinterpret_cast<const void *>(ransac_score_kernel);
+        d.threads = kHypPerBlock;
+        break;
+    case kKRansacCount:
+        d.name = "ransac_count_kernel<768, 2>";
+        d.fn = reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>);
+        d.threads = kCntThreads;
+        d.dynamic_lds = count_lds_bytes(max_kp);
+        break;
+    case kKRansacCount32:
+        d.name = "ransac_count32_kernel<768, 4, 4, 1, false>";
+        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>);
+        d.threads = kCnt32Threads;
+        d.dynamic_lds = count32_lds_bytes(max_kp);
+        break;
+#endif
     default: return false;
     }
     *out = d;
@@ -3119,16 +3135,19 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
 // with a clear message instead of at the first launch.
 hipError_t prepare_kernels()
 {
-    const void *fns[] = {reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>),
+    const void *fns[] = {
+#ifdef MVS_DEBUG_HOOKS
+                         reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl>),
                          reinterpret_cast<const void *>(ransac_count_kernel<kCntThreads, kCntPpl, true>),
-                         reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>),
-                         reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
-                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>),
-                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1, true>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2, true>),
+#endif
+                         reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl>),
+                         reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>),
+                         reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>),
                          reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_count_mfma_kernel<true>),
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
@@ -3142,8 +3161,15 @@ hipError_t prepare_kernels()
     return hipSuccess;
 }
 
+// The product library has ONE path and no process-global mutable state: the switches below are compile-time constants there.
+// Only the diagnostics build (-DMVS_DEBUG_HOOKS: kernels_dbg.o -> libmvslam_hip_dbg.so) turns them into variables with
+// setters, and only that build contains the experiment ladder's kernels (tools/ab_ransac.py, tests/prescreen_gpu_check.py).
+#ifdef MVS_DEBUG_HOOKS
 static int g_match_mfma = 1;   // 1 = by batch size (below); diagnostics: 0 = always the VALU kernel, 2 = always the matrix-core one
 void set_match_mfma(int v) { g_match_mfma = v; }
+#else
+constexpr int g_match_mfma = 1;
+#endif
 
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt)
 {
@@ -3186,9 +3212,11 @@ void launch_prep_points(const BatchDev &b, const double *uv1, const double *uv2,
 // 120 fused; 632 = solve + hypothesis-per-lane scoring as two launches (round 1); 1784 = solve (with the sqrt-free
 // convergence test, bit 128 of the kernel's VAR, for the 9x9 and -- kernel bit 1024 -- the 3x3 SVD) + pruned
 // point-per-lane scoring (bit 1024 of the launch variant): ransac_count + ransac_select
+#ifdef MVS_DEBUG_HOOKS
 static int g_ransac_variant = 9000;
 void set_ransac_variant(int v) { g_ransac_variant = v; }
 int get_ransac_variant() { return g_ransac_variant; }
+#endif
 
 template <int VAR>
 static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid, dim3 block, bool stats, hipStream_t stream,
@@ -3201,6 +3229,7 @@ static void launch_ransac_var(const BatchDev &b, const RunParams &rp, dim3 grid,
         hipLaunchKernelGGL((ransac_kernel<false, VAR>), grid, block, 0, stream, b, rp);
 }
 
+#ifdef MVS_DEBUG_HOOKS   // round 2's pruned scoring (variants 1656 / 1784 / 3832)
 static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt,
                                   bool stats = false)
 {
@@ -3223,6 +3252,9 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
 }
 
+#endif
+
+#ifdef MVS_DEBUG_HOOKS
 static int g_count_dense = 1;   // 1 = pilot + dense matrix-core phase + matrix-core finish; diagnostics: 0 = one
                                 // ransac_count32 launch, 2 = pilot + dense phase + the vector finish (ransac_count32, phase 2)
 void set_count_dense(int v) { g_count_dense = v; }
@@ -3234,6 +3266,10 @@ void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active,
     hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, mode);
     hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((rp.num_hypotheses + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
 }
+#else
+constexpr int g_count_dense = 1;
+constexpr int g_force_mode = -1;
+#endif
 
 // the pre-screened RANSAC stage (variant 9000)
 static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt,
@@ -3264,6 +3300,7 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     // anything can be dropped, no exit tests) -> finish (the listed hypotheses that can still reach the bound, from there on).
     // g_count_dense = 0 (diagnostics library only): ransac_count32_kernel over everything in one launch -- byte-identical
     // results, 5.2 ms against 0.2 + 2.0 + 1.4 per 512 pairs (profiles/r03_count32_experiments.md).
+#ifdef MVS_DEBUG_HOOKS
     if (!g_count_dense) {
         if (lt) lt->mark(kKRansacCount32);
         if (stats)
@@ -3272,7 +3309,9 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
         else
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 1>), dim3(wg, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
-    } else {
+    } else
+#endif
+    {
         const int wg_pilot = std::max(1, std::min(wg, (kPilotHyp / kCnt32Slots) / (kCnt32Threads / 64)));
         const size_t lds_dense = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * 64 * kHypRec * 8;
         if (lt) lt->mark(kKRansacCountPilot);
@@ -3293,10 +3332,13 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
         const dim3 fin_grid(n_active, (H + kDenseThreads - 1) / kDenseThreads);   // workgroups past the list's end leave at once
         if (g_count_dense != 2)
             hipLaunchKernelGGL(ransac_list_sort_kernel, dim3(n_active), dim3(256), 0, stream, b);
+#ifdef MVS_DEBUG_HOOKS
         if (g_count_dense == 2) {   // diagnostics: the vector finish (ransac_count32_kernel, phase 2)
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>), dim3(wg, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg);
-        } else {
+        } else
+#endif
+        {
             // two launches: the first batch of every pair (the 256 largest partial counts: the winner is nearly always among
             // them, so the pair's bound is final afterwards), then the rest -- whose workgroups mostly find nothing left
             const int nb = (int)fin_grid.y;
@@ -3332,27 +3374,35 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
                        b, rp);
 }
 
+// the pre-screened stage, or -- for one or two pairs, the per-hypothesis tables and the instrumented replay's rotation
+// counters -- the fused hypothesis-per-lane kernel
+static void launch_ransac_product(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream,
+                                  LaunchTimer *lt, dim3 grid, dim3 block)
+{
+    const bool split_ok = !stats && b.hyp_F && n_active >= kSplitMinPairs;
+    if (!split_ok || b.hyp_count) {
+        if (!stats)
+            launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
+        else
+            launch_ransac_var<120>(b, rp, grid, block, true, stream, lt);
+        if (stats && b.hyp_F && !b.hyp_count && n_active >= kSplitMinPairs)
+            launch_prescreened(b, rp, n_active, stream, nullptr, true);   // + the product path's own counters
+    } else {
+        launch_prescreened(b, rp, n_active, stream, lt, false);
+    }
+}
+
 void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream, LaunchTimer *lt)
 {
     const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
     const dim3 grid(G, n_active), block(kHypPerBlock);
-    // the instrumented replay and the per-hypothesis tables (every count AND every residual) stay on the
-    // hypothesis-per-lane kernels; so does a launch of one or two pairs (latency: fewer launches)
+#ifndef MVS_DEBUG_HOOKS
+    launch_ransac_product(b, rp, n_active, stats, stream, lt, grid, block);
+#else
+    // diagnostics build: the experiment ladder of rounds 1-2 behind mvs_debug_set_ransac_variant (tools/ab_ransac.py)
     const bool split_ok = !stats && b.hyp_F && n_active >= kSplitMinPairs;
     switch (g_ransac_variant) {
-    case 9000:
-        if (!split_ok || b.hyp_count) {
-            // one or two pairs, per-hypothesis tables, the instrumented replay's rotation counters: hypothesis-per-lane kernels
-            if (!stats)
-                launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
-            else
-                launch_ransac_var<120>(b, rp, grid, block, true, stream, lt);
-            if (stats && b.hyp_F && !b.hyp_count && n_active >= kSplitMinPairs)
-                launch_prescreened(b, rp, n_active, stream, nullptr, true);   // + the product path's own counters
-        } else {
-            launch_prescreened(b, rp, n_active, stream, lt, false);
-        }
-        break;
+    case 9000: launch_ransac_product(b, rp, n_active, stats, stream, lt, grid, block); break;
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream, lt); break;
     case 376: launch_ransac_var<376>(b, rp, grid, block, stats, stream, lt); break;   // timing experiment: no V rotations
     case 632:
@@ -3412,6 +3462,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
         break;
     default: launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt); break;
     }
+#endif
 }
 
 void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream, LaunchTimer *lt)
@@ -3424,6 +3475,7 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
     hipLaunchKernelGGL(finalize_select_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b);
 }
 
+#ifdef MVS_DEBUG_HOOKS   // diagnostics build only
 // diagnostics: one Jacobi pair step on two rows of three elements, guarded (unscaled sequences, seeded divisions) against
 // the compiler's IEEE sqrt / division, bit for bit.  rows: n x 6 doubles (row i, row j).  out[0] = steps whose rotated
 // rows or norms differ, out[1] = steps compared (both rotate, guards hold), out[2] = steps where the decision differs
@@ -3487,6 +3539,8 @@ void launch_fastmath_check(const double *x, const double *y, int n, unsigned lon
 {
     hipLaunchKernelGGL(fastmath_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, out);
 }
+
+#endif  // MVS_DEBUG_HOOKS
 
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream)
 {

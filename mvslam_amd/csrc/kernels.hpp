@@ -266,17 +266,13 @@ void launch_orb(const OrbDev &d, hipStream_t stream);
 enum KernelId : int {
     kKMatchTopk = 0,
     kKMatchCompact,
-    kKRansacFused,     // solve + hypothesis-per-lane scoring in one launch (one or two pairs, per-hypothesis tables)
+    kKRansacFused,     // solve + hypothesis-per-lane scoring in one launch (short launches, per-hypothesis tables)
     kKRansacSolve,
-    kKRansacScore,     // hypothesis-per-lane scoring of stored F records (per-hypothesis tables)
-    kKRansacCount,
     kKRansacSelect,
     kKPairPrepare,     // bounding box of the pair's matches + probe: is this pair pre-screened?
     kKRansacPrescreen, // approximate F + certified band per hypothesis
     kKRansacExactList, // exact solve of the listed hypotheses (flagged by the pre-screen / survivors of the count)
     kKRansacCount2,    // pruned counting with per-hypothesis thresholds (upper / lower bounds of the exact count)
-    kKRansacCount32,   // the same in single precision (thresholds widened by the binary32 evaluation error), everything in one
-                       // launch (A/B only: mvs_debug_set_count_dense(0))
     kKRansacCountPilot,  // ransac_count32_kernel, phase 0: the first kPilotHyp hypotheses in full -> the pair's first bound
     kKRansacCountMfma,   // dense counting of the points that must be seen before anything can be dropped: split bf16 on the
                          // matrix cores, no exit tests
@@ -285,6 +281,11 @@ enum KernelId : int {
     kKFinModel,
     kKTriangulate,
     kKFinSelect,
+    kKernelCountProduct,   // the product library's table ends here
+    // kernels of the experiment ladder: they exist in the diagnostics build (-DMVS_DEBUG_HOOKS) only
+    kKRansacScore = kKernelCountProduct,   // hypothesis-per-lane scoring of stored F records
+    kKRansacCount,     // round 2's pruned counting (one threshold per pair)
+    kKRansacCount32,   // single-precision counting, everything in one launch (A/B: mvs_debug_set_count_dense(0))
     kKernelCount
 };
 struct LaunchTimer {
@@ -320,16 +321,19 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
 void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream, LaunchTimer *lt = nullptr);
 // opt-in to > 64 KB of dynamic LDS for the kernels that need it, once per device; hipSuccess or the first error
 hipError_t prepare_kernels();
-// diagnostics: pair_prepare + ransac_prescreen only, every pair forced into the pre-screened mode
+#ifdef MVS_DEBUG_HOOKS
+// diagnostics build only (libmvslam_hip_dbg.so): process-global switches, the experiment ladder, checkers
+// pair_prepare + ransac_prescreen only, every pair forced into the pre-screened mode
 void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active, int mode, hipStream_t stream);
-void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStream_t stream);   // diagnostics
-void set_count_dense(int v);      // diagnostics: 1 = single-precision counting as pilot + dense MFMA phase + finish
-void set_match_mfma(int v);       // diagnostics: 1 (default) 256-bit descriptors on the matrix cores, 0 the VALU kernel
-void set_prescreen_force(int m);   // diagnostics: -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened
-void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants (diagnostics)
+void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStream_t stream);
+void set_count_dense(int v);      // 1 = single-precision counting as pilot + dense MFMA phase + finish
+void set_match_mfma(int v);       // 1 (default) 256-bit descriptors on the matrix cores by batch size, 0 the VALU kernel
+void set_prescreen_force(int m);   // -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened
+void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants
 int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);
 void launch_pairstep_check(const double *rows, int n, unsigned long long *out, hipStream_t stream);
+#endif
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream);
 
 }  // namespace mvs

@@ -111,3 +111,29 @@ def test_synthetic_generator_is_deterministic():
     assert not np.array_equal(a["desc1"], c["desc1"])
     assert a["kp1"].dtype == np.float32 and a["desc1"].shape == (128, 32)
     assert (a["kp1"][:, 0] >= 0).all() and (a["kp1"][:, 0] < 640).all() and (a["kp1"][:, 1] < 480).all()
+
+
+def test_product_library_has_one_path_and_no_experiment_ladder():
+    """the co-compiled kernel variants of rounds 1-2 (one of which computes wrong results by design), the
+    process-global variant switches and the checkers live in the diagnostics library only.  The product library's symbol
+    table AND its embedded device code hold neither; the diagnostics library holds all of them (so the check is not
+    vacuous)."""
+    from mvslam_amd import capi
+
+    gone = ["ransac_solve_av_kernel", "ransac_score_kernel", "set_ransac_variant", "set_count_dense", "set_prescreen_force",
+            "set_match_mfma", "g_ransac_variant", "g_force_mode", "g_count_dense", "g_match_mfma", "fastmath_check_kernel",
+            "pairstep_check_kernel", "mfma_probe_kernel", "mvs_debug_", "ransac_kernelILb0ELi376", "ransac_kernelILb0ELi0"]
+
+    def names(path):
+        sym = subprocess.check_output(["nm", "-a", path]).decode()
+        dev = subprocess.check_output(["strings", "-a", path]).decode()     # kernel names inside the embedded code object
+        return sym + dev
+
+    prod, dbg = names(capi.LIB_PATH), names(capi.DBG_LIB_PATH)
+    for g in gone:
+        assert g not in prod, "libmvslam_hip.so still contains %s" % g
+        assert g in dbg, "libmvslam_hip_dbg.so lost %s" % g
+    # ... and what the product path launches is there
+    for k in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel", "ransac_exact_list_kernel", "ransac_select_kernel",
+              "match_mfma_kernel", "finalize_model_kernel"):
+        assert k in prod, k
