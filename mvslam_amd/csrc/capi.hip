@@ -421,6 +421,54 @@ int mvs_debug_prescreen_only(mvs_batch *b, const mvs_params *params, int n_activ
     HIP_TRY(b->ctx, sync_stream(b->ctx));
     return MVS_OK;
 }
+
+// full-population audit (kernels.hip: audit_kernel).  phase 0: pair_prepare + ransac_prescreen run here (the probe decides every
+// pair's mode), then every record is checked against the exact solve of its sample; phase 1: the caller has just run the
+// batch with the same parameters, the stage's decisions are checked.  counters[16] as documented at audit_kernel; maxc /
+// bound / mode: [n_active] (largest exact count, the stage's bound, the pair's mode), each may be null.
+int mvs_debug_audit(mvs_batch *b, const mvs_params *params, int n_active, int phase, unsigned long long counters[16],
+                    int32_t *maxc, int32_t *bound, int32_t *mode)
+{
+    if (!b || !params || !counters || n_active < 1 || n_active > b->d.n_pairs || (phase != 0 && phase != 1))
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mvs_status st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    const RunParams rp = to_run(*params);
+    unsigned long long *dc = nullptr;
+    int32_t *dm = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dc, 16 * sizeof(unsigned long long)));
+    if (hipMalloc((void **)&dm, (size_t)n_active * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(dc);
+        return MVS_ERR_HIP;
+    }
+    hipError_t e = hipMemsetAsync(dc, 0, 16 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dm, 0xff, (size_t)n_active * sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess && phase == 0)
+        launch_prescreen_only(b->d, rp, n_active, -1, ctx->stream);
+    if (e == hipSuccess)
+        e = launch_audit(b->d, rp, n_active, phase, dc, dm, ctx->stream);
+    if (e == hipSuccess)
+        e = sync_stream(ctx);
+    if (e == hipSuccess)
+        e = hipMemcpy(counters, dc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && maxc)
+        e = hipMemcpy(maxc, dm, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && bound)
+        e = hipMemcpy(bound, b->d.bound, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mode)
+        e = hipMemcpy(mode, b->d.mode, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dc);
+    (void)hipFree(dm);
+    if (e != hipSuccess) {
+        ctx->err = std::string("mvs_debug_audit: ") + hipGetErrorString(e);
+        return MVS_ERR_HIP;
+    }
+    return MVS_OK;
+}
 #endif  // MVS_DEBUG_HOOKS
 
 const char *mvs_status_str(mvs_status s)

@@ -3542,6 +3542,217 @@ void launch_fastmath_check(const double *x, const double *y, int n, unsigned lon
 
 #endif  // MVS_DEBUG_HOOKS
 
+#ifdef MVS_DEBUG_HOOKS
+// ---- full-population audit of the pre-screened stage (diagnostics build; tests/audit_gpu_check.py, VERDICT r3 #1b) -------
+// Every hypothesis of every pair is solved EXACTLY once more (the arithmetic of ransac_exact_list_kernel) and scored exactly
+// on every match (estimator-RANSAC.cpp:100-129), and what the stage decided about it is checked on the device:
+//   PHASE 0  the records are the pre-screen's own (pair_prepare + ransac_prescreen just ran, nothing else): state byte 0 only
+//            if the exact path rejects the sample, no approximate record for a rejected sample; for every certified record
+//            and EVERY match |r_i(F_J) - r~_i| <= the band the record carries (B), with r~ evaluated as the vector counting
+//            kernels do (mode 1: binary32 nested fma on the rounded point; mode 2: the contract's fused form on F~), and
+//            U >= c_J >= L for the counts against the record's own thresholds.
+//   PHASE 1  the batch has just run the whole default stage: a hypothesis the stage DROPPED (record still approximate, or a
+//            mode-0 record whose count was pruned) has an exact count strictly below the pair's final bound (count_viol); a
+//            record marked exact holds F_J bit for bit; a survivor's recorded (matrix-core) upper count is >= its exact
+//            count; no approximate record reaches the bound without having been solved; state 0 <=> the exact path rejects
+//            the sample; maxc[pair] = the largest exact count (the host compares it with the bound and with best_count).
+// out[16]: 0 hypotheses audited, 1 state violations, 2 count_viol, 3 upper-bound violations, 4 lower-bound violations,
+// 5 matches violating (B), 6 bits of the worst |r_J - r~| / band, 7 certified records (phase 0) / survivors (phase 1)
+// checked, 8 largest 9x9 sweep count, 9 exact records that differ from F_J, 10 approximate records at or above the bound,
+// 11 matches with a NaN exact residual (skipped in (B)), 12 mode-0 counts that differ from the exact count, 13 matches
+// checked for (B), 14 rejected samples, 15 sum of the 9x9 sweep counts
+template <int PHASE>
+__global__ __launch_bounds__(256, 1) void audit_kernel(BatchDev b, RunParams rp, unsigned long long *out, int32_t *maxc)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_apts[];
+    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8)
+        return;
+    const int H = rp.num_hypotheses;
+    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
+    const bool live = h < (uint32_t)H;
+    const uint32_t hh = live ? h : (uint32_t)(H - 1);
+    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
+    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(P);
+        double2 *dst = reinterpret_cast<double2 *>(s_apts);
+        for (int i = tid; i < 2 * M; i += kHypPerBlock)
+            dst[i] = src[i];
+        __syncthreads();
+    }
+    double F[9];
+    unsigned rot = 0, pairs = 0;
+    bool bad = false;
+    bool ok = solve_hypothesis<240 + 1024>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+    if (__builtin_expect(__any(bad), 0)) {
+        rot = 0;
+        pairs = 0;
+        ok = solve_hypothesis<(240 + 1024) & ~(32 | 128)>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
+    }
+    const unsigned sweeps = pairs / 36u;
+    const double thr = pair_max_error_sq(b, rp, pair);
+    const int mode = b.mode[pair];
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const size_t rec = (size_t)pair * Hp + h;
+    const int state = live ? (int)b.hyp_okf[rec] : kPsInvalid;
+    const double4 *L4 = reinterpret_cast<const double4 *>(s_apts);
+    unsigned long long v_state = 0, v_count = 0, v_upper = 0, v_lower = 0, v_band = 0, n_cert = 0, v_F = 0, v_surv = 0, n_nan = 0,
+                       v_m0 = 0, n_match = 0;
+    double worst = 0.0;
+    int cJ = 0;
+    if (PHASE == 0) {
+        if (live && mode != 0) {
+            if (state == kPsInvalid && ok) ++v_state;
+            if (state == kPsApprox && !ok) ++v_state;
+            if (state == kPsApprox) {
+                ++n_cert;
+                const double *Fo = b.hyp_F + rec * kHypRec;
+                int U = 0, L = 0;
+                if (mode == 1) {
+                    const float *fo = reinterpret_cast<const float *>(Fo);
+                    float Ft[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        Ft[k] = fo[k];
+                    const float tu = fo[9], tl = fo[10];
+                    const double beta = (double)tu - thr;
+                    for (int i = 0; i < M; ++i) {
+                        const double4 p = L4[i];
+                        const double rJ = epipolar_residual(F, p.x, p.y, p.z, p.w);
+                        const float x1 = (float)p.x, y1 = (float)p.y, x2 = (float)p.z, y2 = (float)p.w;
+                        // ransac_count32_kernel's chain (count_pair32)
+                        const float u0 = __builtin_fmaf(x2, Ft[0], __builtin_fmaf(y2, Ft[3], Ft[6]));
+                        const float u1 = __builtin_fmaf(x2, Ft[1], __builtin_fmaf(y2, Ft[4], Ft[7]));
+                        const float u2 = __builtin_fmaf(x2, Ft[2], __builtin_fmaf(y2, Ft[5], Ft[8]));
+                        const float r32 = __builtin_fabsf(__builtin_fmaf(u0, x1, __builtin_fmaf(u1, y1, u2)));
+                        cJ += rJ < thr ? 1 : 0;
+                        U += r32 < tu ? 1 : 0;
+                        L += r32 < tl ? 1 : 0;
+                        if (rJ != rJ) {
+                            ++n_nan;
+                        } else {
+                            const double d = dabs(rJ - (double)r32);
+                            ++n_match;
+                            if (!(d <= beta)) ++v_band;
+                            worst = fmax(worst, d / beta);
+                        }
+                    }
+                } else {
+                    double Ft[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        Ft[k] = Fo[k];
+                    const double tu = Fo[9];
+                    const double beta = tu - thr;
+                    const double tl = thr - (tu - thr) * (1.0 + 1e-9) - 1e-15 * thr;   // ransac_count2_kernel's lower threshold
+                    for (int i = 0; i < M; ++i) {
+                        const double4 p = L4[i];
+                        const double rJ = epipolar_residual(F, p.x, p.y, p.z, p.w);
+                        const double rt = epipolar_residual(Ft, p.x, p.y, p.z, p.w);
+                        cJ += rJ < thr ? 1 : 0;
+                        U += rt < tu ? 1 : 0;
+                        L += rt < tl ? 1 : 0;
+                        if (rJ != rJ) {
+                            ++n_nan;
+                        } else {
+                            const double d = dabs(rJ - rt);
+                            ++n_match;
+                            if (!(d <= beta)) ++v_band;
+                            worst = fmax(worst, d / beta);
+                        }
+                    }
+                }
+                if (U < cJ) ++v_upper;
+                if (L > cJ) ++v_lower;
+            }
+        }
+    } else {
+        for (int i = 0; i < M; ++i) {
+            const double4 p = L4[i];
+            const double rJ = epipolar_residual(F, p.x, p.y, p.z, p.w);
+            cJ += rJ < thr ? 1 : 0;
+        }
+        if (live) {
+            const int cnt = b.hyp_cnt[rec];
+            const int bound = b.bound[pair];
+            const double *Fo = b.hyp_F + rec * kHypRec;
+            const bool counted = cnt >= 0 && cnt != 0x7fffffff;
+            if ((state == kPsInvalid) != !ok) ++v_state;
+            if (state == kPsNeedExact) ++v_state;   // nothing may still wait for its exact solve
+            if (state == kPsExact) {
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    same = same && __double_as_longlong(Fo[k]) == __double_as_longlong(F[k]);
+                if (!same) ++v_F;
+            }
+            if (mode == 0) {
+                if (ok && counted && cnt != cJ) ++v_m0;                 // a count that survived the pruning is the exact count
+                if (ok && !counted && !(cJ < bound)) ++v_count;         // pruned: cannot reach the bound
+                if (ok && counted && cnt < bound && !(cJ < bound)) ++v_count;
+            } else {
+                if (state == kPsApprox) {
+                    if (cnt >= bound) ++v_surv;                         // would have had to be solved exactly
+                    if (!(cJ < bound)) ++v_count;                       // DROPPED although its exact count reaches the bound
+                } else if (state == kPsExact && counted) {
+                    ++n_cert;                                           // a survivor of the counting: its recorded upper count
+                    if (cnt < cJ) ++v_upper;
+                }
+            }
+        }
+    }
+    // reductions: wavefront first, one atomic per wavefront and non-zero counter
+    auto wsum = [&](unsigned long long v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_xor(v, o);
+        return v;
+    };
+    const unsigned long long vals[16] = {live ? 1ull : 0ull, v_state, v_count, v_upper, v_lower, v_band, 0ull, n_cert, 0ull, v_F,
+                                         v_surv, n_nan, v_m0, n_match, (live && !ok) ? 1ull : 0ull, live ? sweeps : 0u};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k == 6 || k == 8)
+            continue;
+        const unsigned long long t = wsum(vals[k]);
+        if (lane == 0 && t)
+            atomicAdd(&out[k], t);
+    }
+    unsigned sw = live ? sweeps : 0u;
+    int mc = (live && ok) ? cJ : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sw = max(sw, (unsigned)__shfl_xor((int)sw, o));
+        mc = max(mc, __shfl_xor(mc, o));
+        worst = fmax(worst, __shfl_xor(worst, o));
+    }
+    if (lane == 0) {
+        atomicMax(&out[8], (unsigned long long)sw);
+        atomicMax(&out[6], (unsigned long long)__double_as_longlong(worst));   // non-negative doubles order like their bits
+        if (PHASE == 1)
+            atomicMax(&maxc[pair], mc);
+    }
+}
+
+hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, int phase, unsigned long long *out, int32_t *maxc,
+                        hipStream_t stream)
+{
+    const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
+    const size_t lds = (size_t)b.max_kp * 4 * sizeof(double);
+    const void *fn = phase == 0 ? reinterpret_cast<const void *>(audit_kernel<0>) : reinterpret_cast<const void *>(audit_kernel<1>);
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
+    if (e != hipSuccess)
+        return e;
+    if (phase == 0)
+        hipLaunchKernelGGL(audit_kernel<0>, dim3(G, n_active), dim3(kHypPerBlock), lds, stream, b, rp, out, maxc);
+    else
+        hipLaunchKernelGGL(audit_kernel<1>, dim3(G, n_active), dim3(kHypPerBlock), lds, stream, b, rp, out, maxc);
+    return hipGetLastError();
+}
+#endif  // MVS_DEBUG_HOOKS
+
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream)
 {
     hipLaunchKernelGGL(fundamental_kernel, dim3(1), dim3(64), 0, stream, p1, p2, F, ok);

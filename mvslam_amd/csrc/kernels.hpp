@@ -333,6 +333,9 @@ void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel
 int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);
 void launch_pairstep_check(const double *rows, int n, unsigned long long *out, hipStream_t stream);
+// full-population audit of the pre-screened stage (kernels.hip: audit_kernel); out: 16 counters, maxc: [n_active]
+hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, int phase, unsigned long long *out, int32_t *maxc,
+                        hipStream_t stream);
 #endif
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream);
 

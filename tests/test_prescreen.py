@@ -232,3 +232,26 @@ def test_device_prescreen_against_the_oracle_hypothesis_by_hypothesis():
     assert st["mode0_list"] == [0, 0]                 # forced exact: nothing on the work list
     assert st["mode1_list"][0] > 0 and st["auto_list"][0] > 0
     assert st["mfma_checked"] > 20       # upper bounds of the matrix-core counting checked against exact counts
+
+
+@pytest.mark.gpu
+def test_full_population_device_audit():
+    """VERDICT r3 #1b: every one of the 25.6 M hypotheses of BASELINE configs[2] (and of a 64-pair slice at the reference
+    threshold, and of the first 128 sequence pairs) is solved exactly once more on the device and the stage's decision about
+    it is checked there (tests/audit_gpu_check.py; estimator-RANSAC.cpp:76-84,100-129)."""
+    env = dict(os.environ, MVS_USE_DEBUG_LIB="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "audit_gpu_check.py")], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    st = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print(json.dumps(st))
+    assert st["ok"] and len(st["cases"]) == 3
+    assert st["negative_control"]["count_viol"] > 0          # the checker trips when it should
+    c3 = st["cases"][0]
+    assert c3["hypotheses"] == 512 * 50000 and c3["pairs_mode"][1] == 512       # all of configs[2] is pre-screened at 1e-2
+    assert c3["phase0"]["checked"] > 0.9 * c3["hypotheses"]                     # ... and nearly all of it certified
+    assert c3["phase0"]["matches_checked"] > 2.5e10                             # (B) on every match of every certified record
+    assert c3["phase0"]["worst_ratio"] < 1.0
+    assert st["cases"][1]["pairs_mode"][0] == 64                                # the reference threshold: every pair exact
+    for c in st["cases"]:
+        assert c["phase1"]["count_viol"] == 0 and c["phase1"]["max_sweeps9"] <= 30
