@@ -265,6 +265,39 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     return MVS_OK;
 }
 
+#ifdef MVS_DEBUG_HOOKS
+// generic "n inputs -> m outputs" staging for the two probes below
+template <typename Launch>
+static int probe_io(mvs_ctx *ctx, const void *const *in, const size_t *in_bytes, int n_in, void *const *outp, const size_t *out_bytes,
+                    int n_out, Launch launch)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d[8] = {};
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_in + n_out && e == hipSuccess; ++k)
+        e = hipMalloc(&d[k], k < n_in ? in_bytes[k] : out_bytes[k - n_in]);
+    for (int k = 0; k < n_in && e == hipSuccess; ++k)
+        e = hipMemcpy(d[k], in[k], in_bytes[k], hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch(d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = sync_stream(ctx);
+    for (int k = 0; k < n_out && e == hipSuccess; ++k)
+        e = hipMemcpy(outp[k], d[n_in + k], out_bytes[k], hipMemcpyDeviceToHost);
+    for (int k = 0; k < n_in + n_out; ++k)
+        if (d[k])
+            (void)hipFree(d[k]);
+    if (e != hipSuccess) {
+        ctx->err = std::string("probe: ") + hipGetErrorString(e);
+        return MVS_ERR_HIP;
+    }
+    return MVS_OK;
+}
+
+#endif
+
 extern "C" {
 
 int mvs_abi_version(void) { return MVS_ABI_VERSION; }
@@ -468,6 +501,111 @@ int mvs_debug_audit(mvs_batch *b, const mvs_params *params, int n_active, int ph
         return MVS_ERR_HIP;
     }
     return MVS_OK;
+}
+
+// overwrite the ideal-camera points of one pair: pts4 = m x (x1, y1, x2, y2) doubles (the matcher's output is bypassed)
+int mvs_debug_set_points(mvs_batch *b, int pair, int m, const double *pts4)
+{
+    if (!b || !pts4 || pair < 0 || pair >= b->d.n_pairs || m < 0 || m > b->d.max_kp)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sync_stream(ctx));
+    HIP_TRY(ctx, hipMemcpy(b->d.pts + (size_t)pair * b->d.max_kp * 4, pts4, (size_t)m * 4 * sizeof(double), hipMemcpyHostToDevice));
+    const int32_t mm = m;
+    HIP_TRY(ctx, hipMemcpy(b->d.M + pair, &mm, sizeof(mm), hipMemcpyHostToDevice));
+    return MVS_OK;
+}
+
+// read the ideal-camera points of one pair as the kernels see them: pts4 = capacity x 4 doubles, *m = the pair's match count
+int mvs_debug_get_points(mvs_batch *b, int pair, int *m, double *pts4)
+{
+    if (!b || !pts4 || !m || pair < 0 || pair >= b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sync_stream(ctx));
+    int32_t mm = 0;
+    HIP_TRY(ctx, hipMemcpy(&mm, b->d.M + pair, sizeof(mm), hipMemcpyDeviceToHost));
+    mm = std::min(mm, b->d.max_kp);
+    HIP_TRY(ctx, hipMemcpy(pts4, b->d.pts + (size_t)pair * b->d.max_kp * 4, (size_t)mm * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    *m = mm;
+    return MVS_OK;
+}
+
+// pre-screen (every pair forced into mode pmode: 1 single-, 2 double-precision records) + the counting launches alone, with
+// only hypothesis keep[p] of pair p left valid (keep may be null).  dense: 0 = ransac_count32 in one launch, 1 = the product's
+// pilot + matrix-core dense phase + finish.  Out, each [n_active] and optional: the kept hypothesis' recorded count (U), the
+// pair's bound (best lower bound), the points the dense phase covered.
+int mvs_debug_count_only(mvs_batch *b, const mvs_params *params, int n_active, int pmode, int dense, const int32_t *keep,
+                         int32_t *cnt_out, int32_t *bound_out, int32_t *n1_out)
+{
+    if (!b || !params || n_active < 1 || n_active > b->d.n_pairs || (pmode != 1 && pmode != 2) || dense < 0 || dense > 2)
+        return MVS_ERR_INVALID_ARG;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mvs_status st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    const size_t Hp = (size_t)b->d.max_groups * kHypPerBlock;
+    int32_t *dk = nullptr;
+    if (keep) {
+        for (int p = 0; p < n_active; ++p)
+            if (keep[p] >= (int32_t)Hp)
+                return MVS_ERR_INVALID_ARG;
+        HIP_TRY(ctx, hipMalloc((void **)&dk, (size_t)n_active * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemcpy(dk, keep, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d.dense_n1, 0, (size_t)n_active * sizeof(int32_t), ctx->stream));
+    launch_count_only(b->d, to_run(*params), n_active, pmode, dense, dk, ctx->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = sync_stream(ctx);
+    for (int p = 0; p < n_active && e == hipSuccess; ++p) {
+        if (cnt_out && keep && keep[p] >= 0)
+            e = hipMemcpy(cnt_out + p, b->d.hyp_cnt + (size_t)p * Hp + keep[p], sizeof(int32_t), hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess && bound_out)
+        e = hipMemcpy(bound_out, b->d.bound, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n1_out)
+        e = hipMemcpy(n1_out, b->d.dense_n1, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (dk)
+        (void)hipFree(dk);
+    if (e != hipSuccess) {
+        ctx->err = std::string("mvs_debug_count_only: ") + hipGetErrorString(e);
+        return MVS_ERR_HIP;
+    }
+    return MVS_OK;
+}
+
+// the matrix-core counting's compare-free indicator on caller-supplied accumulator values (kernels.hip: indicator_probe_kernel)
+int mvs_debug_indicator_probe(mvs_ctx *ctx, const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u,
+                              float *ind_l)
+{
+    if (!ctx || !a || !tu || !tl || !T || !ind_u || !ind_l || n < 1)
+        return MVS_ERR_INVALID_ARG;
+    const size_t nb = (size_t)n * sizeof(float);
+    const void *in[4] = {a, tu, tl, T};
+    const size_t ib[4] = {nb, nb, nb, nb};
+    void *out[2] = {ind_u, ind_l};
+    const size_t ob[2] = {nb, nb};
+    return probe_io(ctx, in, ib, 4, out, ob, 2, [&](void **d) {
+        launch_indicator_probe((const float *)d[0], (const float *)d[1], (const float *)d[2], (const float *)d[3], n, (float *)d[4],
+                               (float *)d[5], ctx->stream);
+    });
+}
+
+// de-normalisation + fused residual of both paths on caller-supplied (Fn, transforms, point) tuples: in n x 19, out n x 2
+int mvs_debug_rounding_probe(mvs_ctx *ctx, const double *in19, int n, double *out2)
+{
+    if (!ctx || !in19 || !out2 || n < 1)
+        return MVS_ERR_INVALID_ARG;
+    const void *in[1] = {in19};
+    const size_t ib[1] = {(size_t)n * 19 * sizeof(double)};
+    void *out[1] = {out2};
+    const size_t ob[1] = {(size_t)n * 2 * sizeof(double)};
+    return probe_io(ctx, in, ib, 1, out, ob, 1,
+                    [&](void **d) { launch_rounding_probe((const double *)d[0], n, (double *)d[1], ctx->stream); });
 }
 #endif  // MVS_DEBUG_HOOKS
 

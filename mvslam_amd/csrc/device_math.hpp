@@ -890,6 +890,27 @@ MVS_DEV bool eight_point_front(const double (&x1)[8], const double (&y1)[8], con
     return ok;
 }
 
+// F = T2^T Fn T1, T = [s 0 -m0 s; 0 s -m1 s; 0 0 1] (fundamental-matrix.cpp:245): the exact path's de-normalisation, separate
+// multiplications and additions in the reference's order
+MVS_DEV void denormalise_exact(const double (&Fn)[3][3], const EightNorm &nm, double (&F)[9])
+{
+    const double s1 = nm.s1, s2 = nm.s2;
+    const double tx1 = -nm.m1x * s1, ty1 = -nm.m1y * s1, tx2 = -nm.m2x * s2, ty2 = -nm.m2y * s2;
+    double G[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        G[0][j] = s2 * Fn[0][j];
+        G[1][j] = s2 * Fn[1][j];
+        G[2][j] = (tx2 * Fn[0][j] + ty2 * Fn[1][j]) + Fn[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F[i * 3 + 0] = G[i][0] * s1;
+        F[i * 3 + 1] = G[i][1] * s1;
+        F[i * 3 + 2] = (G[i][0] * tx1 + G[i][1] * ty1) + G[i][2];
+    }
+}
+
 // back half: rank-2 enforcement (:127-136) and de-normalisation (:245) of the null vector f
 // VAR bit 1024 (with 32 and 128): the 3x3 SVD with the unscaled sequences too
 // wout: the singular values of reshape(f) as the 3x3 Jacobi computed them (the pre-screen's gap test reads them)
@@ -912,22 +933,7 @@ MVS_DEV void eight_point_back(const double (&f)[9], const EightNorm &nm, double 
                 Fn[i][j] = a * Vt[0][j] + b * Vt[1][j];
         }
     }
-    // F = T2^T Fn T1, T = [s 0 -m0 s; 0 s -m1 s; 0 0 1]
-    const double s1 = nm.s1, s2 = nm.s2;
-    const double tx1 = -nm.m1x * s1, ty1 = -nm.m1y * s1, tx2 = -nm.m2x * s2, ty2 = -nm.m2y * s2;
-    double G[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        G[0][j] = s2 * Fn[0][j];
-        G[1][j] = s2 * Fn[1][j];
-        G[2][j] = (tx2 * Fn[0][j] + ty2 * Fn[1][j]) + Fn[2][j];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        F[i * 3 + 0] = G[i][0] * s1;
-        F[i * 3 + 1] = G[i][1] * s1;
-        F[i * 3 + 2] = (G[i][0] * tx1 + G[i][1] * ty1) + G[i][2];
-    }
+    denormalise_exact(Fn, nm, F);
 }
 
 template <int VAR = 0>

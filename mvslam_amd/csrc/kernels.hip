@@ -1775,6 +1775,30 @@ __device__ __forceinline__ void dense_count(const v16f &acc, f32x2 negH, f32x2 t
     }
 }
 
+// The thresholds of the matrix-core counting, from a single-precision record (F~, tu, tl) and the pair's box: T = [X2 Y2 1]
+// |F~| [X1 Y1 1]^T with every rounding upwards, tu' = tu + 2^-14 T, tl' = tl - 2^-14 T, and the scaled
+// squares the compare-free indicator takes.  One definition for the dense phase, the finish and the diagnostics probe.
+__device__ __forceinline__ float dense_T(const float (&Ff)[9], float X1, float Y1, float X2, float Y2)
+{
+    const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
+    const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
+    const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
+    return fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f);
+}
+// upper: every |a| < tu' must be counted whatever the rounding of a * a: T2 = tu'^2 (1 + 2^-21)
+__device__ __forceinline__ float dense_t2_upper(float tu_rec, float T, bool on)
+{
+    const float tu = on ? (tu_rec + 0x1p-14f * T) * (1.f + 0x1p-22f) : 0.f;
+    return (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
+}
+// lower: the threshold only shrinks and no |a| >= tl' may be counted: T2 = tl'^2 (1 - 2^-21); a non-positive tl' counts nothing
+__device__ __forceinline__ float dense_t2_lower(float tl_rec, float T, bool on, bool &lpos)
+{
+    const float tl = on ? (tl_rec - 0x1p-14f * T) * (1.f - 0x1p-22f) : 0.f;
+    lpos = tl > 0.f;
+    return lpos ? (tl * tl) * (1.f - 0x1p-21f) * 0x1p100f : 0.f;
+}
+
 // amdgpu_waves_per_eu(4, 8): with the default register budget of a 256-thread kernel hipcc puts the MFMA results into
 // accumulation registers and reads every one back with v_accvgpr_read before it can be used (16 more vector
 // instructions per tile).  A wavefront carries TWO blocks of 32 hypotheses: their MFMA chains are independent and share
@@ -1898,12 +1922,7 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
                 Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
                 Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
                 // tu' = tu + 2^-14 T,  T = [X2 Y2 1] |F~| [X1 Y1 1]^T (every rounding upwards)
-                const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
-                const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
-                const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
-                const float T = fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f);
-                const float tu = on ? (fr[9] + 0x1p-14f * T) * (1.f + 0x1p-22f) : 0.f;
-                const float t2h = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
+                const float t2h = dense_t2_upper(fr[9], dense_T(Ff, X1, Y1, X2, Y2), on);
                 t2H[c] = f32x2{t2h, t2h};
             }
             if (g + 1 < g1)
@@ -2131,17 +2150,9 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
         dense_operands(fh, fl, half, 1, op);
         Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
         Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
-        const float t0 = fmaf(X2, fabsf(Ff[0]), fmaf(Y2, fabsf(Ff[3]), fabsf(Ff[6])));
-        const float t1 = fmaf(X2, fabsf(Ff[1]), fmaf(Y2, fabsf(Ff[4]), fabsf(Ff[7])));
-        const float t2 = fmaf(X2, fabsf(Ff[2]), fmaf(Y2, fabsf(Ff[5]), fabsf(Ff[8])));
-        const float ebf = 0x1p-14f * (fmaf(t0, X1, fmaf(t1, Y1, t2)) * (1.f + 0x1p-18f));
-        const float tu = on[c] ? (fr[9] + ebf) * (1.f + 0x1p-22f) : 0.f;
-        // the lower threshold only shrinks; every |a| < tl' must be counted by an UPPER count and none above it by this
-        // LOWER one: T2 = tl'^2 (1 - 2^-21)
-        const float tl = on[c] ? (fr[10] - ebf) * (1.f - 0x1p-22f) : 0.f;
-        lpos[c] = tl > 0.f;
-        const float tuh = (tu * tu) * (1.f + 0x1p-21f) * 0x1p100f;
-        const float tlh = lpos[c] ? (tl * tl) * (1.f - 0x1p-21f) * 0x1p100f : 0.f;
+        const float T = dense_T(Ff, X1, Y1, X2, Y2);
+        const float tuh = dense_t2_upper(fr[9], T, on[c]);
+        const float tlh = dense_t2_lower(fr[10], T, on[c], lpos[c]);
         tuH[c] = f32x2{tuh, tuh};
         tlH[c] = f32x2{tlh, tlh};
     }
@@ -3271,22 +3282,11 @@ constexpr int g_count_dense = 1;
 constexpr int g_force_mode = -1;
 #endif
 
-// the pre-screened RANSAC stage (variant 9000)
-static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt,
-                               bool stats)
+// the counting part of the pre-screened stage: upper / lower count bounds of every record, the pair's bound (mode 1: pilot ->
+// dense matrix-core phase -> sorted list -> matrix-core finish; modes 0 / 2: ransac_count2_kernel)
+static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt, bool stats)
 {
     const int H = rp.num_hypotheses;
-    const int G = (H + kHypPerBlock - 1) / kHypPerBlock;
-    if (lt) lt->mark(kKPairPrepare);
-    hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, g_force_mode);
-    if (lt) lt->mark(kKRansacPrescreen);
-    hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((H + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
-    // pairs the probe did not certify: every hypothesis through the exact solve, a persistent grid over the list of those pairs
-    if (lt) lt->mark(kKRansacSolve);
-    hipLaunchKernelGGL(mode0_list_kernel, dim3(1), dim3(256), 0, stream, b, n_active);
-    static_assert(kSolveBlock == 64, "ransac_solve_list_kernel takes blocks of 64 hypotheses");
-    hipLaunchKernelGGL((ransac_solve_list_kernel<240 + 1024>), dim3(2048), dim3(64), 0, stream, b, rp,
-                       G * (kHypPerBlock / kSolveBlock));
     const int n_groups4 = (H + kCntSlots - 1) / kCntSlots;
     const int wpw = kCntThreads / 64;
     int wg = (512 + n_active - 1) / n_active;
@@ -3362,6 +3362,25 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     else
         hipLaunchKernelGGL((ransac_count2_kernel<kCntThreads, kCntPpl>), dim3(wg, n_active), dim3(kCntThreads), lds_cnt, stream,
                            b, rp, wg);
+}
+
+// the pre-screened RANSAC stage (variant 9000)
+static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt,
+                               bool stats)
+{
+    const int H = rp.num_hypotheses;
+    const int G = (H + kHypPerBlock - 1) / kHypPerBlock;
+    if (lt) lt->mark(kKPairPrepare);
+    hipLaunchKernelGGL(pair_prepare_kernel, dim3(n_active), dim3(256), 0, stream, b, rp, g_force_mode);
+    if (lt) lt->mark(kKRansacPrescreen);
+    hipLaunchKernelGGL(ransac_prescreen_kernel, dim3((H + 63) / 64, n_active), dim3(64), 0, stream, b, rp);
+    // pairs the probe did not certify: every hypothesis through the exact solve, a persistent grid over the list of those pairs
+    if (lt) lt->mark(kKRansacSolve);
+    hipLaunchKernelGGL(mode0_list_kernel, dim3(1), dim3(256), 0, stream, b, n_active);
+    static_assert(kSolveBlock == 64, "ransac_solve_list_kernel takes blocks of 64 hypotheses");
+    hipLaunchKernelGGL((ransac_solve_list_kernel<240 + 1024>), dim3(2048), dim3(64), 0, stream, b, rp,
+                       G * (kHypPerBlock / kSolveBlock));
+    launch_counting(b, rp, n_active, stream, lt, stats);
     const size_t total = (size_t)n_active * b.max_groups * kHypPerBlock;
     const int sg = (int)std::min<size_t>((total + 255) / 256, 2048);
     if (lt) lt->mark(kKRansacSurvivors);
@@ -3734,6 +3753,79 @@ __global__ __launch_bounds__(256, 1) void audit_kernel(BatchDev b, RunParams rp,
         if (PHASE == 1)
             atomicMax(&maxc[pair], mc);
     }
+}
+
+// ---- worst-case-construction probes (tests/test_constants.py, VERDICT r3 #1c) -------------------------------------------
+// every record of pair p except hypothesis keep[p] becomes a rejected sample (keep[p] < 0: the pair is left alone)
+__global__ __launch_bounds__(256) void keep_only_kernel(BatchDev b, const int32_t *keep)
+{
+    const int pair = blockIdx.y;
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const size_t h = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = keep[pair];
+    if (h < Hp && k >= 0 && h != (size_t)k)
+        b.hyp_okf[(size_t)pair * Hp + h] = (uint8_t)kPsInvalid;
+}
+// the counting launches of the stage alone, on the pre-screen's own records (every pair forced into mode `pmode`), with the
+// counting variant `dense` (0: ransac_count32 in one launch, 1: pilot + matrix-core dense phase + matrix-core finish, the
+// product path); afterwards hyp_cnt[keep] = U, bound = the best lower bound
+void launch_count_only(const BatchDev &b, const RunParams &rp, int n_active, int pmode, int dense, const int32_t *keep,
+                       hipStream_t stream)
+{
+    launch_prescreen_only(b, rp, n_active, pmode, stream);
+    if (keep)
+        hipLaunchKernelGGL(keep_only_kernel, dim3(b.max_groups, n_active), dim3(256), 0, stream, b, keep);
+    const int old = g_count_dense;
+    g_count_dense = dense;
+    launch_counting(b, rp, n_active, stream, nullptr, false);
+    g_count_dense = old;
+}
+// the compare-free indicator of the matrix-core counting on caller-supplied accumulator values: ind_u[i] / ind_l[i] = what
+// dense_count adds for accumulator a[i] under a record with thresholds (tu[i], tl[i]) and box term T[i]
+__global__ __launch_bounds__(64) void indicator_probe_kernel(const float *a, const float *tu, const float *tl, const float *T,
+                                                             int n, float *ind_u, float *ind_l)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n)
+        return;
+    const f32x2 negH = {-0x1p100f, -0x1p100f};
+    bool lpos;
+    const float t2u = dense_t2_upper(tu[i], T[i], true), t2l = dense_t2_lower(tl[i], T[i], true, lpos);
+    const f32x2 x = {a[i], -a[i]};
+    const f32x2 sq = pk_mul(x, x);
+    const f32x2 u = pk_ind(sq, negH, f32x2{t2u, t2u}), l = pk_ind(sq, negH, f32x2{t2l, t2l});
+    ind_u[i] = u.x == u.y ? u.x : -1.f;
+    ind_l[i] = l.x == l.y ? l.x : -1.f;
+}
+void launch_indicator_probe(const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u, float *ind_l,
+                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(indicator_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, a, tu, tl, T, n, ind_u, ind_l);
+}
+// de-normalisation + fused residual exactly as the two paths run them: in[i] = Fn (9, row-major), s1, s2, m1x, m1y, m2x, m2y,
+// x1, y1, x2, y2; out[i] = {residual under prescreen_denormalise(Fn), residual under denormalise_exact(Fn)}
+__global__ __launch_bounds__(64) void rounding_probe_kernel(const double *in, int n, double *out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n)
+        return;
+    const double *q = in + (size_t)i * 19;
+    double Fn[9], Fn3[3][3], Fa[9], Fb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        Fn[k] = q[k];
+        Fn3[k / 3][k % 3] = q[k];
+    }
+    EightNorm nm;
+    nm.s1 = q[9]; nm.s2 = q[10]; nm.m1x = q[11]; nm.m1y = q[12]; nm.m2x = q[13]; nm.m2y = q[14];
+    prescreen_denormalise(Fn, nm, Fa);
+    denormalise_exact(Fn3, nm, Fb);
+    out[2 * i] = epipolar_residual(Fa, q[15], q[16], q[17], q[18]);
+    out[2 * i + 1] = epipolar_residual(Fb, q[15], q[16], q[17], q[18]);
+}
+void launch_rounding_probe(const double *in, int n, double *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rounding_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, in, n, out);
 }
 
 hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, int phase, unsigned long long *out, int32_t *maxc,

@@ -334,6 +334,11 @@ int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);
 void launch_pairstep_check(const double *rows, int n, unsigned long long *out, hipStream_t stream);
 // full-population audit of the pre-screened stage (kernels.hip: audit_kernel); out: 16 counters, maxc: [n_active]
+void launch_count_only(const BatchDev &b, const RunParams &rp, int n_active, int pmode, int dense, const int32_t *keep,
+                       hipStream_t stream);
+void launch_indicator_probe(const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u, float *ind_l,
+                            hipStream_t stream);
+void launch_rounding_probe(const double *in, int n, double *out, hipStream_t stream);
 hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, int phase, unsigned long long *out, int32_t *maxc,
                         hipStream_t stream);
 #endif
