@@ -285,7 +285,10 @@ def roofline_object(table, stats, traffic, traffic_src):
                  "evals_possible": int(stats["score_evals"]), "evals_executed": int(stats["score_evals_executed"]),
                  "evals_executed_f32": int(stats["score_evals_executed_f32"]),
                  "evals_executed_mfma_dense": int(stats.get("score_evals_executed_mfma", 0)),
-                 "evals_executed_mfma_finish": int(stats.get("score_evals_executed_mfma_finish", 0))},
+                 "evals_executed_mfma_finish": int(stats.get("score_evals_executed_mfma_finish", 0)),
+                 "max_sweeps9": int(stats.get("max_sweeps9", 0)),
+                 "dense_points_over_matches": round(stats["dense_points"] / stats["matches_mode1"], 3)
+                 if stats.get("matches_mode1") else None},
         "per_kernel": table,
         "fp64_issue_note": "a dependency-free v_fma_f64 stream sustains 53 (1 wave/SIMD) to 61 TFLOP/s (2 waves) on this "
                            "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"}
@@ -439,6 +442,46 @@ def bench_extract(capi, np, dev, args, images=64, width=640, height=480):
     return out
 
 
+def bench_sensitivity(capi, synth, np, dev, args, pairs=64):
+    """How the pre-screened stage behaves away from the headline workload: wrong-match share x pixel noise x
+    inlier threshold, 64 pairs per cell, full keypoint and hypothesis counts.  Per cell: pairs/s of the whole path (HIP
+    events around 3 passes), the share of the hypotheses that went through the exact solve, the pairs per mode as the
+    probe decided, the share of a pair's matches the dense counting phase had to cover (n1 / M), best count."""
+    ctx = capi.Context(dev)
+    batch = capi.Batch(ctx, pairs, args.kp, 32)
+    cells = []
+    t_all = time.perf_counter()
+    for outl in (0.3, 0.5, 0.7, 0.9):
+        for noise in (0.5, 2.0):
+            data = synth.make_batch(9000, pairs, n_kp=args.kp, noise_px=noise, outlier_frac=outl)
+            batch.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+                         data["global_index"])
+            for thr in (1e-2, 1e-3, 1e-4):
+                prm = capi.default_params(sampler=capi.SAMPLER_PHILOX, min_inliers=8, ratio=0.7, max_dist=10.0, max_error_sq=thr,
+                                          num_hypotheses=args.hyp, seed=synth.SEED_BASE)
+                tot, _ = batch.time(prm, steps=3, warmup=1, per_kernel=False)
+                st = batch.stats(prm)
+                res = batch.download(matches=False, mask=False, points=False)["results"]
+                ms = tot / 3
+                cells.append({
+                    "outlier_frac": outl, "noise_px": noise, "max_error_sq": thr, "ms_per_batch": round(ms, 3),
+                    "pairs_per_s": round(pairs / (ms * 1e-3), 1),
+                    "exact_solve_share": round(st["exact_solves"] / max(st["hypotheses"], 1), 5),
+                    "pairs_mode": st["pairs_mode"],
+                    "dense_points_over_matches": round(st["dense_points"] / st["matches_mode1"], 3) if st["matches_mode1"] else None,
+                    "avg_matches": round(float(res["n_matches"].mean()), 1),
+                    "avg_best_count": round(float(res["best_count"].mean()), 1), "valid_pairs": int(res["valid"].sum())})
+    batch.close()
+    ctx.close()
+    worst = min(cells, key=lambda c: c["pairs_per_s"])
+    return {"pairs_per_cell": pairs, "keypoints": args.kp, "hypotheses": args.hyp, "seconds": round(time.perf_counter() - t_all, 1),
+            "min_pairs_per_s": worst["pairs_per_s"],
+            "min_cell": {k: worst[k] for k in ("outlier_frac", "noise_px", "max_error_sq")},
+            "note": "64-pair batches: rates are below the 512-pair headline at equal work (fewer workgroups per launch); the "
+                    "forced-exact rate of every cell is in profiles/r04_sensitivity_guard.json (diagnostics build)",
+            "cells": cells}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,14 +497,16 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1; 'gloo' (+ MVS_BENCH_ONE_DEVICE=1) rehearses the multi-rank path on "
                          "a single-GPU box: every rank uses cuda:0 and the pose records are gathered through host memory")
-    ap.add_argument("--pcie", action="store_true", help="also time upload + run + download of the whole batch (host "
-                    "buffers over PCIe); reported as pcie_inclusive_pairs_per_s, never as `value`")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the transfer-inclusive leg (upload + run + download of the "
+                    "whole batch through pinned host buffers, double-buffered): reported as pcie_inclusive_pairs_per_s -- what "
+                    "a host C++ caller of the boundary sees --, never as `value`")
+    ap.add_argument("--pcie-naive", action="store_true", help="also time the synchronous pageable-memory variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
     ap.add_argument("--no-ref-threshold", action="store_true", help="skip the reference-threshold leg (profiling runs: "
                     "keeps every launch of a kernel on the same workload)")
     ap.add_argument("--ref-steps", type=int, default=10, help="wall-clock steps of the reference-threshold leg")
-    ap.add_argument("--sections", default="main,sequence,refine,extract",
+    ap.add_argument("--sections", default="main,sensitivity,sequence,refine,extract",
                     help="legs to run on rank 0 at N = 1 (main is always timed; the others add their sub-objects)")
     ap.add_argument("--seq-frames", type=int, default=1000)
     ap.add_argument("--seq-cpu-frames", type=int, default=48)
@@ -660,6 +705,7 @@ def main():
                 "pairs_per_s": round(n_local * args.ref_steps / dt, 1), "ms_per_step": round(dt / args.ref_steps * 1e3, 3),
                 "valid_pairs": int(res_ref["valid"].sum()), "avg_best_count": round(float(res_ref["best_count"].mean()), 2),
                 "roofline": roofline_object(table_ref, stats_ref, None, None)}
+            out["reference_threshold_pairs_per_s"] = out["reference_threshold"]["pairs_per_s"]
             batch.run(prm)      # back to the headline results for the legs below
             batch.sync()
             dl = batch.download(matches=False, mask=False, points=False)
@@ -670,16 +716,17 @@ def main():
             tot, _ = b1.time(prm, steps=20, warmup=3, per_kernel=False)
             out["single_pair_ms"] = round(tot / 20, 4)  # BASELINE configs[1]: one pair at a time
             b1.close()
-        if args.pcie:
-            # (a) naive: synchronous upload from pageable memory + run + synchronous download, nothing overlapped
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                batch.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"],
-                             data["K"], data["global_index"])
-                batch.run(prm)
-                batch.download()
-            out["pcie_inclusive_pairs_per_s_naive"] = round(n_local * reps / (time.perf_counter() - t0), 1)
+        if not args.no_pcie and world == 1:
+            if args.pcie_naive:
+                # (a) naive: synchronous upload from pageable memory + run + synchronous download, nothing overlapped
+                t0 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    batch.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"],
+                                 data["K"], data["global_index"])
+                    batch.run(prm)
+                    batch.download()
+                out["pcie_inclusive_pairs_per_s_naive"] = round(n_local * reps / (time.perf_counter() - t0), 1)
             # (b) double-buffered: two batches on two contexts (streams), pinned host buffers (mvs_host_alloc),
             # asynchronous upload -> run -> asynchronous download; batch k+1's transfers overlap batch k's kernels.
             # Every step moves the full inputs host -> device and the full outputs device -> host.
@@ -737,6 +784,8 @@ def main():
     batch.close()
     ctx.close()
     if rank == 0 and world == 1:
+        if "sensitivity" in sections:
+            out["sensitivity"] = bench_sensitivity(capi, synth, np, dev, args)
         if "sequence" in sections:
             out["sequence"] = bench_sequence(capi, synth, np, dev, args)
         if "extract" in sections:

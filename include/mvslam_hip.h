@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MVS_ABI_VERSION 2
+#define MVS_ABI_VERSION 3
 
 typedef enum mvs_status {
     MVS_OK = 0,
@@ -268,6 +268,12 @@ typedef struct mvs_work_stats {
                                      2 pre-screened + double-precision counting */
     int64_t score_evals_executed_mfma; /* the part of score_evals_executed done by the dense matrix-core phase (split bf16) */
     int64_t score_evals_executed_mfma_finish; /* ... and by the matrix-core finish (upper and lower bound per evaluation) */
+    /* ABI 3 */
+    int64_t max_sweeps9;          /* largest number of sweeps any 9x9 Jacobi SVD of the replay took (OpenCV's cap: 30; the
+                                     pre-screen's bound assumes the iteration ends by its own test within it) */
+    int64_t dense_points;         /* sum over the pairs in mode 1 of n1, the points the dense matrix-core phase covered */
+    int64_t matches_mode1;        /* sum of M over the same pairs (dense_points / matches_mode1 = the share of a pair's matches
+                                     every hypothesis is counted on before anything can be dropped) */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 

@@ -107,7 +107,9 @@ class WorkStats(C.Structure):
                                               "score_evals_executed", "score_evals_executed_f32", "exact_solves",
                                               "prescreened")] + [("pairs_mode", C.c_int64 * 3),
                                                                  ("score_evals_executed_mfma", C.c_int64),
-                                                                 ("score_evals_executed_mfma_finish", C.c_int64)]
+                                                                 ("score_evals_executed_mfma_finish", C.c_int64),
+                                                                 ("max_sweeps9", C.c_int64), ("dense_points", C.c_int64),
+                                                                 ("matches_mode1", C.c_int64)]
 
 
 class KernelInfo(C.Structure):

@@ -1248,12 +1248,12 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     b->d.hyp_count = nullptr;
     b->d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 6 * sizeof(unsigned long long), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 8 * sizeof(unsigned long long), s));
     st = enqueue_pipeline(b, to_run(*params), n_active, true, nullptr);
     if (st != MVS_OK)
         return st;
     HIP_TRY(ctx, sync_stream(ctx));
-    unsigned long long h[6];
+    unsigned long long h[8];
     HIP_TRY(ctx, hipMemcpy(h, b->d.stats, sizeof(h), hipMemcpyDeviceToHost));
     std::vector<mvs_pair_result> res(n_active);
     HIP_TRY(ctx, hipMemcpy(res.data(), b->d.results, n_active * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
@@ -1264,11 +1264,14 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     out->score_evals_executed_f32 = (int64_t)h[3];
     out->score_evals_executed_mfma = (int64_t)h[4];
     out->score_evals_executed_mfma_finish = (int64_t)h[5];
+    out->max_sweeps9 = (int64_t)h[6];
     if (b->d.mode && b->d.xcount && h[2] + h[3] + h[4] + h[5] > 0) {   // the pre-screened stage ran: its bookkeeping
         std::vector<int32_t> mode(n_active);
         uint32_t xc[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpy(mode.data(), b->d.mode, n_active * sizeof(int32_t), hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(xc, b->d.xcount, sizeof(xc), hipMemcpyDeviceToHost));
+        std::vector<int32_t> n1(n_active);
+        HIP_TRY(ctx, hipMemcpy(n1.data(), b->d.dense_n1, n_active * sizeof(int32_t), hipMemcpyDeviceToHost));
         int64_t legacy = 0, screened = 0;
         for (int i = 0; i < n_active; ++i) {
             if (res[i].n_matches < 8)
@@ -1276,6 +1279,10 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
             const int m = mode[i] < 0 || mode[i] > 2 ? 0 : mode[i];
             out->pairs_mode[m] += 1;
             (m == 0 ? legacy : screened) += params->num_hypotheses;
+            if (m == 1) {
+                out->dense_points += n1[i];
+                out->matches_mode1 += res[i].n_matches;
+            }
         }
         out->exact_solves = legacy + (int64_t)xc[0];
         out->prescreened = screened - (int64_t)xc[0];

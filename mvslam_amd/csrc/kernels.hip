@@ -521,9 +521,14 @@ __global__ __launch_bounds__(256, 1) void ransac_kernel(BatchDev b, RunParams rp
             r += __shfl_xor(r, o);
             p += __shfl_xor(p, o);
         }
+        unsigned sw = live ? pairs / 36u : 0u;   // 9x9 sweeps of this lane's hypothesis (36 pair visits per sweep)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            sw = max(sw, (unsigned)__shfl_xor((int)sw, o));
         if ((tid & 63) == 0) {
             atomicAdd(&b.stats[0], (unsigned long long)r);
             atomicAdd(&b.stats[1], (unsigned long long)p);
+            atomicMax(&b.stats[6], (unsigned long long)sw);
         }
     }
 
@@ -1132,7 +1137,9 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
         const bool live = lane < H;
         const int n_ok = __popcll(__ballot(live && flag != kPsInvalid));
         const int n_s64 = __popcll(__ballot(live && flag == kPsApprox && band <= kPsProbeFrac * thr));
-        const int n_s32 = __popcll(__ballot(live && flag == kPsApprox && band + e32 <= kPsProbeFrac * thr));
+        // e32 = 16 * 2^-24 T: the matrix cores' split-bf16 term 2^-14 T is 64 e32
+        const int n_s32 = __popcll(__ballot(live && flag == kPsApprox && band + e32 <= kPsProbeFrac * thr &&
+                                            band + 65.0 * e32 <= kPsProbeMfmaFrac * thr));
         // 1: pre-screened, counted in single precision; 2: pre-screened, counted in double precision (the band is useful
         // at this threshold but single-precision evaluation is too coarse for it); 0: every hypothesis solved exactly
         // the pre-screen costs about a tenth of an exact solve, so it pays as soon as a fair share of the hypotheses gets

@@ -40,6 +40,15 @@ constexpr double kPsBandFrac = 4.0;       // a hypothesis is certified only if b
 constexpr double kPsProbeFrac = 0.125;    // ... but a PAIR is pre-screened only if a third of its probe gets bands within this
                                           // fraction of the threshold: with bands near the threshold nothing is pruned, every
                                           // hypothesis ends in the exact solve anyway and the pre-screen is pure overhead
+constexpr double kPsProbeMfmaFrac = 1.25; // ... and counted on the matrix cores (mode 1) only if the band INCLUDING the split-bf16
+                                          // term 2^-14 T = 64 e32 stays within this multiple of the threshold.  Beyond the threshold
+                                          // the matrix cores' lower threshold tl' = thr - band - e32 - 2^-14 T is gone and their
+                                          // upper counts take in every match within twice the threshold: only the pilot's bound
+                                          // (vector kernel, no 2^-14 T) prunes, less and less -- such pairs take double-precision
+                                          // counting (mode 2).  Measured on 64-pair batches, outlier share 0.3 .. 0.9, 0.5 / 2 px noise
+                                          // (profiles/r04_sensitivity_guard.json; 2^-14 T is 3 .. 6e-4 there): thr 5e-4 mode 1 1.7-2.8
+                                          // against mode 2 2.7-3.0 ms; 2e-4: 3.6-8.3 against 2.9-3.1; 1e-4: 5.8-9.5 against 3.0-3.2 and
+                                          // 7.4 for solving everything exactly (round 3's probe chose mode 1 there)
 constexpr int kPsInvalid = 0, kPsApprox = 1, kPsNeedExact = 2, kPsExact = 3;   // per-hypothesis state byte (hyp_okf)
 
 // 1 / x for 2^-190 <= |x| <= 2^190 (div_fast's guarded range), correctly rounded like the compiler's division

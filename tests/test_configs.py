@@ -326,3 +326,43 @@ def test_config5_sequence1000(ctx):
             ni = len(ref["inliers"])
             assert t["n_inliers"] == ni and np.array_equal(gt["inlier_idx"][q][:ni], ref["inliers"]), q
             assert t["R"].tobytes() == ref["R"].tobytes() and t["t"].tobytes() == ref["t"].tobytes(), q
+
+
+def test_high_outlier_pairs_at_full_size(ctx):
+    """where the pre-screen prunes least -- 90 % wrong matches, M ~ 2000 matches, 50 000 hypotheses, no
+    all-inlier sample among them (best counts ~70 at 1e-2, ~16 at 1e-3; at 2e-4 the matrix cores' error term exceeds the
+    threshold and the probe sends every pair to double-precision counting).  Oracle parity of winner, count, residual
+    sum, mask, points on every pair at the three thresholds (estimator-RANSAC.cpp:76-84)."""
+    from mvslam_amd import capi
+
+    P, N, H = 8, 2500, 50000
+    data = synth.make_batch(7700, P, n_kp=N, outlier_frac=0.9)
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
+             data["global_index"])
+    for thr in (1e-2, 1e-3, 2e-4):
+        prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=thr)
+        b.run(prm)
+        b.sync()
+        out = b.download()
+        st = b.stats(prm)
+        assert (out["results"]["n_matches"] > 1900).all()
+        assert st["pairs_mode"][0] == 0 and st["pairs_mode"][1] + st["pairs_mode"][2] == P      # pre-screened, one way or the other
+        if thr == 2e-4:
+            assert st["pairs_mode"][2] == P        # the matrix cores' 2^-14 T term is beyond this threshold: double-precision counting
+
+        def oracle(i):
+            return o.image_pair(data["desc1"][i], data["kp1"][i], data["desc2"][i], data["kp2"][i], data["K"][i].reshape(3, 3),
+                                o.make_params(H, o.SAMPLER_PHILOX, synth.SEED_BASE + int(data["global_index"][i]), thr), 0.7, 10.0)
+
+        for i, ref in enumerate(_threads(oracle, list(range(P)))):
+            r = out["results"][i]
+            M, n = ref["n_matches"], ref["n_points"]
+            assert r["n_matches"] == M and bool(r["valid"]) == bool(ref["ok"]), (thr, i)
+            assert r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"], (thr, i)
+            assert r["best_residual"] == ref["best_residual"], (thr, i)
+            assert np.array_equal(out["mask"][i][:M], ref["mask"]), (thr, i)
+            if ref["ok"]:
+                assert r["n_points"] == n and np.array_equal(out["point_idx"][i][:n], ref["point_idx"]), (thr, i)
+                assert np.abs(r["R"] - ref["R"]).max() <= 1e-12 and np.abs(r["t"] - ref["t"]).max() <= 1e-12, (thr, i)
+    b.close()
