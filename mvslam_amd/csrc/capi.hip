@@ -234,9 +234,11 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     uint8_t *ho = nullptr;
     int32_t *hc = nullptr;
     uint32_t *xl = nullptr;
+    float *h32 = nullptr;   // single-precision pre-screen records (mode 1): 48 B x hypotheses x pairs
     mvs_status st;
     if ((st = dev_alloc(b, &p, P * G)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &hf, P * kHypRec * Hp)) != MVS_OK) return st;
+    if ((st = dev_alloc(b, &h32, P * kHypRec32 * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &ho, P * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &hc, P * Hp)) != MVS_OK) return st;
     if ((st = dev_alloc(b, &xl, P * Hp)) != MVS_OK) return st;
@@ -251,12 +253,14 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 2)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
     dev_release(b, b->d.hyp_F);
+    dev_release(b, b->d.hyp_r32);
     dev_release(b, b->d.hyp_okf);
     dev_release(b, b->d.hyp_cnt);
     dev_release(b, b->d.xlist);
     dev_release(b, b->d.clist);
     b->d.wgbest = p;
     b->d.hyp_F = hf;
+    b->d.hyp_r32 = h32;
     b->d.hyp_okf = ho;
     b->d.hyp_cnt = hc;
     b->d.xlist = xl;
@@ -420,11 +424,26 @@ int mvs_debug_read_hyp_rec(mvs_batch *b, int pair, int n_hyp, double *rec_out, u
         return MVS_ERR_INVALID_ARG;
     const size_t Hp = (size_t)b->d.max_groups * kHypPerBlock;
     HIP_TRY(b->ctx, sync_stream(b->ctx));
-    if (rec_out)
+    std::vector<unsigned char> stv(n_hyp);
+    HIP_TRY(b->ctx, hipMemcpy(stv.data(), b->d.hyp_okf + (size_t)pair * Hp, (size_t)n_hyp, hipMemcpyDeviceToHost));
+    if (rec_out) {
         HIP_TRY(b->ctx, hipMemcpy(rec_out, b->d.hyp_F + (size_t)pair * Hp * kHypRec, (size_t)n_hyp * kHypRec * sizeof(double),
                                   hipMemcpyDeviceToHost));
+        // a pair in mode 1 keeps its APPROXIMATE records in the 48-byte single-precision array: they are returned in the
+        // first 48 bytes of the hypothesis' 80-byte slot (the layout the records had when they shared one array)
+        int32_t pmode = 0;
+        HIP_TRY(b->ctx, hipMemcpy(&pmode, b->d.mode + pair, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (pmode == 1) {
+            std::vector<float> r32((size_t)n_hyp * kHypRec32);
+            HIP_TRY(b->ctx, hipMemcpy(r32.data(), b->d.hyp_r32 + (size_t)pair * Hp * kHypRec32, r32.size() * sizeof(float),
+                                      hipMemcpyDeviceToHost));
+            for (int h = 0; h < n_hyp; ++h)
+                if (stv[h] == 1)
+                    std::memcpy(rec_out + (size_t)h * kHypRec, r32.data() + (size_t)h * kHypRec32, kHypRec32 * sizeof(float));
+        }
+    }
     if (state_out)
-        HIP_TRY(b->ctx, hipMemcpy(state_out, b->d.hyp_okf + (size_t)pair * Hp, (size_t)n_hyp, hipMemcpyDeviceToHost));
+        std::memcpy(state_out, stv.data(), (size_t)n_hyp);
     if (cnt_out)
         HIP_TRY(b->ctx, hipMemcpy(cnt_out, b->d.hyp_cnt + (size_t)pair * Hp, (size_t)n_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (info) {
@@ -580,18 +599,18 @@ int mvs_debug_count_only(mvs_batch *b, const mvs_params *params, int n_active, i
 
 // the matrix-core counting's compare-free indicator on caller-supplied accumulator values (kernels.hip: indicator_probe_kernel)
 int mvs_debug_indicator_probe(mvs_ctx *ctx, const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u,
-                              float *ind_l)
+                              float *ind_l, float *scale)
 {
-    if (!ctx || !a || !tu || !tl || !T || !ind_u || !ind_l || n < 1)
+    if (!ctx || !a || !tu || !tl || !T || !ind_u || !ind_l || !scale || n < 1)
         return MVS_ERR_INVALID_ARG;
     const size_t nb = (size_t)n * sizeof(float);
     const void *in[4] = {a, tu, tl, T};
     const size_t ib[4] = {nb, nb, nb, nb};
-    void *out[2] = {ind_u, ind_l};
-    const size_t ob[2] = {nb, nb};
-    return probe_io(ctx, in, ib, 4, out, ob, 2, [&](void **d) {
+    void *out[3] = {ind_u, ind_l, scale};
+    const size_t ob[3] = {nb, nb, nb};
+    return probe_io(ctx, in, ib, 4, out, ob, 3, [&](void **d) {
         launch_indicator_probe((const float *)d[0], (const float *)d[1], (const float *)d[2], (const float *)d[3], n, (float *)d[4],
-                               (float *)d[5], ctx->stream);
+                               (float *)d[5], (float *)d[6], ctx->stream);
     });
 }
 
@@ -795,6 +814,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.Kinv = Kinv; d.K = K; d.gidx = gidx;
     d.wgbest = nullptr;
     d.hyp_F = nullptr;
+    d.hyp_r32 = nullptr;
     d.hyp_okf = nullptr;
     d.hyp_cnt = nullptr;
     d.bound = nullptr;

@@ -1029,19 +1029,6 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, R
 //                                bounds of the hypotheses that finish raise the pair's bound
 // survivors      flat            approximate records whose upper bound reaches the final bound -> work list (-> exact_list)
 // select         grid P          exact count + residual of everything at or above the bound (ransac_select_kernel)
-// bf16 (round to nearest even, 8 significant bits: unit roundoff 2^-8) of a finite binary32 number, as its 16 bits;
-// x = hi + lo + (<= 2^-16 |x|)
-__device__ __forceinline__ uint32_t bf16_bits(float x)
-{
-    uint32_t u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ void bf16_split(float x, uint32_t &hi, uint32_t &lo)
-{
-    hi = bf16_bits(x);
-    lo = bf16_bits(x - __uint_as_float(hi << 16));   // the difference is exact
-}
 __device__ __forceinline__ PairBox load_box(const BatchDev &b, int pair)
 {
     const double *q = b.box + (size_t)pair * 8;
@@ -1178,8 +1165,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const size_t rec = (size_t)pair * Hp + h;
     double *Fo = b.hyp_F + rec * kHypRec;
     if (mode == 1) {
-        // single-precision record: F~ (9 floats), upper and lower counting thresholds rounded outwards
-        float *fo = reinterpret_cast<float *>(Fo);
+        // single-precision record (48 bytes, its own array): F~ (9 floats), upper and lower counting thresholds rounded outwards
+        float *fo = b.hyp_r32 + rec * kHypRec32;
         float q[12];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -1518,7 +1505,7 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
     if (tid == 0)
         s_bound = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
+    const float *Fp = b.hyp_r32 + (size_t)pair * Hp * kHypRec32;   // 48-byte single-precision records
     const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
     int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
     const float4 *L = reinterpret_cast<const float4 *>(s_f) + lane;   // plane stride 64, pair stride 128, block stride 128 NP
@@ -1547,8 +1534,8 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
             // (one base + constant offsets when the four records are neighbours: the loads coalesce)
-            const CU64 *f = phase == 2 ? (const CU64 *)(uintptr_t)(Fp + (size_t)hq[q] * kHypRec)
-                                       : (const CU64 *)(uintptr_t)(Fp + (size_t)h0 * kHypRec) + q * kHypRec;
+            const CU64 *f = phase == 2 ? (const CU64 *)(uintptr_t)(Fp + (size_t)hq[q] * kHypRec32)
+                                       : (const CU64 *)(uintptr_t)(Fp + (size_t)h0 * kHypRec32) + q * (kHypRec32 / 2);
             R[q].q01 = f[0];
             R[q].q23 = f[1];
             R[q].q45 = f[2];
@@ -1712,9 +1699,14 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
 // ransac_count32_kernel then resumes behind n1 for the hypotheses that can still reach the bound.
 // Wavefront = 2 x 32 hypotheses (the B operands: 16 VGPRs, built once) x all point tiles (A operands: two ds_read_b128 per
 // tile); the accumulator tile has the hypothesis on the lane and 16 points in the registers.
-constexpr int kDenseThreads = 256;   // 4 wavefronts x 64 hypotheses
+constexpr int kDenseThreads = 256;   // dense phase: 4 wavefronts x 64 hypotheses share one staged chunk of points, two workgroups per
+                                     // CU.  A/B on the bench batch (tools/dense_ab.py, profiles/r04_dense_ab.json): 256 x 8 1.27 ms,
+                                     // 384 x 6 1.30, 512 x 4 1.35; the three-stage software pipeline 1.31 / 1.83 / 1.47
+constexpr int kFinishThreads = 256;  // finish: 4 wavefronts x 64 list entries
 constexpr int kDenseChunk = 768;     // points staged per pass (multiple of 32): 48 KB of split monomials
-constexpr int kDenseBatches = 8;     // batches of 256 hypotheses a workgroup takes over the points it has staged
+constexpr int kDenseBatches = 8;     // batches of kDenseThreads hypotheses a workgroup takes over the points it has staged
+constexpr int kDensePipe = 0;        // 0: load -> MFMA -> count per tile; 2: three-stage software pipeline (measured slower)
+constexpr int kDenseWin = 256;       // uint4 words of a wavefront's LDS window: 64 records x 48 B in, 64 operands x 64 B out
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
@@ -1726,29 +1718,7 @@ __device__ __forceinline__ int dense_points(int M, int B0)
 
 // K slot s = 0 .. 31 of the two MFMAs carries term (k, part) = (s % 9, s / 9) for s < 27: part 0 = hi hi, 1 = hi(Phi) lo(F),
 // 2 = lo(Phi) hi(F); slot s sits in MFMA j = s / 16, lane half (s / 8) & 1, element s & 7 -- for BOTH operands, so the sum does
-// not depend on how the instruction numbers its k.
-__device__ __forceinline__ uint32_t dense_slot(const uint32_t (&hi)[9], const uint32_t (&lo)[9], int s, int lo_part)
-{
-    return s >= 27 ? 0u : (s / 9 == lo_part ? lo[s % 9] : hi[s % 9]);
-}
-// the sixteen slots of one lane half as two 128-bit operands (j = 0, 1); lo_part: 2 for the points, 1 for the hypotheses
-__device__ __forceinline__ void dense_operands(const uint32_t (&hi)[9], const uint32_t (&lo)[9], int half, int lo_part,
-                                               uint4 (&op)[2])
-{
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        uint32_t wd[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int s0 = j * 16 + 2 * e, s1 = j * 16 + 8 + 2 * e;   // half 0 / half 1
-            const uint32_t v0 = dense_slot(hi, lo, s0, lo_part) | (dense_slot(hi, lo, s0 + 1, lo_part) << 16);
-            const uint32_t v1 = dense_slot(hi, lo, s1, lo_part) | (dense_slot(hi, lo, s1 + 1, lo_part) << 16);
-            wd[e] = half ? v1 : v0;
-        }
-        op[j] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-    }
-}
-
+// not depend on how the instruction numbers its k (dense_operands_pk below builds the four 128-bit words [j][lane half]).
 // Counting without compares: for a pair of accumulators a, ind = clamp((T2 - a * a) * 2^100) is 1 when a^2 < T2 and 0 when
 // a^2 >= T2 (the product with 2^100 is >= 1 as soon as the difference is one ulp of T2 >= 2^-79), so the per-lane count is a
 // float sum of indicators: v_pk_mul_f32, v_pk_fma_f32 with the clamp bit, v_pk_add_f32 -- three packed instructions per TWO
@@ -1818,21 +1788,94 @@ __device__ __forceinline__ float dense_t2_lower(float tl_rec, float T, bool on, 
 // takes bytes [1024 j + 16 l, + 16)) and transposed through a 5 KB LDS window of the wavefront -- a lane reading "its" record
 // directly touches 64 records x 80 bytes with 16-byte pieces, 44 cache-line requests per instruction (1.83 ms -> see DESIGN).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct DenseRaw {
-    u32x4 p0, p1, p2, p3, p4;
-    int st0, st1;
-};
-constexpr int kDenseRecWin = 64 * kHypRec * 8 / 16;   // uint4 words of one wavefront's window (320)
 
-template <bool STATS>
-__global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_count_mfma_kernel(BatchDev b,
-                                                                                                                    RunParams rp)
+// bf16 pair of two binary32 numbers, round to nearest even (v_cvt_pk_bf16_f32): first argument in the low half
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pk(float lo, float hi)
+{
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float mul_legacy(float a, float b)   // a * b with 0 * anything = 0 (also 0 * inf, 0 * NaN)
+{
+    float d;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// The four 128-bit MFMA operands [j][lane half] of nine binary32 terms x (split as hi = bf16(x), lo = bf16(x - hi)) in the K slot
+// order of dense_slot: lo_part = 1 (a hypothesis: slots 9..17 carry lo) or 2 (a point: slots 18..26 carry lo).  Same bits as
+// dense_operands on bf16_split parts; 28-32 instructions instead of ~110 (the hardware conversion packs two values at a time
+// in the pair order the slots need).
+template <int LO_PART>
+__device__ __forceinline__ void dense_operands_pk(const float (&x)[9], uint4 (&op)[2][2])
+{
+    const uint32_t P01 = bf16_pk(x[0], x[1]), P23 = bf16_pk(x[2], x[3]), P45 = bf16_pk(x[4], x[5]), P67 = bf16_pk(x[6], x[7]);
+    const uint32_t P8z = bf16_pk(x[8], 0.f);
+    const uint32_t pk[5] = {P01, P23, P45, P67, P8z};
+    float L[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t w = pk[k >> 1];
+        const float h = __uint_as_float((k & 1) ? (w & 0xffff0000u) : (w << 16));
+        L[k] = x[k] - h;   // exact
+    }
+    if (LO_PART == 1) {
+        // slots 0..8 hi | 9..17 lo | 18..26 hi | 27..31 zero
+        op[0][0] = make_uint4(P01, P23, P45, P67);
+        op[0][1] = make_uint4(bf16_pk(x[8], L[0]), bf16_pk(L[1], L[2]), bf16_pk(L[3], L[4]), bf16_pk(L[5], L[6]));
+        op[1][0] = make_uint4(bf16_pk(L[7], L[8]), P01, P23, P45);
+        op[1][1] = make_uint4(P67, P8z, 0u, 0u);
+    } else {
+        // slots 0..8 hi | 9..17 hi | 18..26 lo | 27..31 zero
+        op[0][0] = make_uint4(P01, P23, P45, P67);
+        op[0][1] = make_uint4(bf16_pk(x[8], x[0]), bf16_pk(x[1], x[2]), bf16_pk(x[3], x[4]), bf16_pk(x[5], x[6]));
+        op[1][0] = make_uint4(bf16_pk(x[7], x[8]), bf16_pk(L[0], L[1]), bf16_pk(L[2], L[3]), bf16_pk(L[4], L[5]));
+        op[1][1] = make_uint4(bf16_pk(L[6], L[7]), bf16_pk(L[8], 0.f), 0u, 0u);
+    }
+}
+
+// NORMALISED counting (round 4).  Round 3 counted with three packed vector instructions per two accumulators (v_pk_mul,
+// v_pk_fma clamp, v_pk_add: a compare-free indicator against the hypothesis' own threshold) -- 48 packed instructions per tile
+// pair at 6.6 clocks each beside 4 MFMAs, and packed binary32 instructions do not overlap with the matrix pipe on this part
+// (319 clocks per tile pair against 130 for the MFMAs alone, profiles/r03_pk_mfma_microbench.txt): the kernel was a vector
+// kernel with an MFMA inside.  Here the hypothesis' threshold is folded into its B operand: F' = F~ * s with
+// s = 2 / tu' rounded down, so that the accumulator is q = s * a and  |a| < tu'  ==>  |q| < 2  -- and |q| < 2 is ONE BIT of the
+// binary32 pattern: the biased exponent of q is <= 127 exactly when bit 30 is clear (zero, denormals included; infinities
+// and NaNs have it set).  v_alignbit_b32 coll, coll, q, 30 shifts the two top bits (sign, bit 30) of an accumulator into a
+// collection word: ONE full-rate integer instruction per accumulator, sixteen accumulators fill the word, and
+// popcount(coll & 0x55555555) is the number of accumulators NOT below the threshold: 18 plain vector instructions per 32 x 32
+// tile, which issue beside the MFMAs.  Error budget of the scaling: F'_k = fl(F~_k s) adds 2^-24 s T to
+// the split-bf16 term 0.82 * 2^-14 s T: still below 2^-14 s T, and s tu' <= 2 (1 - 2^-22)(1 + 2^-24) < 2.
+__device__ __forceinline__ float dense_tu(float tu_rec, float T) { return (tu_rec + 0x1p-14f * T) * (1.f + 0x1p-22f); }
+// scale of a record's B operand: 2 / tu' rounded down; 0 (every point counted: still an upper bound) for a threshold too
+// small to invert or a record that is not counted at all
+__device__ __forceinline__ float dense_scale(float tu_rec, float T, bool on)
+{
+    const float tup = dense_tu(tu_rec, T);
+    // v_rcp_f32 is good to one ulp: 2 rcp(tu') (1 - 2^-21) <= (2 / tu')(1 + 2^-23)(1 - 2^-21)(1 + 2^-24) < 2 / tu'
+    return (on && tup > 0x1p-60f) ? (2.f * __builtin_amdgcn_rcpf(tup)) * (1.f - 0x1p-21f) : 0.f;
+}
+__device__ __forceinline__ uint32_t dense_collect(const v16f &acc)
+{
+    uint32_t c = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        c = __builtin_amdgcn_alignbit(c, __float_as_uint(acc[r]), 30);   // (c << 2) | (sign, bit 30) of the accumulator
+    return c;
+}
+
+template <bool STATS, int THREADS, int BATCHES, int PIPE>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void ransac_count_mfma_kernel(BatchDev b, RunParams rp)
 {
     // LDS: the split monomials of a chunk of points as MFMA operands, [tile of 32 points][j][lane half][point] x 16 bytes:
-    // the lanes of a wavefront read consecutive 16-byte words (no bank conflicts), two ds_read_b128 per tile
+    // the lanes of a wavefront read consecutive 16-byte words (no bank conflicts), two ds_read_b128 per tile; behind them one
+    // 4 KB window per wavefront: the 64 records of its batch come in as one coalesced 3 KB span, lane l takes record l out,
+    // builds that hypothesis' four operand words ONCE (round 3: every lane built the operands of two hypotheses and kept
+    // half of each) and puts them back as [block][j][lane half][hypothesis] for the lanes that feed them to the MFMAs
     extern __shared__ __attribute__((aligned(16))) double s_cpts[];
-    __shared__ uint32_t s_list[kDenseBatches * kDenseThreads];   // the workgroup's survivors
+    __shared__ uint16_t s_list[BATCHES * THREADS];   // the workgroup's survivors, relative to its first hypothesis
     __shared__ int s_nlist, s_base;
+    static_assert(BATCHES * THREADS <= 65536, "16-bit list entries");
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
     const int M = min(b.M[pair], b.max_kp);
     if (M < 8 || b.mode[pair] != 1)
@@ -1844,8 +1887,8 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     if (blockIdx.x == 0 && tid == 0)
         b.dense_n1[pair] = n1;
     const int H = rp.num_hypotheses;
-    const int G = (H + kDenseThreads - 1) / kDenseThreads;
-    const int g0 = blockIdx.x * kDenseBatches, g1 = min(g0 + kDenseBatches, G);
+    const int G = (H + THREADS - 1) / THREADS;
+    const int g0 = blockIdx.x * BATCHES, g1 = min(g0 + BATCHES, G);
     if (g0 >= G)
         return;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
@@ -1856,103 +1899,176 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     const float Y1 = (float)fmax(dabs(bx.y1lo), dabs(bx.y1hi)) * (1.f + 0x1p-22f);
     const float X2 = (float)fmax(dabs(bx.x2lo), dabs(bx.x2hi)) * (1.f + 0x1p-22f);
     const float Y2 = (float)fmax(dabs(bx.y2lo), dabs(bx.y2hi)) * (1.f + 0x1p-22f);
-    const f32x2 negH = {-0x1p100f, -0x1p100f};
     const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
-    uint4 *s_rec = s_op + (size_t)kDenseChunk * 4 + w * kDenseRecWin;
-    auto fetch = [&](int g, DenseRaw &r) __attribute__((always_inline)) {
-        const int hw = (g * (kDenseThreads / 64) + w) * 64;
+    uint4 *s_win = s_op + (size_t)kDenseChunk * 4 + w * kDenseWin;
+    struct Raw {
+        u32x4 p0, p1, p2;
+        int st;
+    };
+    auto fetch = [&](int g, Raw &r) __attribute__((always_inline)) {
+        const int hw = (g * (THREADS / 64) + w) * 64;
         const size_t rec0 = (size_t)pair * Hp + (hw + 64 <= (int)Hp ? hw : 0);
-        const u32x4 *span = reinterpret_cast<const u32x4 *>(b.hyp_F + rec0 * kHypRec) + lane;
+        const u32x4 *span = reinterpret_cast<const u32x4 *>(b.hyp_r32 + rec0 * kHypRec32) + lane;   // 64 x 48 B = 3 x 1 KB
         r.p0 = span[0];
         r.p1 = span[64];
         r.p2 = span[128];
-        r.p3 = span[192];
-        r.p4 = span[256];
-        const int ha = hw + col, hb = hw + 32 + col;
-        r.st0 = ha < H ? (int)b.hyp_okf[(size_t)pair * Hp + ha] : kPsInvalid;
-        r.st1 = hb < H ? (int)b.hyp_okf[(size_t)pair * Hp + hb] : kPsInvalid;
+        // (an UNCONDITIONAL load of a clamped index: a select on `hl < H` right here needs the loaded byte at once, and the wait
+        // for it is a wait for the three record loads in front of it -- the prefetch then hides nothing: the dense phase spent
+        // a memory round trip per batch that way, rounds 3 and 4a)
+        r.st = (int)b.hyp_okf[(size_t)pair * Hp + min(hw + lane, (int)Hp - 1)];
     };
     int c0 = 0;
     do {   // the points go through LDS in chunks (one for nearly every pair); n1 = 0 still takes one pass (counts of zero)
         const int nc = max(0, min(kDenseChunk, n1 - c0));
         const bool first = c0 == 0, last = c0 + kDenseChunk >= n1;
         __syncthreads();
-        for (int i = tid; i < nc; i += kDenseThreads) {
+        for (int i = tid; i < nc; i += THREADS) {
             const double4 pd = src[c0 + i];
             const float x1 = (float)pd.x, y1 = (float)pd.y, x2 = (float)pd.z, y2 = (float)pd.w;
             const float ph[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.f};
-            uint32_t mh[9], ml[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                bf16_split(ph[k], mh[k], ml[k]);
-            uint4 o0[2], o1[2];
-            dense_operands(mh, ml, 0, 2, o0);
-            dense_operands(mh, ml, 1, 2, o1);
+            uint4 o[2][2];
+            dense_operands_pk<2>(ph, o);
             uint4 *q = s_op + (size_t)(i >> 5) * 128 + (i & 31);
-            q[0] = o0[0];     // j = 0, half 0
-            q[32] = o1[0];    // j = 0, half 1
-            q[64] = o0[1];    // j = 1, half 0
-            q[96] = o1[1];    // j = 1, half 1
+            q[0] = o[0][0];     // j = 0, half 0
+            q[32] = o[0][1];    // j = 0, half 1
+            q[64] = o[1][0];    // j = 1, half 0
+            q[96] = o[1][1];    // j = 1, half 1
         }
-        DenseRaw raw;
+        Raw raw;
         fetch(g0, raw);
         __syncthreads();
         for (int g = g0; g < g1; ++g) {
-            const int hw = (g * (kDenseThreads / 64) + w) * 64;   // first hypothesis of the wavefront (two blocks of 32)
-            int h[2], st[2];
-            v8bf Bop[2][2];
-            f32x2 t2H[2];
-            u32x4 *wr = reinterpret_cast<u32x4 *>(s_rec) + lane;
+            const int hw = (g * (THREADS / 64) + w) * 64;   // first hypothesis of the wavefront (two blocks of 32)
+            // records in: the coalesced span, then lane l reads record l
+            u32x4 *wr = reinterpret_cast<u32x4 *>(s_win) + lane;
             wr[0] = raw.p0;
             wr[64] = raw.p1;
             wr[128] = raw.p2;
-            wr[192] = raw.p3;
-            wr[256] = raw.p4;
+            const int st_l = hw + lane < H ? raw.st : kPsInvalid;
+            const float4 *rq = reinterpret_cast<const float4 *>(s_win + lane * 3);
+            const float4 q0 = rq[0], q1 = rq[1], q2 = rq[2];
+            if (g + 1 < g1)
+                fetch(g + 1, raw);   // in flight during this batch's build and tiles
+            {
+                const float fr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+                const bool on = st_l == kPsApprox;
+                // F' = F~ * s,  s = 2 / tu' rounded down,  tu' = tu + 2^-14 T,  T = [X2 Y2 1] |F~| [X1 Y1 1]^T (rounded up)
+                float sc = dense_scale(q2.y, dense_T(fr, X1, Y1, X2, Y2), on);
+                float big = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    big = fmaxf(big, fabsf(fr[k]));
+                // an operand that is not finite would poison the accumulators: F' = 0 counts every point -- still an upper
+                // bound (the comparison is false for a NaN, and v_mul_legacy gives 0 * x = 0 for every x)
+                sc = (big * sc < 0x1p100f) ? sc : 0.f;
+                float Fs[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    Fs[k] = mul_legacy(fr[k], sc);
+                uint4 o[2][2];
+                dense_operands_pk<1>(Fs, o);
+                // operands out: [block][j][lane half][hypothesis of the block]
+                uint4 *wo = s_win + (lane >> 5) * 128 + (lane & 31);
+                wo[0] = o[0][0];
+                wo[32] = o[0][1];
+                wo[64] = o[1][0];
+                wo[96] = o[1][1];
+            }
+            int h[2], st[2];
+            v8bf Bop[2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 h[c] = hw + 32 * c + col;    // this lane's hypothesis of block c (both lane halves)
-                st[c] = c ? raw.st1 : raw.st0;
-                // the record's first twelve floats: F~[9], tu, tl, -
-                const float4 *rq = reinterpret_cast<const float4 *>(s_rec + (32 * c + col) * 5);
-                const float4 q0 = rq[0], q1 = rq[1], q2 = rq[2];
-                const float fr[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
-                const bool on = st[c] == kPsApprox;
-                float Ff[9];
-                uint32_t fh[9], fl[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    Ff[k] = on ? fr[k] : 0.f;
-                    bf16_split(Ff[k], fh[k], fl[k]);
-                }
-                uint4 op[2];
-                dense_operands(fh, fl, half, 1, op);
-                Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
-                Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
-                // tu' = tu + 2^-14 T,  T = [X2 Y2 1] |F~| [X1 Y1 1]^T (every rounding upwards)
-                const float t2h = dense_t2_upper(fr[9], dense_T(Ff, X1, Y1, X2, Y2), on);
-                t2H[c] = f32x2{t2h, t2h};
+                st[c] = __shfl(st_l, 32 * c + col);
+                const uint4 *ro = s_win + c * 128 + half * 32 + col;
+                Bop[c][0] = __builtin_bit_cast(v8bf, ro[0]);
+                Bop[c][1] = __builtin_bit_cast(v8bf, ro[64]);
             }
-            if (g + 1 < g1)
-                fetch(g + 1, raw);   // in flight during this batch's tiles
             if (hw >= H)
                 continue;
-            f32x2 cntf[2] = {{0.f, 0.f}, {0.f, 0.f}};
-            for (int p0 = 0; p0 < nc; p0 += 32) {
-                const uint4 *q = s_op + (size_t)(p0 >> 5) * 128 + half * 32 + col;
-                const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
-                // two independent accumulation chains, interleaved
-                v16f a0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
-                // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
-                dense_count(a0, negH, t2H[0], cntf[0]);
-                dense_count(a1, negH, t2H[1], cntf[1]);
+            uint32_t nn[2] = {0u, 0u};   // accumulators NOT below the threshold
+            // Software pipeline over the point tiles, two accumulator sets: the four MFMAs of tile t + 1 are issued BEFORE the
+            // 36 vector instructions that count tile t, one MFMA per nine of them (sched_group_barrier), so that one wavefront
+            // keeps the matrix pipe and the vector pipe busy at the same time (without it a wavefront waited for its LDS reads,
+            // then for its MFMAs, then counted: 425 clocks per tile pair and SIMD against 192 of issue)
+            const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const uint4 *qt = s_op + half * 32 + col;
+            const int nt = nc >> 5;
+            if (PIPE == 0) {
+                for (int t = 0; t < nt; ++t) {
+                    const uint4 *q = qt + (size_t)t * 128;
+                    const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
+                    v16f a0, a1;
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], zero, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], zero, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
+                    nn[0] += (uint32_t)__builtin_popcount(dense_collect(a0) & 0x55555555u);
+                    nn[1] += (uint32_t)__builtin_popcount(dense_collect(a1) & 0x55555555u);
+                }
+            } else {
+                // three stages: the A operands of tile t + 2 are requested from LDS, the MFMAs of tile t + 1 issue on operands that
+                // arrived a stage ago, the accumulators of tile t are counted
+                auto load_a = [&](int t, v8bf &A0, v8bf &A1) __attribute__((always_inline)) {
+                    const uint4 *q = qt + (size_t)t * 128;
+                    A0 = __builtin_bit_cast(v8bf, q[0]);
+                    A1 = __builtin_bit_cast(v8bf, q[64]);
+                };
+                auto issue = [&](const v8bf &A0, const v8bf &A1, v16f &a0, v16f &a1) __attribute__((always_inline)) {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], zero, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], zero, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
+                };
+                auto count = [&](const v16f &a0, const v16f &a1) __attribute__((always_inline)) {
+                    // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
+                    nn[0] += (uint32_t)__builtin_popcount(dense_collect(a0) & 0x55555555u);
+                    nn[1] += (uint32_t)__builtin_popcount(dense_collect(a1) & 0x55555555u);
+                };
+                auto interleave = [&]() __attribute__((always_inline)) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the two LDS reads of the tile after next
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // nine vector instructions
+                    }
+                };
+                v16f x0, x1, y0, y1;
+                v8bf Ae0, Ae1, Ao0, Ao1;
+                if (nt > 0)
+                    load_a(0, Ae0, Ae1);
+                if (nt > 1)
+                    load_a(1, Ao0, Ao1);
+                if (nt > 0)
+                    issue(Ae0, Ae1, x0, x1);
+                int t = 0;
+                while (t < nt) {
+                    if (t + 2 < nt)
+                        load_a(t + 2, Ae0, Ae1);
+                    if (t + 1 < nt) {
+                        issue(Ao0, Ao1, y0, y1);
+                        count(x0, x1);
+                        interleave();
+                    } else {
+                        count(x0, x1);
+                    }
+                    if (++t >= nt)
+                        break;
+                    if (t + 2 < nt)
+                        load_a(t + 2, Ao0, Ao1);
+                    if (t + 1 < nt) {
+                        issue(Ae0, Ae1, x0, x1);
+                        count(y0, y1);
+                        interleave();
+                    } else {
+                        count(y0, y1);
+                    }
+                    ++t;
+                }
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                int cnt = (int)(cntf[c].x + cntf[c].y);
+                int cnt = (nc >> 1) - (int)nn[c];   // this lane half saw 16 points of every tile
                 cnt += __shfl_xor(cnt, 32);   // the two lane halves hold different points of the same hypothesis
                 const size_t rec = (size_t)pair * Hp + h[c];
                 const bool mine = half == 0 && h[c] < H;
@@ -1971,7 +2087,7 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
                         base = atomicAdd(&s_nlist, __popcll(mm));
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (go)
-                        s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)h[c];
+                        s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)(h[c] - g0 * THREADS);
                 }
                 if (STATS && b.stats) {
                     const unsigned long long ma = __ballot(st[c] == kPsApprox && mine);
@@ -1989,8 +2105,8 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
             s_base = atomicAdd(&b.ccount[pair], nl);
         __syncthreads();
         uint32_t *dst = b.clist + (size_t)pair * Hp + s_base;
-        for (int i = tid; i < nl; i += kDenseThreads)
-            dst[i] = s_list[i];
+        for (int i = tid; i < nl; i += THREADS)
+            dst[i] = (uint32_t)(g0 * THREADS) + s_list[i];
     }
 }
 
@@ -2095,7 +2211,7 @@ __global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
 // ransac_survivors_kernel compares U with the final bound as before.  The points past M in the last tile are staged as zero
 // monomials: their residual is exactly 0, so each is counted once by every positive threshold and subtracted again.
 template <bool STATS>
-__global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_mfma_kernel(BatchDev b,
+__global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_mfma_kernel(BatchDev b,
                                                                                                                      RunParams rp,
                                                                                                                      int batch0)
 {
@@ -2106,7 +2222,7 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     if (M < 8 || b.mode[pair] != 1)
         return;
     const int n_list = b.ccount[pair];
-    const int e0 = (batch0 + blockIdx.y) * kDenseThreads;   // first list entry of the workgroup
+    const int e0 = (batch0 + blockIdx.y) * kFinishThreads;   // first list entry of the workgroup
     if (e0 >= n_list)
         return;
     if (tid == 0)
@@ -2143,20 +2259,17 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     f32x2 tuH[2], tlH[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_F + ((size_t)pair * Hp + h[c]) * kHypRec);
+        const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_r32 + ((size_t)pair * Hp + h[c]) * kHypRec32);
         const float4 q0 = fr4[0], q1 = fr4[1], q2 = fr4[2];
         const float fr[11] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
         float Ff[9];
-        uint32_t fh[9], fl[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < 9; ++k)
             Ff[k] = on[c] ? fr[k] : 0.f;
-            bf16_split(Ff[k], fh[k], fl[k]);
-        }
-        uint4 op[2];
-        dense_operands(fh, fl, half, 1, op);
-        Bop[c][0] = __builtin_bit_cast(v8bf, op[0]);
-        Bop[c][1] = __builtin_bit_cast(v8bf, op[1]);
+        uint4 op[2][2];
+        dense_operands_pk<1>(Ff, op);
+        Bop[c][0] = __builtin_bit_cast(v8bf, half ? op[0][1] : op[0][0]);
+        Bop[c][1] = __builtin_bit_cast(v8bf, half ? op[1][1] : op[1][0]);
         const float T = dense_T(Ff, X1, Y1, X2, Y2);
         const float tuh = dense_t2_upper(fr[9], T, on[c]);
         const float tlh = dense_t2_lower(fr[10], T, on[c], lpos[c]);
@@ -2169,26 +2282,21 @@ __global__ __launch_bounds__(kDenseThreads) __attribute__((amdgpu_waves_per_eu(4
     for (int c0 = 0; c0 < Mr; c0 += kDenseChunk) {
         const int nc = min(kDenseChunk, Mr - c0);
         __syncthreads();
-        for (int i = tid; i < nc; i += kDenseThreads) {
-            uint4 o0[2], o1[2];
+        for (int i = tid; i < nc; i += kFinishThreads) {
+            uint4 o[2][2];
             if (c0 + i < M) {
                 const double4 pd = src[c0 + i];
                 const float x1 = (float)pd.x, y1 = (float)pd.y, x2 = (float)pd.z, y2 = (float)pd.w;
                 const float ph[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.f};
-                uint32_t mh[9], ml[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    bf16_split(ph[k], mh[k], ml[k]);
-                dense_operands(mh, ml, 0, 2, o0);
-                dense_operands(mh, ml, 1, 2, o1);
+                dense_operands_pk<2>(ph, o);
             } else {
-                o0[0] = o0[1] = o1[0] = o1[1] = make_uint4(0u, 0u, 0u, 0u);
+                o[0][0] = o[0][1] = o[1][0] = o[1][1] = make_uint4(0u, 0u, 0u, 0u);
             }
             uint4 *q = s_op + (size_t)(i >> 5) * 128 + (i & 31);
-            q[0] = o0[0];
-            q[32] = o1[0];
-            q[64] = o0[1];
-            q[96] = o1[1];
+            q[0] = o[0][0];
+            q[32] = o[0][1];
+            q[64] = o[1][0];
+            q[96] = o[1][1];
         }
         __syncthreads();
         if (!wave_live || wave_dead)
@@ -3094,14 +3202,14 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
     case kKRansacCountFinish:
         d.name = "ransac_finish_mfma_kernel<false>";
         d.fn = reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>);
-        d.threads = kDenseThreads;
+        d.threads = kFinishThreads;
         d.dynamic_lds = (size_t)kDenseChunk * 64;
         break;
     case kKRansacCountMfma:
-        d.name = "ransac_count_mfma_kernel<false>";
-        d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>);
+        d.name = "ransac_count_mfma_kernel<false, 256, 8, 0>";
+        d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>);
         d.threads = kDenseThreads;
-        d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * 64 * kHypRec * 8;
+        d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacSurvivors:
         d.name = "ransac_survivors_kernel";
@@ -3166,8 +3274,16 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<true>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches, kDensePipe>),
+#ifdef MVS_DEBUG_HOOKS
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 0>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 0>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 2>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 2>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 2>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0>),
+#endif
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
@@ -3320,7 +3436,6 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
 #endif
     {
         const int wg_pilot = std::max(1, std::min(wg, (kPilotHyp / kCnt32Slots) / (kCnt32Threads / 64)));
-        const size_t lds_dense = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * 64 * kHypRec * 8;
         if (lt) lt->mark(kKRansacCountPilot);
         if (stats)
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>), dim3(wg_pilot, n_active),
@@ -3329,14 +3444,27 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>), dim3(wg_pilot, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
         if (lt) lt->mark(kKRansacCountMfma);
-        if (stats)
-            hipLaunchKernelGGL(ransac_count_mfma_kernel<true>, dim3(((H + 255) / 256 + kDenseBatches - 1) / kDenseBatches, n_active), dim3(kDenseThreads), lds_dense,
-                               stream, b, rp);
+        auto dense = [&](auto kern, int threads, int batches) {
+            const size_t lds = (size_t)kDenseChunk * 64 + (size_t)(threads / 64) * kDenseWin * 16;
+            const dim3 grid(((H + threads - 1) / threads + batches - 1) / batches, n_active);
+            hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, b, rp);
+        };
+#ifdef MVS_DEBUG_HOOKS
+        // A/B of the dense phase's shape: mvs_debug_set_count_dense(10 + k)
+        if (g_count_dense == 10) dense(ransac_count_mfma_kernel<false, 256, 8, 0>, 256, 8);
+        else if (g_count_dense == 11) dense(ransac_count_mfma_kernel<false, 384, 6, 0>, 384, 6);
+        else if (g_count_dense == 12) dense(ransac_count_mfma_kernel<false, 256, 8, 2>, 256, 8);
+        else if (g_count_dense == 13) dense(ransac_count_mfma_kernel<false, 384, 6, 2>, 384, 6);
+        else if (g_count_dense == 14) dense(ransac_count_mfma_kernel<false, 512, 4, 2>, 512, 4);
+        else if (g_count_dense == 15) dense(ransac_count_mfma_kernel<false, 512, 4, 0>, 512, 4);
         else
-            hipLaunchKernelGGL(ransac_count_mfma_kernel<false>, dim3(((H + 255) / 256 + kDenseBatches - 1) / kDenseBatches, n_active), dim3(kDenseThreads), lds_dense,
-                               stream, b, rp);
+#endif
+        if (stats)
+            dense(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches, kDensePipe>, kDenseThreads, kDenseBatches);
+        else
+            dense(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>, kDenseThreads, kDenseBatches);
         if (lt) lt->mark(kKRansacCountFinish);
-        const dim3 fin_grid(n_active, (H + kDenseThreads - 1) / kDenseThreads);   // workgroups past the list's end leave at once
+        const dim3 fin_grid(n_active, (H + kFinishThreads - 1) / kFinishThreads);   // workgroups past the list's end leave at once
         if (g_count_dense != 2)
             hipLaunchKernelGGL(ransac_list_sort_kernel, dim3(n_active), dim3(256), 0, stream, b);
 #ifdef MVS_DEBUG_HOOKS
@@ -3354,10 +3482,10 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
                 if (g.y == 0)
                     break;
                 if (stats)
-                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<true>, g, dim3(kDenseThreads), (size_t)kDenseChunk * 64, stream,
+                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<true>, g, dim3(kFinishThreads), (size_t)kDenseChunk * 64, stream,
                                        b, rp, part);
                 else
-                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, g, dim3(kDenseThreads), (size_t)kDenseChunk * 64, stream,
+                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, g, dim3(kFinishThreads), (size_t)kDenseChunk * 64, stream,
                                        b, rp, part);
             }
         }
@@ -3637,7 +3765,7 @@ __global__ __launch_bounds__(256, 1) void audit_kernel(BatchDev b, RunParams rp,
                 const double *Fo = b.hyp_F + rec * kHypRec;
                 int U = 0, L = 0;
                 if (mode == 1) {
-                    const float *fo = reinterpret_cast<const float *>(Fo);
+                    const float *fo = b.hyp_r32 + rec * kHypRec32;
                     float Ft[9];
 #pragma unroll
                     for (int k = 0; k < 9; ++k)
@@ -3790,7 +3918,7 @@ void launch_count_only(const BatchDev &b, const RunParams &rp, int n_active, int
 // the compare-free indicator of the matrix-core counting on caller-supplied accumulator values: ind_u[i] / ind_l[i] = what
 // dense_count adds for accumulator a[i] under a record with thresholds (tu[i], tl[i]) and box term T[i]
 __global__ __launch_bounds__(64) void indicator_probe_kernel(const float *a, const float *tu, const float *tl, const float *T,
-                                                             int n, float *ind_u, float *ind_l)
+                                                             int n, float *ind_u, float *ind_l, float *scale)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n)
@@ -3803,11 +3931,12 @@ __global__ __launch_bounds__(64) void indicator_probe_kernel(const float *a, con
     const f32x2 u = pk_ind(sq, negH, f32x2{t2u, t2u}), l = pk_ind(sq, negH, f32x2{t2l, t2l});
     ind_u[i] = u.x == u.y ? u.x : -1.f;
     ind_l[i] = l.x == l.y ? l.x : -1.f;
+    scale[i] = dense_scale(tu[i], T[i], true);   // the dense phase's B-operand scale: s tu' must stay below 2
 }
 void launch_indicator_probe(const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u, float *ind_l,
-                            hipStream_t stream)
+                            float *scale, hipStream_t stream)
 {
-    hipLaunchKernelGGL(indicator_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, a, tu, tl, T, n, ind_u, ind_l);
+    hipLaunchKernelGGL(indicator_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, a, tu, tl, T, n, ind_u, ind_l, scale);
 }
 // de-normalisation + fused residual exactly as the two paths run them: in[i] = Fn (9, row-major), s1, s2, m1x, m1y, m2x, m2y,
 // x1, y1, x2, y2; out[i] = {residual under prescreen_denormalise(Fn), residual under denormalise_exact(Fn)}

@@ -11,6 +11,7 @@ constexpr int kMaxKp = 4096;          // capacity limit of one image (LDS lists 
 constexpr int kHypPerBlock = 256;     // hypotheses per RANSAC workgroup (one per lane, 4 waves)
 constexpr int kMaxDescWords = 16;     // descriptor <= 64 bytes
 constexpr int kHypRec = 10;           // doubles per hypothesis record: F[9], counting threshold (thr + band)
+constexpr int kHypRec32 = 12;         // floats per single-precision record (mode 1): F~[9], tu, tl, spare
 
 // Best hypothesis of one RANSAC workgroup.  count < 0: no valid hypothesis in the group.
 struct WgBest {
@@ -61,6 +62,9 @@ struct BatchDev {
     WgBest *wgbest;      // [P][max_groups]
     double *hyp_F;       // [P][max_groups * 256][kHypRec]: F (9) of every hypothesis + its counting threshold thr + band
                          // (solve / pre-screen -> scoring hand-over), may be null
+    float *hyp_r32;      // [P][max_groups * 256][kHypRec32]: the SINGLE-PRECISION pre-screen records of the pairs in mode 1 (48
+                         // bytes: F~ as 9 floats, upper and lower counting threshold, one spare): written by the pre-screen, read
+                         // by the pilot / dense / finish counting kernels.  Exact F (survivors, uncertified) stays in hyp_F
     uint8_t *hyp_okf;    // [P][max_groups * 256] state of the record: 0 rejected sample, 1 approximate F (pre-screen), 2 waits
                          // for the exact solve, 3 exact F
     int32_t *hyp_cnt;    // [P][max_groups * 256] full (upper-bound) inlier count of a hypothesis that can still win, -1 otherwise
@@ -337,7 +341,7 @@ void launch_pairstep_check(const double *rows, int n, unsigned long long *out, h
 void launch_count_only(const BatchDev &b, const RunParams &rp, int n_active, int pmode, int dense, const int32_t *keep,
                        hipStream_t stream);
 void launch_indicator_probe(const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u, float *ind_l,
-                            hipStream_t stream);
+                            float *scale, hipStream_t stream);
 void launch_rounding_probe(const double *in, int n, double *out, hipStream_t stream);
 hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, int phase, unsigned long long *out, int32_t *maxc,
                         hipStream_t stream);

@@ -372,8 +372,13 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
         }
     }
     __syncthreads();
-    if (!s_ok)
+    if (!s_ok) {
+        // rows of the inlier list behind n_inliers are cleared on every run (a download of the whole capacity is deterministic)
+        int32_t *z = p.inliers + (size_t)q * p.stride;
+        for (int i = tid; i < p.stride; i += 256)
+            z[i] = 0;
         return;
+    }
     double R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i)
@@ -413,6 +418,8 @@ __global__ __launch_bounds__(256) void pnp_finalize_kernel(PnpDev p)
         basepos += tot;
         __syncthreads();
     }
+    for (int i = basepos + tid; i < p.stride; i += 256)
+        inl[i] = 0;
     if (tid == 0) {
         out->n_inliers = basepos;
         // pose = SE3(SO3(R), t).inverse() (pnp-solve.cpp:99-101; lie-group.hpp:31-36,212-216)

@@ -110,11 +110,16 @@ def check_indicator(ctx, lib, rng):
                 a.append(v); tu.append(t); tl.append(lrec); T.append(TT); kind.append((tag, float(tup), float(tlp)))
     a, tu, tl, T = (np.ascontiguousarray(v, dtype=np.float32) for v in (a, tu, tl, T))
     n = len(a)
-    iu, il = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    iu, il, sc = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
     st = lib.mvs_debug_indicator_probe(ctx._h, a.ctypes.data_as(PF), tu.ctypes.data_as(PF), tl.ctypes.data_as(PF),
-                                       T.ctypes.data_as(PF), C.c_int(n), iu.ctypes.data_as(PF), il.ctypes.data_as(PF))
+                                       T.ctypes.data_as(PF), C.c_int(n), iu.ctypes.data_as(PF), il.ctypes.data_as(PF),
+                                       sc.ctypes.data_as(PF))
     assert st == 0, st
     bad_u = bad_l = loose_u = loose_l = shape = 0
+    # the dense phase's normalisation: q = s a is tested by its exponent, |q| < 2.  Sound iff s tu' < 2 in exact arithmetic
+    # (every |a| < tu' then has |s a| < 2); tight iff s tu' is within a few ulps of 2
+    bad_scale = sum(1 for i in range(n) if not Fr(float(sc[i])) * Fr(kind[i][1]) < 2)
+    loose_scale = sum(1 for i in range(n) if kind[i][1] > 2.0 ** -50 and Fr(float(sc[i])) * Fr(kind[i][1]) < Fr(2) * (1 - Fr(1, 2 ** 20)))
     for i in range(n):
         _, tup, tlp = kind[i]
         av = abs(float(a[i]))
@@ -128,7 +133,9 @@ def check_indicator(ctx, lib, rng):
         if tlp > 0 and av < tlp * (1 - 2.0 ** -17) and il[i] != 1.0:
             loose_l += 1
     return dict(values=n, upper_missed=bad_u, lower_overcounted=bad_l, not_an_indicator=shape, upper_loose=loose_u,
-                lower_loose=loose_l, ok=bool(bad_u == 0 and bad_l == 0 and shape == 0 and loose_u == 0 and loose_l == 0))
+                lower_loose=loose_l, scale_unsound=bad_scale, scale_loose=loose_scale,
+                ok=bool(bad_u == 0 and bad_l == 0 and shape == 0 and loose_u == 0 and loose_l == 0 and bad_scale == 0 and
+                        loose_scale == 0))
 
 
 # ---- C: matches on the band edges through the counting kernels ---------------------------------------------------------------
