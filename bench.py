@@ -211,6 +211,14 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
             e["evals_executed"] = int(ev)
             e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
             peak, bound = FP32_PEAK_TFLOPS, "valu_fp32"
+        elif name.startswith("ransac_finish_upper_kernel"):
+            # the rest of the list: upper counts only, behind the dense phase's points (the dense phase's loop over list entries)
+            ev = stats.get("score_evals_executed_mfma_rest", 0)
+            fl_alg = fl_exec = ev * PER_EVAL_MFMA
+            e["evals_executed"] = int(ev)
+            e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
+            e["evals_per_ns"] = round(ev / max(e["ms"] * 1e6, 1e-9), 2)
+            peak, bound = BF16_MFMA_PEAK_TFLOPS, "mfma_bf16"
         elif name.startswith("ransac_finish_mfma_kernel"):
             # the same tile product for the few per cent of the hypotheses the dense phase leaves: every point against the lower
             # threshold, the points behind the dense phase against the upper one as well
@@ -232,7 +240,8 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
             peak, bound = BF16_MFMA_PEAK_TFLOPS, "mfma_bf16"
         elif name.startswith("ransac_count_kernel") or name.startswith("ransac_count2_kernel"):
             ev64 = stats["score_evals_executed"] - stats["score_evals_executed_f32"] - \
-                stats.get("score_evals_executed_mfma", 0) - stats.get("score_evals_executed_mfma_finish", 0)
+                stats.get("score_evals_executed_mfma", 0) - stats.get("score_evals_executed_mfma_finish", 0) - \
+                stats.get("score_evals_executed_mfma_rest", 0)
             fl_alg = stats["score_evals"] * PER_EVAL
             fl_exec = ev64 * PER_EVAL
             e["evals_executed_frac"] = round(ev64 / max(stats["score_evals"], 1), 4)
@@ -286,6 +295,7 @@ def roofline_object(table, stats, traffic, traffic_src):
                  "evals_executed_f32": int(stats["score_evals_executed_f32"]),
                  "evals_executed_mfma_dense": int(stats.get("score_evals_executed_mfma", 0)),
                  "evals_executed_mfma_finish": int(stats.get("score_evals_executed_mfma_finish", 0)),
+                 "evals_executed_mfma_finish_rest": int(stats.get("score_evals_executed_mfma_rest", 0)),
                  "max_sweeps9": int(stats.get("max_sweeps9", 0)),
                  "dense_points_over_matches": round(stats["dense_points"] / stats["matches_mode1"], 3)
                  if stats.get("matches_mode1") else None},
@@ -641,7 +651,7 @@ def main():
         # rocprofv3 --pmc pass of this same workload committed under profiles/ ((2*FETCH_SIZE + WRITE_SIZE) KB per
         # MI355X_MICROARCH.md, its own pass); only quoted for the default workload, null otherwise
         traffic, traffic_src = None, None
-        for tname in ("r03_ransac_hbm_traffic.json", "r02_ransac_hbm_traffic.json"):
+        for tname in ("r04_ransac_hbm_traffic.json", "r03_ransac_hbm_traffic.json", "r02_ransac_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000 and args.max_error_sq == 1e-2:
                 traffic = int(json.load(open(tpath))["hbm_bytes_per_pair"] * n_local)

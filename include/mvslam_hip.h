@@ -274,6 +274,8 @@ typedef struct mvs_work_stats {
     int64_t dense_points;         /* sum over the pairs in mode 1 of n1, the points the dense matrix-core phase covered */
     int64_t matches_mode1;        /* sum of M over the same pairs (dense_points / matches_mode1 = the share of a pair's matches
                                      every hypothesis is counted on before anything can be dropped) */
+    int64_t score_evals_executed_mfma_rest; /* evaluations of the finish's second launch (upper counts of the rest of the list);
+                                     included in score_evals_executed, not in score_evals_executed_mfma_finish */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 

@@ -249,6 +249,7 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if (!b->d.mode && (st = dev_alloc(b, &b->d.mode, P)) != MVS_OK) return st;
     if (!b->d.dense_n1 && (st = dev_alloc(b, &b->d.dense_n1, P)) != MVS_OK) return st;
     if (!b->d.ccount && (st = dev_alloc(b, &b->d.ccount, P)) != MVS_OK) return st;
+    if (!b->d.pcount && (st = dev_alloc(b, &b->d.pcount, P)) != MVS_OK) return st;
     if (!b->d.m0list && (st = dev_alloc(b, &b->d.m0list, P + 1)) != MVS_OK) return st;
     if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 2)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
@@ -400,6 +401,12 @@ int mvs_debug_mfma_probe(mvs_ctx *ctx, const uint16_t *a, const uint16_t *b, flo
     (void)hipFree(da);
     (void)hipFree(db);
     (void)hipFree(dout);
+    return MVS_OK;
+}
+
+int mvs_debug_set_split_min_pairs(int v)
+{
+    set_split_min_pairs(v);
     return MVS_OK;
 }
 
@@ -823,6 +830,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.dense_n1 = nullptr;
     d.clist = nullptr;
     d.ccount = nullptr;
+    d.pcount = nullptr;
     d.m0list = nullptr;
     d.xlist = nullptr;
     d.xcount = nullptr;
@@ -1280,7 +1288,8 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     std::memset(out, 0, sizeof(*out));
     out->rotations9 = (int64_t)h[0];
     out->pairs9 = (int64_t)h[1];
-    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4] + h[5]);   // double-, single-precision and matrix-core counting
+    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4] + h[5] + h[7]);   // double-, single-precision and matrix-core counting
+    out->score_evals_executed_mfma_rest = (int64_t)h[7];
     out->score_evals_executed_f32 = (int64_t)h[3];
     out->score_evals_executed_mfma = (int64_t)h[4];
     out->score_evals_executed_mfma_finish = (int64_t)h[5];

@@ -1062,6 +1062,7 @@ __global__ __launch_bounds__(256) void pair_prepare_kernel(BatchDev b, RunParams
     if (tid == 0) {
         b.bound[pair] = 0;
         b.ccount[pair] = 0;
+        b.pcount[pair] = 0;
     }
     if (M < 8) {
         if (tid == 0)
@@ -2374,61 +2375,250 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
         __hip_atomic_fetch_max(b.bound + pair, s_lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The REST of the finish (round 4).  After the first batch of every pair (ransac_finish_mfma_kernel over the 256 largest partial
+// counts, upper AND lower bounds) the pair's bound is final for all practical purposes: the other listed hypotheses only need
+// their UPPER count completed over the points behind the dense phase, [n1, M) -- a lower bound that does not exceed the
+// bound changes nothing, and one that would exceed it belongs to a hypothesis the first batch did not hold: then the bound
+// simply stays lower and more hypotheses than necessary survive (sound; the sort puts the winner into the first batch).  So
+// this launch is the dense phase's loop again -- thresholds folded into the B operand, one v_alignbit per accumulator --
+// over list entries instead of consecutive hypotheses, with a wavefront-level exit test every 256 points.  Round 3 ran
+// ransac_finish_mfma_kernel here: every point against both thresholds with five packed instructions per two accumulators,
+// in 100 k workgroups of which all but ~4 k left at once.  Grid (P, kFinUpperWg): a workgroup strides over the pair's batches.
+// Rows past M in the last tile are staged as NaN monomials: their accumulators are NaN, bit 30 set, never counted.
+constexpr int kFinUpperWg = 8;
+template <bool STATS>
+__global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_upper_kernel(BatchDev b,
+                                                                                                                       RunParams rp)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, half = lane >> 5;
+    const int M = min(b.M[pair], b.max_kp);
+    if (M < 8 || b.mode[pair] != 1)
+        return;
+    const int n_list = b.ccount[pair];
+    const int n_batches = (n_list + kFinishThreads - 1) / kFinishThreads;
+    if (1 + (int)blockIdx.y >= n_batches)
+        return;   // batch 0 belongs to ransac_finish_mfma_kernel
+    const int n1 = b.dense_n1[pair];
+    const int Mr = (M + 31) & ~31;
+    if (n1 >= Mr)
+        return;   // the dense phase saw every point: the counts are complete
+    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
+    const uint32_t *clist = b.clist + ((size_t)b.n_pairs + pair) * Hp;   // sorted by ransac_list_sort_kernel
+    const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint4 *s_op = reinterpret_cast<uint4 *>(s_cpts);
+    uint4 *s_win = s_op + (size_t)kDenseChunk * 4 + w * kDenseWin;
+    const PairBox bx = load_box(b, pair);
+    const float X1 = (float)fmax(dabs(bx.x1lo), dabs(bx.x1hi)) * (1.f + 0x1p-22f);
+    const float Y1 = (float)fmax(dabs(bx.y1lo), dabs(bx.y1hi)) * (1.f + 0x1p-22f);
+    const float X2 = (float)fmax(dabs(bx.x2lo), dabs(bx.x2hi)) * (1.f + 0x1p-22f);
+    const float Y2 = (float)fmax(dabs(bx.y2lo), dabs(bx.y2hi)) * (1.f + 0x1p-22f);
+    const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
+    const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long evals = 0;
+    for (int c0 = n1; c0 < Mr; c0 += kDenseChunk) {
+        const int nc = min(kDenseChunk, Mr - c0);
+        __syncthreads();
+        for (int i = tid; i < nc; i += kFinishThreads) {
+            uint4 o[2][2];
+            if (c0 + i < M) {
+                const double4 pd = src[c0 + i];
+                const float x1 = (float)pd.x, y1 = (float)pd.y, x2 = (float)pd.z, y2 = (float)pd.w;
+                const float ph[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.f};
+                dense_operands_pk<2>(ph, o);
+            } else {
+                const float qn = __builtin_nanf("");
+                const float ph[9] = {qn, qn, qn, qn, qn, qn, qn, qn, qn};
+                dense_operands_pk<2>(ph, o);
+            }
+            uint4 *q = s_op + (size_t)(i >> 5) * 128 + (i & 31);
+            q[0] = o[0][0];
+            q[32] = o[0][1];
+            q[64] = o[1][0];
+            q[96] = o[1][1];
+        }
+        __syncthreads();
+        const int left0 = M - c0;   // points of the pair not yet seen when this chunk starts (>= 1)
+        for (int batch = 1 + blockIdx.y; batch < n_batches; batch += gridDim.y) {
+            const int e = batch * kFinishThreads + w * 64 + lane;   // this lane's list entry
+            const bool have = e < n_list;
+            const int h_l = have ? (int)clist[e] : 0;
+            const size_t rec_l = (size_t)pair * Hp + h_l;
+            const int u_l = b.hyp_cnt[rec_l];   // upper count over the points seen so far
+            const bool on_l = have && !(u_l + left0 < Bnow);
+            if (__ballot(on_l) == 0ull)
+                continue;   // (wave-uniform) none of the 64 entries can still reach the bound
+            {
+                const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_r32 + rec_l * kHypRec32);
+                const float4 q0 = fr4[0], q1 = fr4[1], q2 = fr4[2];
+                const float fr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
+                float sc = dense_scale(q2.y, dense_T(fr, X1, Y1, X2, Y2), on_l);
+                float big = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    big = fmaxf(big, fabsf(fr[k]));
+                sc = (big * sc < 0x1p100f) ? sc : 0.f;
+                float Fs[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    Fs[k] = mul_legacy(fr[k], sc);
+                uint4 o[2][2];
+                dense_operands_pk<1>(Fs, o);
+                uint4 *wo = s_win + (lane >> 5) * 128 + (lane & 31);
+                wo[0] = o[0][0];
+                wo[32] = o[0][1];
+                wo[64] = o[1][0];
+                wo[96] = o[1][1];
+            }
+            int u0[2];
+            bool on[2];
+            v8bf Bop[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u0[c] = __shfl(u_l, 32 * c + col);
+                on[c] = __shfl((int)on_l, 32 * c + col) != 0;
+                const uint4 *ro = s_win + c * 128 + half * 32 + col;
+                Bop[c][0] = __builtin_bit_cast(v8bf, ro[0]);
+                Bop[c][1] = __builtin_bit_cast(v8bf, ro[64]);
+            }
+            uint32_t nn[2] = {0u, 0u};
+            const uint4 *qt = s_op + half * 32 + col;
+            const int nt = nc >> 5;
+            int t = 0;
+            for (; t < nt; ++t) {
+                if (t > 0 && (t & 7) == 0) {
+                    // exit test every 256 points: the list is sorted, the 64 entries of a wavefront are of one quality and
+                    // die together.  A dead entry keeps an upper count below the bound (what it has + what is left < bound)
+                    bool any = false;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        int U = 16 * t - (int)nn[c];
+                        U += __shfl_xor(U, 32);
+                        any = any || (on[c] && !(u0[c] + U + (left0 - 32 * t) < Bnow));
+                    }
+                    if (__ballot(any) == 0ull)
+                        break;
+                }
+                const uint4 *q = qt + (size_t)t * 128;
+                const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
+                v16f a0, a1;
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], zero, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], zero, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
+                nn[0] += (uint32_t)__builtin_popcount(dense_collect(a0) & 0x55555555u);
+                nn[1] += (uint32_t)__builtin_popcount(dense_collect(a1) & 0x55555555u);
+            }
+            // back to the lane that owns the entry (it read the count, it writes it: a later chunk re-reads its own store)
+            int Uc[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                Uc[c] = 16 * t - (int)nn[c];
+                Uc[c] += __shfl_xor(Uc[c], 32);
+            }
+            const int U1 = __shfl(Uc[1], lane & 31);
+            if (on_l)
+                b.hyp_cnt[rec_l] = u_l + (lane < 32 ? Uc[0] : U1);
+            if (STATS)
+                evals += (unsigned long long)__popcll(__ballot(on_l)) * (unsigned long long)(32 * t);
+        }
+    }
+    if (STATS && b.stats && lane == 0 && evals)
+        atomicAdd(&b.stats[7], evals);
+}
+
 // The work list of the exact solve (-> ransac_exact_list_kernel): records the pre-screen could not certify, and approximate
 // records whose upper-bound count reaches the pair's final bound -- they may be the winner, so they get their exact F before
 // ransac_select_kernel scores everything at or above the bound.  Entries are collected per workgroup in LDS and appended
 // with one atomic per flush: a returning atomic per wavefront on the list's single counter stalls every wavefront for a
 // memory round trip and serialises in the L2.
-constexpr int kSurvList = 2048;
+// Round 4: grid (kSurvWg, P), a workgroup owns a contiguous stretch of ONE pair's records and a thread four records at a
+// time (one 32-bit load of the state bytes, one 128-bit load of the counts, no dependent second round trip: the flat grid of
+// round 3 spent 49 iterations of state -> branch -> count per thread, 0.11 ms of latency).  Besides the work list of the exact
+// solve the kernel writes the pair's CANDIDATE list for ransac_select_kernel (plist = the first half of clist, dead after the
+// list sort; pcount): everything that will be scored exactly -- the work-list entries plus exact records at or above the bound
+// (pairs in mode 0) --, so that the selection no longer scans the pair's 50 000 counts itself.
+constexpr int kSurvList = 1024;   // per list and workgroup, flushed when the next 1024 records might not fit
+constexpr int kSurvWg = 8;
 __global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunParams rp, int n_active)
 {
-    __shared__ uint32_t s_l[kSurvList];
-    __shared__ int s_n;
-    __shared__ unsigned s_base;
+    __shared__ uint32_t s_x[kSurvList + 1024], s_c[kSurvList + 1024];
+    __shared__ int s_nx, s_nc;
+    __shared__ unsigned s_bx, s_bc;
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    if (b.M[pair] < 8)
+        return;
+    const int mode = b.mode[pair];
+    const int bound = b.bound[pair];
+    const int H = rp.num_hypotheses;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const size_t total = (size_t)n_active * Hp;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0)
-        s_n = 0;
+    const uint32_t *st4 = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
+    const int4 *cnt4 = reinterpret_cast<const int4 *>(b.hyp_cnt + (size_t)pair * Hp);
+    uint32_t *plist = b.clist + (size_t)pair * Hp;
+    if (tid == 0) {
+        s_nx = 0;
+        s_nc = 0;
+    }
     __syncthreads();
     auto flush = [&]() {   // called by the whole workgroup
-        const int n = s_n;
-        if (n > 0) {
-            if (tid == 0)
-                s_base = atomicAdd(&b.xcount[0], (unsigned)n);
-            __syncthreads();
-            for (int i = tid; i < n; i += 256)
-                b.xlist[s_base + i] = s_l[i];
-            __syncthreads();
-            if (tid == 0)
-                s_n = 0;
+        const int nx = s_nx, nc = s_nc;
+        if (tid == 0) {
+            s_bx = nx ? atomicAdd(&b.xcount[0], (unsigned)nx) : 0u;
+            s_bc = nc ? (unsigned)atomicAdd(&b.pcount[pair], nc) : 0u;
+        }
+        __syncthreads();
+        for (int i = tid; i < nx; i += 256)
+            b.xlist[s_bx + i] = s_x[i];
+        for (int i = tid; i < nc; i += 256)
+            plist[s_bc + i] = s_c[i];
+        __syncthreads();
+        if (tid == 0) {
+            s_nx = 0;
+            s_nc = 0;
         }
         __syncthreads();
     };
-    for (size_t base0 = (size_t)blockIdx.x * 256; base0 < total; base0 += (size_t)gridDim.x * 256) {
-        const size_t rec = base0 + tid;
-        bool take = false;
-        if (rec < total) {
-            const int pair = (int)(rec / Hp);
-            const uint32_t h = (uint32_t)(rec - (size_t)pair * Hp);
-            if (h < (uint32_t)rp.num_hypotheses && b.M[pair] >= 8 && b.mode[pair] != 0) {
-                const int okf = b.hyp_okf[rec];
-                take = okf == kPsNeedExact || (okf == kPsApprox && b.hyp_cnt[rec] >= b.bound[pair]);
+    const int n4 = (int)(Hp / 4);                                   // groups of four records
+    const int per_wg = (n4 + gridDim.x - 1) / gridDim.x;
+    const int g_begin = blockIdx.x * per_wg, g_end = min(n4, g_begin + per_wg);
+    for (int g0 = g_begin; g0 < g_end; g0 += 256) {
+        const int g = g0 + tid;
+        uint32_t st = 0u;
+        int4 c = make_int4(-1, -1, -1, -1);
+        if (g < g_end) {
+            st = st4[g];
+            c = cnt4[g];
+        }
+        const int cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = 4 * g + k;
+            const int okf = (int)((st >> (8 * k)) & 0xffu);
+            const bool live = g < g_end && h < H;
+            // the exact solve still owes: records without a certificate, approximate records whose upper count reaches the bound
+            const bool need = live && mode != 0 && (okf == kPsNeedExact || (okf == kPsApprox && cv[k] >= bound));
+            // scored exactly by the selection: those, and exact records at or above the bound
+            const bool cand = need || (live && okf == kPsExact && cv[k] >= bound);
+            const unsigned long long mx = __ballot(need), mc = __ballot(cand);
+            if (mc) {   // (rare: ~10 of a pair's 50 000)
+                const int first = __builtin_ctzll(mc);
+                int bx = 0, bc = 0;
+                if (lane == first) {
+                    bc = atomicAdd(&s_nc, __popcll(mc));
+                    bx = mx ? atomicAdd(&s_nx, __popcll(mx)) : 0;
+                }
+                bc = __shfl(bc, first);
+                bx = __shfl(bx, first);
+                if (cand)
+                    s_c[bc + __popcll(mc & ((1ull << lane) - 1ull))] = (uint32_t)h;
+                if (need)
+                    s_x[bx + __popcll(mx & ((1ull << lane) - 1ull))] = (uint32_t)((size_t)pair * Hp + h);
             }
         }
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            int base = 0;
-            if (lane == 0)
-                base = atomicAdd(&s_n, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (take)
-                s_l[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)rec;
-        }
         __syncthreads();           // every append of this round is in
-        const int n_now = s_n;
-        __syncthreads();           // ... and read by everyone before the next round appends: the decision is uniform
-        if (n_now > kSurvList - 256)
+        const bool full = s_nc > kSurvList || s_nx > kSurvList;
+        __syncthreads();           // ... and read by everyone: the decision is uniform
+        if (full)
             flush();
     }
     flush();
@@ -2439,13 +2629,16 @@ __global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunPa
 // point stream with the fused kernel's exact operations (count AND residual sum in index order), and the best by
 // (residual, index) becomes the pair's single WgBest record; finalize_model reduces the records as before.
 constexpr int kSelThreads = 256;
-constexpr int kSelList = 1024;
+constexpr int kSelList = 2048;   // capacity of the candidate list in LDS
+constexpr int kSelSeg = 1024;    // hypotheses scanned between two barriers (the list is worked off once a segment might overflow it)
 constexpr int kSelSerial = 24;   // up to this many ties are scored one at a time by the whole workgroup
 
-__global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, RunParams rp)
+__global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, RunParams rp, int use_plist)
 {
     extern __shared__ __attribute__((aligned(16))) double s_spts[];   // [max_kp][4] points OR [max_kp] residuals
     __shared__ uint32_t s_list[kSelList];
+    __shared__ int s_cnt[kSelList];
+    __shared__ int s_nlist;
     __shared__ double s_F[9];
     __shared__ int s_tot[4];
     __shared__ Cand s_c[4];
@@ -2487,32 +2680,121 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
     const double4 *L4 = reinterpret_cast<const double4 *>(s_spts);
     double *s_r = s_spts;
     const int lane = tid & 63, w = tid >> 6;
-    int scan = 0;
-    while (scan < H) {
-        // collect the next <= kSelList tied hypotheses, ascending
-        int n_list = 0;
-        while (scan < H && n_list <= kSelList - kSelThreads) {
-            const int h = scan + tid;
-            // every hypothesis whose (upper-bound) count reaches the pair's bound; with exact counts these are the ties at
-            // the maximum, with pre-screened ones the survivors -- all of them carry their exact F by now
-            const bool flag = h < H && cntp[h] >= cmax && okb[h] != kPsInvalid;
-            const unsigned long long bal = __ballot(flag);
-            if (lane == 0)
-                s_tot[w] = __popcll(bal);
+    int scan = 0;   // position in the pair's candidate list (use_plist) or in its hypothesis range
+    const int n_total = use_plist ? b.pcount[pair] : H;
+    const uint32_t *plist = b.clist + (size_t)pair * Hp;
+    while (scan < n_total) {
+        if (tid == 0)
+            s_nlist = 0;
+        __syncthreads();
+        if (use_plist) {
+            // the candidates ransac_survivors_kernel listed: everything whose (upper-bound) count reaches the pair's bound
+            const int n = min(kSelList, n_total - scan);
+            for (int q = tid; q < n; q += kSelThreads)
+                s_list[q] = plist[scan + q];
+            if (tid == 0)
+                s_nlist = n;
+            scan += n;
             __syncthreads();
-            int off = n_list, tot = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int v = s_tot[k];
-                off += (k < w) ? v : 0;
-                tot += v;
+        } else {
+            // (no candidate list: the diagnostics ladder's launches) collect the hypotheses whose count reaches the pair's
+            // bound, appended per wavefront with one LDS atomic, no barrier inside a segment of kSelSeg hypotheses; the list
+            // order is immaterial, candidates are compared by (count, residual, index)
+            while (scan < H) {
+                const int seg_end = min(H, scan + kSelSeg);
+                for (int h = scan + tid; h < seg_end; h += kSelThreads) {
+                    const bool flag = cntp[h] >= cmax && okb[h] != kPsInvalid;
+                    const unsigned long long bal = __ballot(flag);
+                    if (bal) {
+                        int base = 0;
+                        if (lane == __builtin_ctzll(bal))
+                            base = atomicAdd(&s_nlist, __popcll(bal));
+                        base = __shfl(base, __builtin_ctzll(bal));
+                        if (flag)
+                            s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)h;
+                    }
+                }
+                scan = seg_end;
+                __syncthreads();
+                if (s_nlist > kSelList - kSelSeg)
+                    break;   // (uniform) the next segment might not fit: work this list off first
             }
-            if (flag)
-                s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)h;
-            n_list += tot;
-            scan += kSelThreads;
-            __syncthreads();
         }
+        int n_list = s_nlist;
+        __syncthreads();
+        if (n_list == 0)
+            continue;
+        // Exact COUNTS first (round 4): with pre-screened counts the list holds every hypothesis whose UPPER bound reaches the
+        // pair's bound (~10 per pair on the bench workload, dozens to hundreds elsewhere), but only those that tie at the
+        // largest exact count need the residual sum in index order -- a serial chain of one addition per inlier, the
+        // latency floor of this kernel (0.25 ms per 512 pairs when every listed hypothesis went through it).  One wavefront
+        // per hypothesis, lanes are points: the count is a handful of ballots.  Pairs in mode 0 carry exact counts already.
+        if (b.mode[pair] != 0) {
+            for (int q = w; q < n_list; q += kSelThreads / 64) {
+                if (okb[s_list[q]] == kPsInvalid) {   // (wave-uniform) its exact solve rejected the sample: out
+                    if (lane == 0)
+                        s_cnt[q] = -1;
+                    continue;
+                }
+                const double *f = Fp + (size_t)s_list[q] * kHypRec;
+                double F[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    F[k] = f[k];
+                int c = 0;
+                for (int i = lane; i < M; i += 64) {
+                    const double4 p = P4[i];
+                    c += epipolar_residual(F, p.x, p.y, p.z, p.w) < thr ? 1 : 0;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    c += __shfl_xor(c, o);
+                if (lane == 0)
+                    s_cnt[q] = c;
+            }
+        } else {
+            for (int q = tid; q < n_list; q += kSelThreads)
+                s_cnt[q] = cntp[s_list[q]];
+        }
+        __syncthreads();
+        {
+            // the largest count of this round against the best so far; the hypotheses at that count, in index order
+            int cm = -1;
+            for (int q = tid; q < n_list; q += kSelThreads)
+                cm = max(cm, s_cnt[q]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                cm = max(cm, __shfl_xor(cm, o));
+            if (lane == 0)
+                s_tot[w] = cm;
+            __syncthreads();
+            const int target = max(max(max(s_tot[0], s_tot[1]), max(s_tot[2], s_tot[3])), s_best.cnt);
+            __syncthreads();
+            int n_ties = 0;
+            for (int q0 = 0; q0 < n_list; q0 += kSelThreads) {
+                const int q = q0 + tid;
+                const bool tie = q < n_list && s_cnt[q] == target;
+                const uint32_t hq = q < n_list ? s_list[q] : 0u;
+                const unsigned long long bal = __ballot(tie);
+                if (lane == 0)
+                    s_tot[w] = __popcll(bal);
+                __syncthreads();   // (also: every s_list[q] of this stretch has been read)
+                int off = n_ties, tot = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = s_tot[k];
+                    off += (k < w) ? v : 0;
+                    tot += v;
+                }
+                if (tie)
+                    s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = hq;   // off + ... <= q: in-place compaction
+                n_ties += tot;
+                __syncthreads();
+            }
+            n_list = n_ties;
+        }
+        if (n_list == 0)
+            continue;
         if (n_list <= kSelSerial) {
             // few ties (the usual case is one): the whole workgroup scores ONE hypothesis at a time -- residuals of all
             // points in parallel, inliers compacted in index order, then one lane adds them up in that order.  The
@@ -3123,7 +3405,12 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
 constexpr int kCntThreads = 768;   // 12 wavefronts: two workgroups fit a CU (2 x 64 KB of LDS, 6 of the 7 wavefronts per SIMD the
 constexpr int kCntPpl = 2;         // 70 registers allow) against one workgroup of 1024 (4 per SIMD): 42.7 -> 42.3 ms per 512 pairs
 constexpr int kSolveBlock = 64;    // one wavefront per workgroup: every SIMD refills on its own (45.4 -> 44.5 ms, same bits)
+#ifdef MVS_DEBUG_HOOKS
+static int kSplitMinPairs = 3;     // (diagnostics: settable, tools/single_pair.py times a single pair on the pre-screened stage)
+void set_split_min_pairs(int v) { kSplitMinPairs = v; }
+#else
 constexpr int kSplitMinPairs = 3;  // one or two pairs stay on the fused kernel (latency: fewer launches)
+#endif
 
 constexpr int kCnt32Threads = 768;
 constexpr int kCnt32Slots = 4;     // hypotheses a wavefront carries at a time
@@ -3204,6 +3491,12 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.fn = reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>);
         d.threads = kFinishThreads;
         d.dynamic_lds = (size_t)kDenseChunk * 64;
+        break;
+    case kKRansacCountFinishRest:
+        d.name = "ransac_finish_upper_kernel<false>";
+        d.fn = reinterpret_cast<const void *>(ransac_finish_upper_kernel<false>);
+        d.threads = kFinishThreads;
+        d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacCountMfma:
         d.name = "ransac_count_mfma_kernel<false, 256, 8, 0>";
@@ -3286,6 +3579,8 @@ hipError_t prepare_kernels()
 #endif
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true>),
+                         reinterpret_cast<const void *>(ransac_finish_upper_kernel<false>),
+                         reinterpret_cast<const void *>(ransac_finish_upper_kernel<true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
@@ -3383,7 +3678,7 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
     else
         hipLaunchKernelGGL((ransac_count_kernel<kCntThreads, kCntPpl>), grid, dim3(kCntThreads), lds_cnt, stream, b, rp, wg);
     if (lt) lt->mark(kKRansacSelect);
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), lds_sel, stream, b, rp, 0);
 }
 
 #endif
@@ -3475,18 +3770,23 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
 #endif
         {
             // two launches: the first batch of every pair (the 256 largest partial counts: the winner is nearly always among
-            // them, so the pair's bound is final afterwards), then the rest -- whose workgroups mostly find nothing left
-            const int nb = (int)fin_grid.y;
-            for (int part = 0; part < 2; ++part) {
-                const dim3 g(n_active, part == 0 ? 1 : nb - 1);
-                if (g.y == 0)
-                    break;
+            // them, so the pair's bound is final afterwards: upper and lower bounds over every point), then the rest of the
+            // list: upper counts only, over the points behind the dense phase
+            if (stats)
+                hipLaunchKernelGGL(ransac_finish_mfma_kernel<true>, dim3(n_active, 1), dim3(kFinishThreads), (size_t)kDenseChunk * 64,
+                                   stream, b, rp, 0);
+            else
+                hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, dim3(n_active, 1), dim3(kFinishThreads), (size_t)kDenseChunk * 64,
+                                   stream, b, rp, 0);
+            if (fin_grid.y > 1) {
+                const size_t lds_up = (size_t)kDenseChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
+                if (lt) lt->mark(kKRansacCountFinishRest);
                 if (stats)
-                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<true>, g, dim3(kFinishThreads), (size_t)kDenseChunk * 64, stream,
-                                       b, rp, part);
+                    hipLaunchKernelGGL(ransac_finish_upper_kernel<true>, dim3(n_active, kFinUpperWg), dim3(kFinishThreads), lds_up,
+                                       stream, b, rp);
                 else
-                    hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, g, dim3(kFinishThreads), (size_t)kDenseChunk * 64, stream,
-                                       b, rp, part);
+                    hipLaunchKernelGGL(ransac_finish_upper_kernel<false>, dim3(n_active, kFinUpperWg), dim3(kFinishThreads), lds_up,
+                                       stream, b, rp);
             }
         }
     }
@@ -3516,16 +3816,14 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
     hipLaunchKernelGGL((ransac_solve_list_kernel<240 + 1024>), dim3(2048), dim3(64), 0, stream, b, rp,
                        G * (kHypPerBlock / kSolveBlock));
     launch_counting(b, rp, n_active, stream, lt, stats);
-    const size_t total = (size_t)n_active * b.max_groups * kHypPerBlock;
-    const int sg = (int)std::min<size_t>((total + 255) / 256, 2048);
     if (lt) lt->mark(kKRansacSurvivors);
-    hipLaunchKernelGGL(ransac_survivors_kernel, dim3(sg), dim3(256), 0, stream, b, rp, n_active);
+    hipLaunchKernelGGL(ransac_survivors_kernel, dim3(kSurvWg, n_active), dim3(256), 0, stream, b, rp, n_active);
     // one exact solve over the whole work list: what the pre-screen flagged + the survivors of the counting
     if (lt) lt->mark(kKRansacExactList);
     hipLaunchKernelGGL((ransac_exact_list_kernel<240 + 1024>), dim3(1024), dim3(64), 0, stream, b, rp, 0);
     if (lt) lt->mark(kKRansacSelect);
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_active), dim3(kSelThreads), (size_t)b.max_kp * 4 * sizeof(double), stream,
-                       b, rp);
+                       b, rp, 1);
 }
 
 // the pre-screened stage, or -- for one or two pairs, the per-hypothesis tables and the instrumented replay's rotation

@@ -74,6 +74,8 @@ struct BatchDev {
                          // screened, counted in double precision
     uint32_t *clist;     // [P][max_groups * 256] hypotheses of the pair the dense counting phase left alive (for the finish)
     int32_t *ccount;     // [P] their number
+    int32_t *pcount;     // [P] entries of the pair's candidate list for the selection (ransac_survivors_kernel -> ransac_select_kernel;
+                         // the list itself reuses the first half of clist, which is dead after the list sort)
     int32_t *m0list;     // [1 + P] number of pairs in mode 0, then those pairs (mode0_list_kernel -> ransac_solve_list_kernel)
     int32_t *dense_n1;   // [P] points the dense (matrix-core) counting phase covered for the pair
     uint32_t *xlist;     // [P * max_groups * 256] work list of the list-driven exact solve: flat indices pair * Hp + h
@@ -280,7 +282,8 @@ enum KernelId : int {
     kKRansacCountPilot,  // ransac_count32_kernel, phase 0: the first kPilotHyp hypotheses in full -> the pair's first bound
     kKRansacCountMfma,   // dense counting of the points that must be seen before anything can be dropped: split bf16 on the
                          // matrix cores, no exit tests
-    kKRansacCountFinish, // the listed hypotheses that can still reach the bound: upper and lower count bounds, matrix cores
+    kKRansacCountFinish, // the first batch of every pair's list (largest partial counts): upper and lower count bounds, matrix cores
+    kKRansacCountFinishRest, // the rest of the list: upper counts completed behind the dense phase's points
     kKRansacSurvivors, // hypotheses whose upper bound reaches the pair's best lower bound -> work list
     kKFinModel,
     kKTriangulate,
@@ -333,6 +336,7 @@ void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStre
 void set_count_dense(int v);      // 1 = single-precision counting as pilot + dense MFMA phase + finish
 void set_match_mfma(int v);       // 1 (default) 256-bit descriptors on the matrix cores by batch size, 0 the VALU kernel
 void set_prescreen_force(int m);   // -1 probe decides (default), 0 every pair exact, 1 every pair pre-screened
+void set_split_min_pairs(int v);  // launches with fewer pairs stay on the fused hypothesis-per-lane kernel (default 3)
 void set_ransac_variant(int v);  // A/B switch between co-compiled ransac_kernel variants
 int get_ransac_variant();
 void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream);
