@@ -54,6 +54,34 @@ constexpr int kPsInvalid = 0, kPsApprox = 1, kPsNeedExact = 2, kPsExact = 3;   /
 // 1 / x for 2^-190 <= |x| <= 2^190 (div_fast's guarded range), correctly rounded like the compiler's division
 MVS_DEV double recip_guarded(double x) { return div_fast(1.0, x); }
 
+// Square root and reciprocal for BOUND arithmetic (round 4): results within 2^-49 of the true value instead of correctly
+// rounded -- 7 and 5 instructions where the IEEE sequences of hipcc take ~20 and ~13.  They are used only where the
+// derivation multiplies by an explicit slack factor (1 +- 1e-14 or more) or adds an absolute term in the safe direction, and
+// never on the path that has to reproduce the exact solve's bits (the Hartley scales) or that feeds F~ itself.
+MVS_DEV double sqrt_bound(double x)   // x finite and >= 2^-700 (callers' arguments are >= 1e-13 by construction)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    const double h = y * 0.5;
+    const double r = dfma(-h, g, 0.5);
+    g = dfma(g, r, g);
+    const double d = dfma(-g, g, x);
+    return dfma(d, h, g);   // second-order correction with the unrefined h: error ~2^-52 + 2^-26 * 2^-50
+}
+MVS_DEV double sqrt_bound0(double x)  // the same, 0 for x below 2^-700 (a NaN stays a NaN)
+{
+    const double g = sqrt_bound(x);
+    return x < 0x1p-700 ? 0.0 : g;
+}
+MVS_DEV double rcp_bound(double x)    // 1 / x for normal x, two Newton steps on v_rcp_f64
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = dfma(-x, r, 1.0);
+    r = dfma(r, e, r);
+    e = dfma(-x, r, 1.0);
+    return dfma(r, e, r);
+}
+
 // Hartley normalisation of a sample from its gathered points: means and scales only (the normalised coordinates are
 // rebuilt point by point where they are needed).  The same operations as normalise8: the same bits.
 MVS_DEV bool sample_norm(const double (&px)[8], const double (&py)[8], double &scale, double &mx, double &my, bool &tiny)
@@ -150,7 +178,7 @@ MVS_DEV void prescreen_rank2(const double (&g)[9], double (&X)[9], double &e_out
     const double e0 = dfma(g[6], u2, dfma(g[3], u1, dfma(g[0], u0, -(sig * vx))));
     const double e1 = dfma(g[7], u2, dfma(g[4], u1, dfma(g[1], u0, -(sig * vy))));
     const double e2 = dfma(g[8], u2, dfma(g[5], u1, dfma(g[2], u0, -(sig * vz))));
-    const double eps2 = dsqrt(dfma(e2, e2, dfma(e1, e1, e0 * e0)));
+    const double eps2 = sqrt_bound0(dfma(e2, e2, dfma(e1, e1, e0 * e0))) * (1.0 + 1e-14);   // (kPsTrip covers the rest)
     const bool useA = (eps2 < sig) && (sig >= 0x1p-190);
     e_out = (useA ? eps2 : sig) + kPsTrip;
     sige_out = useA ? sig : 0.0;
@@ -296,7 +324,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     }
     S *= 1.0 + 1e-12;
     piv_ok = piv_ok && (S <= 0x1p100);
-    const double sqrtS = dsqrt(S) * (1.0 + 1e-12);
+    const double sqrtS = sqrt_bound(S) * (1.0 + 1e-12);   // (S >= 8: every row of A holds a 1)
     // n~ = H_0 H_1 ... H_7 e_8
     double n[9];
 #pragma unroll
@@ -345,7 +373,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
             }
         }
     }
-    const double yf = dsqrt(y2sum) * (1.0 + 1e-12);
+    const double yf = sqrt_bound(y2sum) * (1.0 + 1e-12);  // (y2sum >= 1 / pivot^2 >= 2^-380; a zero pivot fails piv_ok)
     // residual of n~ against the rows of A -- a priori: with A^T + E = Q~ [R^; 0] (||E||_F <= 176 u ||A||_F, Q~ within 250 u of
     // orthogonal: DESIGN.md 4.3e (iii)) and n~ = the computed Q~ e_9 (eight reflector applications, <= 176 u of rounding),
     // A n~ = [R^T 0] Q~^T n~ - E^T n~ and Q~^T n~ = e_9 up to 500 u + 176 u, so || A n~ || <= 852 u ||A||_F + 176 u ||A||_F.
@@ -354,10 +382,10 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     const double rho = 1.2e-13 * sqrtS;
     // sigma_8(A) >= (1 - z) / ||R^-1||_F (1 - 250 u) - 176 u ||A||_F
     const double z = 12.0 * kPsU * sqrtS * yf;
-    const double sig8 = (1.0 - z) / yf * (1.0 - 1e-13) - 4e-14 * sqrtS;
-    const double g = sig8 * sig8;
-    const double eta_j = 1.01 * kPsTauC * S / g + kPsEtaQ;
-    const double eta_a = 1.5 * rho / sig8 + 1e-13;
+    const double sig8 = (1.0 - z) * rcp_bound(yf) * (1.0 - 1e-13) - 4e-14 * sqrtS;   // (250 u + the reciprocal's 2^-49 < 1e-13)
+    const double rg = rcp_bound(sig8);   // (NaN / inf for sig8 <= 0: the certificate is refused below)
+    const double eta_j = 1.01 * kPsTauC * S * (rg * rg) + kPsEtaQ;   // (1.01 * 2.0e-12 is 13 % above 2.001 (8000 u + 8.01 u))
+    const double eta_a = 1.5 * rho * rg + 1e-13;
     // rank-2 through one verified singular triplet of reshape(n~), de-normalisation
     double Fn[9], e3, sige, extra, s2lb;
     bool ok3;
@@ -366,7 +394,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     bad3 = false;
     const double eta = (eta_j + eta_a + e3 + kPsSvd3) * (1.0 + 1e-12);
     const double delta = ((s2lb - extra) - sige) - eta;
-    const double dfn = (2.0 + 2.0 * (sige + 3.0 * eta) / delta) * eta + extra + kPsSvd3;
+    const double dfn = (2.0 + 2.0 * (sige + 3.0 * eta) * rcp_bound(delta) * (1.0 + 1e-14)) * eta + extra + kPsSvd3;
     // N = max over the pair's points of || T p || (T = the sample's Hartley transform), N' with absolute values
     const double d1x = fmax(dabs(nm.m1x - bx.x1lo), dabs(nm.m1x - bx.x1hi));
     const double d1y = fmax(dabs(nm.m1y - bx.y1lo), dabs(nm.m1y - bx.y1hi));
@@ -380,7 +408,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     // N1^2 N2^2 and N1'^2 N2'^2 first, one square root each
     const double n12 = dfma(s1q, dfma(d1x, d1x, d1y * d1y), 1.0) * dfma(s2q, dfma(d2x, d2x, d2y * d2y), 1.0);
     const double n12p = dfma(s1q, dfma(e1x, e1x, e1y * e1y), 1.0) * dfma(s2q, dfma(e2x, e2x, e2y * e2y), 1.0);
-    const double band = (dfn * dsqrt(n12) * (1.0 + 1e-9) + 64.0 * kPsU * dsqrt(n12p)) * (1.0 + 1e-9) + 1e-15 * thr;
+    const double band = (dfn * sqrt_bound(n12) * (1.0 + 1e-9) + 64.0 * kPsU * sqrt_bound(n12p)) * (1.0 + 1e-9) + 1e-15 * thr;
     band_out = band;
     // single-precision counting: r32 = the residual evaluated in binary32 on F~ and the point rounded to binary32, either as
     // the nested fma chain of ransac_count32_kernel (a term p2_j F_jk p1_k passes at most 7 roundings: three inputs, four

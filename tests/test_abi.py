@@ -137,3 +137,26 @@ def test_product_library_has_one_path_and_no_experiment_ladder():
     for k in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel", "ransac_exact_list_kernel", "ransac_select_kernel",
               "match_mfma_kernel", "finalize_model_kernel"):
         assert k in prod, k
+
+
+def test_hot_kernels_do_not_spill():
+    """The build's -Rpass-analysis=kernel-resource-usage digest (lib/kernel_resources.json): the hot kernels of the pre-screened
+    stage keep their state in registers.  ransac_prescreen_kernel sits a few registers below the 168 that three wavefronts
+    per SIMD allow -- a harmless-looking edit in prescreen.hpp once pushed it to 284 bytes of scratch per lane and from
+    2.6 to 4.1 ms per 512 pairs (round 4); this test makes that visible without a GPU."""
+    import json
+
+    res = json.load(open(os.path.join(ROOT, "mvslam_amd", "lib", "kernel_resources.json")))
+
+    def one(prefix):
+        hits = {k: v for k, v in res.items() if prefix in k}
+        assert hits, prefix
+        return hits
+
+    for k, v in one("ransac_prescreen_kernel").items():
+        assert v["scratch_bytes_per_lane"] == 0 and v["vgpr_spills"] == 0 and v["occupancy_waves_per_simd"] >= 3, (k, v)
+    for prefix in ("ransac_count_mfma_kernelILb0", "ransac_finish_mfma_kernelILb0", "ransac_finish_upper_kernelILb0",
+                   "ransac_count32_kernel", "ransac_count2_kernel", "match_mfma_kernel", "triangulate_kernel"):
+        for k, v in one(prefix).items():
+            assert v["scratch_bytes_per_lane"] == 0, (k, v)
+            assert v["agprs"] == 0 or "mfma" not in prefix, (k, v)     # MFMA results stay in VGPRs (no v_accvgpr_read per use)
