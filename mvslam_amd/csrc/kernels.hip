@@ -2630,6 +2630,7 @@ __global__ __launch_bounds__(256) void ransac_survivors_kernel(BatchDev b, RunPa
 // (residual, index) becomes the pair's single WgBest record; finalize_model reduces the records as before.
 constexpr int kSelThreads = 256;
 constexpr int kSelList = 2048;   // capacity of the candidate list in LDS
+constexpr int kSelWaveCount = 96;   // up to this many candidates are counted one per wavefront (lanes = points), more one per lane
 constexpr int kSelSeg = 1024;    // hypotheses scanned between two barriers (the list is worked off once a segment might overflow it)
 constexpr int kSelSerial = 24;   // up to this many ties are scored one at a time by the whole workgroup
 
@@ -2729,7 +2730,36 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
         // largest exact count need the residual sum in index order -- a serial chain of one addition per inlier, the
         // latency floor of this kernel (0.25 ms per 512 pairs when every listed hypothesis went through it).  One wavefront
         // per hypothesis, lanes are points: the count is a handful of ballots.  Pairs in mode 0 carry exact counts already.
-        if (b.mode[pair] != 0) {
+        if (b.mode[pair] != 0 && n_list > kSelWaveCount) {
+            // long lists (pairs with many uncertified hypotheses: ~1000 per pair on the small-baseline sequence): one
+            // hypothesis per LANE over the LDS point stream, 256 at a time, counts only
+            if (!staged) {
+                const double2 *src = reinterpret_cast<const double2 *>(P4);
+                double2 *dst = reinterpret_cast<double2 *>(s_spts);
+                for (int i = tid; i < 2 * M; i += kSelThreads)
+                    dst[i] = src[i];
+                staged = true;
+                __syncthreads();
+            }
+            for (int q = tid; q < n_list; q += kSelThreads) {
+                const uint32_t h = s_list[q];
+                int c = -1;
+                if (okb[h] != kPsInvalid) {
+                    const double *f = Fp + (size_t)h * kHypRec;
+                    double F[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        F[k] = f[k];
+                    c = 0;
+#pragma unroll 4
+                    for (int i = 0; i < M; ++i) {
+                        const double4 p = L4[i];
+                        c += epipolar_residual(F, p.x, p.y, p.z, p.w) < thr ? 1 : 0;
+                    }
+                }
+                s_cnt[q] = c;
+            }
+        } else if (b.mode[pair] != 0) {
             for (int q = w; q < n_list; q += kSelThreads / 64) {
                 if (okb[s_list[q]] == kPsInvalid) {   // (wave-uniform) its exact solve rejected the sample: out
                     if (lane == 0)
