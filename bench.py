@@ -726,6 +726,19 @@ def main():
             tot, _ = b1.time(prm, steps=20, warmup=3, per_kernel=False)
             out["single_pair_ms"] = round(tot / 20, 4)  # BASELINE configs[1]: one pair at a time
             b1.close()
+            # ... and what a caller of the reference's own interface waits for: the shim's ImagePair constructor (host C++,
+            # front-end/image-pair.cpp:30-71), host buffers in, host objects out -- a child process (tests/cpp/image_pair_latency.cpp,
+            # built by __graft_entry__.build())
+            probe = os.path.join(ROOT, "mvslam_amd", "lib", "image_pair_latency")
+            out["image_pair_ctor_ms"] = None
+            if os.path.exists(probe):
+                try:
+                    pr = subprocess.run([probe, str(args.kp), str(args.hyp), "100"], capture_output=True, text=True, timeout=120)
+                    lat = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+                    out["image_pair_ctor_ms"] = lat["image_pair_ctor_ms"]
+                    out["image_pair_probe"] = lat
+                except Exception as e:   # the probe is a convenience: never fail the bench line for it
+                    out["image_pair_probe"] = {"error": str(e)[:200]}
         if not args.no_pcie and world == 1:
             if args.pcie_naive:
                 # (a) naive: synchronous upload from pageable memory + run + synchronous download, nothing overlapped

@@ -23,6 +23,10 @@ struct mvs_ctx {
     double *d_uv1 = nullptr, *d_uv2 = nullptr;
     int uv_cap = 0;
     double *d_small = nullptr;  // 64 doubles of staging (fundamental_kernel)
+    unsigned char *d_single = nullptr;   // gathered outputs of a single-shot call (one device-to-host copy)
+    size_t single_cap = 0;
+    unsigned char *d_single_in = nullptr;   // packed inputs of mvs_image_pair (one host-to-device copy)
+    size_t single_in_cap = 0;
     void *d_pnp = nullptr;      // pnp_solve workspace
     size_t pnp_bytes = 0;
     void *d_ref = nullptr;      // sfm_refine / pnp_refine workspace
@@ -730,6 +734,8 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_pnp) (void)hipFree(ctx->d_pnp);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->d_single) (void)hipFree(ctx->d_single);
+    if (ctx->d_single_in) (void)hipFree(ctx->d_single_in);
     if (ctx->orb_graph) (void)hipGraphExecDestroy(ctx->orb_graph);
     if (ctx->d_orb) (void)hipFree(ctx->d_orb);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -1420,23 +1426,29 @@ static mvs_status fetch_single(mvs_ctx *ctx, int m, mvs_pair_result *res, double
     mvs_batch *b = ctx->scratch;
     hipStream_t s = ctx->stream;
     const size_t rows = (size_t)std::max(m, 0);
-    mvs_pair_result *h_res = static_cast<mvs_pair_result *>(pin_get(ctx, sizeof(mvs_pair_result)));
-    uint8_t *h_mask = (mask && rows) ? static_cast<uint8_t *>(pin_get(ctx, rows)) : nullptr;
-    double *h_pts = (points_xyz && rows) ? static_cast<double *>(pin_get(ctx, rows * 3 * sizeof(double))) : nullptr;
-    int32_t *h_idx = (point_idx && rows) ? static_cast<int32_t *>(pin_get(ctx, rows * sizeof(int32_t))) : nullptr;
-    mvs_match *h_mt = (matches && rows) ? static_cast<mvs_match *>(pin_get(ctx, rows * sizeof(mvs_match))) : nullptr;
-    PIN_TRY(ctx, h_res);
-    if ((mask && rows && !h_mask) || (points_xyz && rows && !h_pts) || (point_idx && rows && !h_idx) || (matches && rows && !h_mt))
-        PIN_TRY(ctx, (void *)nullptr);
-    HIP_TRY(ctx, hipMemcpyAsync(h_res, b->d.results, sizeof(*res), hipMemcpyDeviceToHost, s));
-    if (h_mask)
-        HIP_TRY(ctx, hipMemcpyAsync(h_mask, b->d.mask, rows, hipMemcpyDeviceToHost, s));
-    if (h_pts)
-        HIP_TRY(ctx, hipMemcpyAsync(h_pts, b->d.points, rows * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (h_idx)
-        HIP_TRY(ctx, hipMemcpyAsync(h_idx, b->d.point_idx, rows * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (h_mt)
-        HIP_TRY(ctx, hipMemcpyAsync(h_mt, b->d.matches, rows * sizeof(mvs_match), hipMemcpyDeviceToHost, s));
+    // pair 0's outputs gathered on the device into one block, ONE copy to the pinned arena
+    const int flags = ((mask && rows) ? 1 : 0) | ((points_xyz && rows) ? 2 : 0) | ((point_idx && rows) ? 4 : 0) |
+                      ((matches && rows) ? 8 : 0);
+    const SingleLayout L = single_layout((int)rows, flags);
+    if (ctx->single_cap < L.total) {
+        HIP_TRY(ctx, sync_stream(ctx));
+        if (ctx->d_single)
+            (void)hipFree(ctx->d_single);
+        ctx->d_single = nullptr;
+        ctx->single_cap = 0;
+        const size_t cap = std::max<size_t>(L.total, single_layout(b->d.max_kp, 15).total);
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_single, cap));
+        ctx->single_cap = cap;
+    }
+    unsigned char *h_all = static_cast<unsigned char *>(pin_get(ctx, L.total));
+    PIN_TRY(ctx, h_all);
+    launch_single_gather(b->d, (int)rows, flags, ctx->d_single, s);
+    HIP_TRY(ctx, hipMemcpyAsync(h_all, ctx->d_single, L.total, hipMemcpyDeviceToHost, s));
+    const mvs_pair_result *h_res = reinterpret_cast<const mvs_pair_result *>(h_all);
+    const uint8_t *h_mask = (flags & 1) ? h_all + L.mask : nullptr;
+    const double *h_pts = (flags & 2) ? reinterpret_cast<const double *>(h_all + L.points) : nullptr;
+    const int32_t *h_idx = (flags & 4) ? reinterpret_cast<const int32_t *>(h_all + L.idx) : nullptr;
+    const mvs_match *h_mt = (flags & 8) ? reinterpret_cast<const mvs_match *>(h_all + L.matches) : nullptr;
     HIP_TRY(ctx, sync_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     *res = *h_res;
@@ -1580,23 +1592,48 @@ mvs_status mvs_image_pair(mvs_ctx *ctx, const uint8_t *base_desc, const float *b
     b->d.hyp_residual = nullptr;
     const size_t db1 = (size_t)n_base * desc_bytes, db2 = (size_t)n_pair * desc_bytes;
     const size_t kb1 = (size_t)n_base * 2 * sizeof(float), kb2 = (size_t)n_pair * 2 * sizeof(float);
-    if ((st = pin_begin(ctx, db1 + db2 + kb1 + kb2 + 2048 + sizeof(mvs_pair_result) + (size_t)n_pair * (1 + 24 + 4 + 16) + 512)) != MVS_OK)
+    if ((st = pin_begin(ctx, db1 + db2 + kb1 + kb2 + 2048 + single_layout(n_pair, 15).total + 512)) != MVS_OK)
         return st;
     double kinv[9];
     mat3_inverse(K, kinv);
     const int32_t n1 = n_base, n2 = n_pair;
     const int64_t zero = 0;
-    // <= 4096 x 64 B per image: through the pinned arena (a memcpy of ~100 KB), so that the device copies are true
-    // asynchronous DMA whatever memory the caller's cv::Mat / std::vector lives in
-    if ((st = up_async(ctx, const_cast<uint32_t *>(b->d.desc1), base_desc, db1)) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<uint32_t *>(b->d.desc2), pair_desc, db2)) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<float *>(b->d.kp1), base_kp, kb1)) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<float *>(b->d.kp2), pair_kp, kb2)) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<int32_t *>(b->d.n1), &n1, sizeof(n1))) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<int32_t *>(b->d.n2), &n2, sizeof(n2))) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<double *>(b->d.K), K, 9 * sizeof(double))) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<double *>(b->d.Kinv), kinv, 9 * sizeof(double))) != MVS_OK) return st;
-    if ((st = up_async(ctx, const_cast<int64_t *>(b->d.gidx), &zero, sizeof(zero))) != MVS_OK) return st;
+    // <= 4096 x 64 B per image: through the pinned arena (a memcpy of ~160 KB), so that the device copy is true asynchronous
+    // DMA whatever memory the caller's cv::Mat / std::vector lives in -- as ONE block [desc1 | desc2 | kp1 | kp2] and one copy
+    // command; the kernel that receives the pair's scalars as arguments also puts the parts in place
+    {
+        auto up16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+        const size_t total = up16(db1) + up16(db2) + up16(kb1) + up16(kb2);
+        if (ctx->single_in_cap < total) {
+            HIP_TRY(ctx, sync_stream(ctx));
+            if (ctx->d_single_in)
+                (void)hipFree(ctx->d_single_in);
+            ctx->d_single_in = nullptr;
+            ctx->single_in_cap = 0;
+            const size_t cap = std::max<size_t>(total, (size_t)b->d.max_kp * (2 * 64 + 2 * 8) + 64);
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_single_in, cap));
+            ctx->single_in_cap = cap;
+        }
+        unsigned char *h_in = static_cast<unsigned char *>(pin_get(ctx, total));
+        PIN_TRY(ctx, h_in);
+        size_t o = 0;
+        std::memcpy(h_in + o, base_desc, db1); o += up16(db1);
+        std::memcpy(h_in + o, pair_desc, db2); o += up16(db2);
+        std::memcpy(h_in + o, base_kp, kb1); o += up16(kb1);
+        std::memcpy(h_in + o, pair_kp, kb2);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_single_in, h_in, total, hipMemcpyHostToDevice, ctx->stream));
+        SingleParams sp;
+        sp.n1 = n1;
+        sp.n2 = n2;
+        sp.gidx = zero;
+        for (int k = 0; k < 9; ++k) {
+            sp.K[k] = K[k];
+            sp.Kinv[k] = kinv[k];
+        }
+        sp.part_bytes[0] = (uint32_t)db1; sp.part_bytes[1] = (uint32_t)db2;
+        sp.part_bytes[2] = (uint32_t)kb1; sp.part_bytes[3] = (uint32_t)kb2;
+        launch_single_params(b->d, sp, ctx->d_single_in, ctx->stream);
+    }
     if ((st = enqueue_pipeline(b, to_run(*params), 1, false, nullptr)) != MVS_OK)
         return st;
     if ((st = fetch_single(ctx, n_pair, result, points_xyz, point_idx, inlier_mask, matches)) != MVS_OK)

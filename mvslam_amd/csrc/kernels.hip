@@ -2439,16 +2439,42 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
         }
         __syncthreads();
         const int left0 = M - c0;   // points of the pair not yet seen when this chunk starts (>= 1)
-        for (int batch = 1 + blockIdx.y; batch < n_batches; batch += gridDim.y) {
+        // the entries of a batch sit behind dependent global round trips (list entry -> its count -> its record): the list
+        // entries are requested two batches ahead and the counts one (the kernel waited in s_waitcnt for 76 % of its
+        // wavefront cycles: profiles/r04_pmc_summary.json)
+        struct Ent {
+            int h, u;
+            bool have;
+        };
+        auto fetch_h = [&](int batch, Ent &en) __attribute__((always_inline)) {
             const int e = batch * kFinishThreads + w * 64 + lane;   // this lane's list entry
-            const bool have = e < n_list;
-            const int h_l = have ? (int)clist[e] : 0;
+            en.have = batch < n_batches && e < n_list;
+            en.h = (int)clist[en.have ? e : 0];   // (unconditional load of a clamped index: no wait at the select)
+        };
+        auto fetch_rest = [&](Ent &en) __attribute__((always_inline)) {
+            const size_t rec = (size_t)pair * Hp + (en.have ? en.h : 0);
+            en.u = b.hyp_cnt[rec];   // upper count over the points seen so far
+        };
+        Ent nxt, nn;   // next batch: everything; the one after: its list entry
+        fetch_h(1 + blockIdx.y, nxt);
+        fetch_h(1 + blockIdx.y + gridDim.y, nn);
+        fetch_rest(nxt);
+        for (int batch = 1 + blockIdx.y; batch < n_batches; batch += gridDim.y) {
+            const Ent cur = nxt;
+            nxt.have = nn.have;
+            nxt.h = nn.h;
+            fetch_rest(nxt);
+            fetch_h(batch + 2 * gridDim.y, nn);
+            const bool have = cur.have;
+            const int h_l = cur.have ? cur.h : 0;
             const size_t rec_l = (size_t)pair * Hp + h_l;
-            const int u_l = b.hyp_cnt[rec_l];   // upper count over the points seen so far
+            const int u_l = cur.u;
             const bool on_l = have && !(u_l + left0 < Bnow);
             if (__ballot(on_l) == 0ull)
                 continue;   // (wave-uniform) none of the 64 entries can still reach the bound
             {
+                // (the records only for the batches that go on: most leave at the test above, and fetching every batch's
+                // records ahead of time doubled this kernel's time)
                 const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_r32 + rec_l * kHypRec32);
                 const float4 q0 = fr4[0], q1 = fr4[1], q2 = fr4[2];
                 const float fr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
@@ -4308,6 +4334,70 @@ hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, in
     return hipGetLastError();
 }
 #endif  // MVS_DEBUG_HOOKS
+
+// ---- single-shot glue (the reference's one-pair-at-a-time call pattern: front-end/image-pair.cpp:30-71) ----------------------
+// The per-pair scalars of pair 0 travel as KERNEL ARGUMENTS instead of five small host-to-device copies, and the outputs of
+// pair 0 are gathered into one contiguous block for ONE device-to-host copy instead of five: every copy command costs the
+// stream several microseconds that a 0.25 ms call notices (shim ImagePair ctor 0.38 -> 0.36 ms with the faster kernels of
+// round 4; see profiles/r04_image_pair_latency.json).
+__global__ __launch_bounds__(256) void single_params_kernel(BatchDev b, SingleParams sp, const uint4 *in)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {
+        const_cast<int32_t *>(b.n1)[0] = sp.n1;
+        const_cast<int32_t *>(b.n2)[0] = sp.n2;
+        const_cast<int64_t *>(b.gidx)[0] = sp.gidx;
+    }
+    if (t < 9) {
+        const_cast<double *>(b.K)[t] = sp.K[t];
+        const_cast<double *>(b.Kinv)[t] = sp.Kinv[t];
+    }
+    if (in) {
+        // the pair's descriptors and keypoints arrived as ONE block [desc1 | desc2 | kp1 | kp2] (16-byte aligned parts)
+        uint4 *dst[4] = {reinterpret_cast<uint4 *>(const_cast<uint32_t *>(b.desc1)), reinterpret_cast<uint4 *>(const_cast<uint32_t *>(b.desc2)),
+                         reinterpret_cast<uint4 *>(const_cast<float *>(b.kp1)), reinterpret_cast<uint4 *>(const_cast<float *>(b.kp2))};
+        size_t off = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t n16 = sp.part_bytes[k] / 16;   // parts are multiples of 8 bytes: whole 16-byte words, then one half
+            for (size_t i = t; i < n16; i += (size_t)gridDim.x * 256)
+                dst[k][i] = in[off + i];
+            if (t == 0 && (sp.part_bytes[k] & 8u))
+                reinterpret_cast<uint2 *>(dst[k] + n16)[0] = reinterpret_cast<const uint2 *>(in + off + n16)[0];
+            off += (sp.part_bytes[k] + 15) / 16;
+        }
+    }
+}
+void launch_single_params(const BatchDev &b, const SingleParams &sp, const void *in, hipStream_t stream)
+{
+    hipLaunchKernelGGL(single_params_kernel, dim3(in ? 32 : 1), dim3(256), 0, stream, b, sp, reinterpret_cast<const uint4 *>(in));
+}
+// out: [result, 512 B][mask rows][points rows x 3 f64][point_idx rows x i32][matches rows x 16 B], each part 16-byte aligned
+// (single_layout); parts with a zero flag are skipped
+__global__ __launch_bounds__(256) void single_gather_kernel(BatchDev b, int rows, int flags, unsigned char *out)
+{
+    const SingleLayout L = single_layout(rows, flags);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(b.results);
+    for (int i = tid; i < (int)(sizeof(mvs_pair_result) / 4); i += nth)
+        reinterpret_cast<uint32_t *>(out)[i] = r32[i];
+    if (flags & 1)
+        for (int i = tid; i < rows; i += nth)
+            out[L.mask + i] = b.mask[i];
+    if (flags & 2)
+        for (int i = tid; i < rows * 3; i += nth)
+            reinterpret_cast<double *>(out + L.points)[i] = b.points[i];
+    if (flags & 4)
+        for (int i = tid; i < rows; i += nth)
+            reinterpret_cast<int32_t *>(out + L.idx)[i] = b.point_idx[i];
+    if (flags & 8)
+        for (int i = tid; i < rows; i += nth)
+            reinterpret_cast<mvs_match *>(out + L.matches)[i] = b.matches[i];
+}
+void launch_single_gather(const BatchDev &b, int rows, int flags, unsigned char *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(single_gather_kernel, dim3(16), dim3(256), 0, stream, b, rows, flags, out);
+}
 
 void launch_fundamental(const double *p1, const double *p2, double *F, int *ok, hipStream_t stream)
 {

@@ -266,6 +266,36 @@ struct OrbDev {
 hipError_t orb_prepare(int cand_cap);
 void launch_orb(const OrbDev &d, hipStream_t stream);
 
+// ---- single-shot glue: pair 0's scalars as kernel arguments, pair 0's outputs gathered for one device-to-host copy --------
+struct SingleParams {
+    int32_t n1, n2;
+    int64_t gidx;
+    double K[9], Kinv[9];
+    uint32_t part_bytes[4];   // desc1, desc2, kp1, kp2 of the packed input block (when one is given)
+};
+struct SingleLayout {
+    size_t mask, points, idx, matches, total;
+};
+// flags: 1 mask, 2 points, 4 point indices, 8 matches
+__host__ __device__ inline SingleLayout single_layout(int rows, int flags)
+{
+    auto up = [](size_t x) { return (x + 15) & ~size_t(15); };
+    SingleLayout L;
+    size_t o = 512;   // the 368-byte result record
+    L.mask = o;
+    o += (flags & 1) ? up((size_t)rows) : 0;
+    L.points = o;
+    o += (flags & 2) ? up((size_t)rows * 24) : 0;
+    L.idx = o;
+    o += (flags & 4) ? up((size_t)rows * 4) : 0;
+    L.matches = o;
+    o += (flags & 8) ? up((size_t)rows * 16) : 0;
+    L.total = o;
+    return L;
+}
+void launch_single_params(const BatchDev &b, const SingleParams &sp, const void *packed_in, hipStream_t stream);
+void launch_single_gather(const BatchDev &b, int rows, int flags, unsigned char *out, hipStream_t stream);
+
 // ---- kernel table (mvs_kernel_info_get) and per-launch timing (mvs_batch_time_kernels) ---------------------------
 // One id per kernel of the two-view pipeline.  launch_* record an event in front of every launch when given a
 // LaunchTimer, so the per-kernel times of the bench line are measured on the launches' own stream, launch by launch.
