@@ -1700,12 +1700,16 @@ __global__ __launch_bounds__(CNT_THREADS) void ransac_count32_kernel(BatchDev b,
 // ransac_count32_kernel then resumes behind n1 for the hypotheses that can still reach the bound.
 // Wavefront = 2 x 32 hypotheses (the B operands: 16 VGPRs, built once) x all point tiles (A operands: two ds_read_b128 per
 // tile); the accumulator tile has the hypothesis on the lane and 16 points in the registers.
-constexpr int kDenseThreads = 256;   // dense phase: 4 wavefronts x 64 hypotheses share one staged chunk of points, two workgroups per
-                                     // CU.  A/B on the bench batch (tools/dense_ab.py, profiles/r04_dense_ab.json): 256 x 8 1.27 ms,
-                                     // 384 x 6 1.30, 512 x 4 1.35; the three-stage software pipeline 1.31 / 1.83 / 1.47
+constexpr int kDenseThreads = 512;   // dense phase: 8 wavefronts x 64 hypotheses share one staged chunk of points; with 672-point
+                                     // chunks two workgroups fit a CU = 4 wavefronts per SIMD (what the 102 registers allow).
+                                     // A/B on the bench batch (tools/dense_ab.py, profiles/r04_dense_ab.json), same box: 256 x 8
+                                     // threads x batches with 768-point chunks (2 per SIMD) 1.36 ms, 512 x 4 / 768 (one workgroup
+                                     // per CU) 1.44, 512 x 4 / 640 1.22, 512 x 4 / 672 1.19; the three-stage software pipeline
+                                     // 1.43 / 1.97 / 1.58 at 256 / 384 / 512 threads
 constexpr int kFinishThreads = 256;  // finish: 4 wavefronts x 64 list entries
 constexpr int kDenseChunk = 768;     // points staged per pass (multiple of 32): 48 KB of split monomials
-constexpr int kDenseBatches = 8;     // batches of kDenseThreads hypotheses a workgroup takes over the points it has staged
+constexpr int kDenseBatches = 4;     // batches of kDenseThreads hypotheses a workgroup takes over the points it has staged
+constexpr int kDenseChunkD = 672;    // points the DENSE phase stages per pass: 42 KB + 8 x 4 KB of windows + the list = 79.9 KB
 constexpr int kDensePipe = 0;        // 0: load -> MFMA -> count per tile; 2: three-stage software pipeline (measured slower)
 constexpr int kDenseWin = 256;       // uint4 words of a wavefront's LDS window: 64 records x 48 B in, 64 operands x 64 B out
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -1865,7 +1869,7 @@ __device__ __forceinline__ uint32_t dense_collect(const v16f &acc)
     return c;
 }
 
-template <bool STATS, int THREADS, int BATCHES, int PIPE>
+template <bool STATS, int THREADS, int BATCHES, int PIPE, int CHUNK = kDenseChunkD>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void ransac_count_mfma_kernel(BatchDev b, RunParams rp)
 {
     // LDS: the split monomials of a chunk of points as MFMA operands, [tile of 32 points][j][lane half][point] x 16 bytes:
@@ -1901,7 +1905,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4)))
     const float X2 = (float)fmax(dabs(bx.x2lo), dabs(bx.x2hi)) * (1.f + 0x1p-22f);
     const float Y2 = (float)fmax(dabs(bx.y2lo), dabs(bx.y2hi)) * (1.f + 0x1p-22f);
     const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
-    uint4 *s_win = s_op + (size_t)kDenseChunk * 4 + w * kDenseWin;
+    uint4 *s_win = s_op + (size_t)CHUNK * 4 + w * kDenseWin;
     struct Raw {
         u32x4 p0, p1, p2;
         int st;
@@ -1920,8 +1924,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4)))
     };
     int c0 = 0;
     do {   // the points go through LDS in chunks (one for nearly every pair); n1 = 0 still takes one pass (counts of zero)
-        const int nc = max(0, min(kDenseChunk, n1 - c0));
-        const bool first = c0 == 0, last = c0 + kDenseChunk >= n1;
+        const int nc = max(0, min(CHUNK, n1 - c0));
+        const bool first = c0 == 0, last = c0 + CHUNK >= n1;
         __syncthreads();
         for (int i = tid; i < nc; i += THREADS) {
             const double4 pd = src[c0 + i];
@@ -2097,7 +2101,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4)))
                 }
             }
         }
-        c0 += kDenseChunk;
+        c0 += CHUNK;
     } while (c0 < n1);
     __syncthreads();
     const int nl = s_nlist;
@@ -3555,10 +3559,10 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacCountMfma:
-        d.name = "ransac_count_mfma_kernel<false, 256, 8, 0>";
+        d.name = "ransac_count_mfma_kernel<false, 512, 4, 0, 672>";
         d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>);
         d.threads = kDenseThreads;
-        d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kDenseThreads / 64) * kDenseWin * 16;
+        d.dynamic_lds = (size_t)kDenseChunkD * 64 + (size_t)(kDenseThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacSurvivors:
         d.name = "ransac_survivors_kernel";
@@ -3626,12 +3630,15 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>),
                          reinterpret_cast<const void *>(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches, kDensePipe>),
 #ifdef MVS_DEBUG_HOOKS
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 0>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 0>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 2>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 2>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 2>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 0, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 0, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 2, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 2, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 2, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0, 640>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0, 672>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 2, 0, 672>),
 #endif
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true>),
@@ -3795,19 +3802,22 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>), dim3(wg_pilot, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
         if (lt) lt->mark(kKRansacCountMfma);
-        auto dense = [&](auto kern, int threads, int batches) {
-            const size_t lds = (size_t)kDenseChunk * 64 + (size_t)(threads / 64) * kDenseWin * 16;
+        auto dense = [&](auto kern, int threads, int batches, int chunk = kDenseChunkD) {
+            const size_t lds = (size_t)chunk * 64 + (size_t)(threads / 64) * kDenseWin * 16;
             const dim3 grid(((H + threads - 1) / threads + batches - 1) / batches, n_active);
             hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, b, rp);
         };
 #ifdef MVS_DEBUG_HOOKS
         // A/B of the dense phase's shape: mvs_debug_set_count_dense(10 + k)
-        if (g_count_dense == 10) dense(ransac_count_mfma_kernel<false, 256, 8, 0>, 256, 8);
-        else if (g_count_dense == 11) dense(ransac_count_mfma_kernel<false, 384, 6, 0>, 384, 6);
-        else if (g_count_dense == 12) dense(ransac_count_mfma_kernel<false, 256, 8, 2>, 256, 8);
-        else if (g_count_dense == 13) dense(ransac_count_mfma_kernel<false, 384, 6, 2>, 384, 6);
-        else if (g_count_dense == 14) dense(ransac_count_mfma_kernel<false, 512, 4, 2>, 512, 4);
-        else if (g_count_dense == 15) dense(ransac_count_mfma_kernel<false, 512, 4, 0>, 512, 4);
+        if (g_count_dense == 10) dense(ransac_count_mfma_kernel<false, 256, 8, 0, 768>, 256, 8, 768);
+        else if (g_count_dense == 11) dense(ransac_count_mfma_kernel<false, 384, 6, 0, 768>, 384, 6, 768);
+        else if (g_count_dense == 12) dense(ransac_count_mfma_kernel<false, 256, 8, 2, 768>, 256, 8, 768);
+        else if (g_count_dense == 13) dense(ransac_count_mfma_kernel<false, 384, 6, 2, 768>, 384, 6, 768);
+        else if (g_count_dense == 14) dense(ransac_count_mfma_kernel<false, 512, 4, 2, 768>, 512, 4, 768);
+        else if (g_count_dense == 15) dense(ransac_count_mfma_kernel<false, 512, 4, 0, 768>, 512, 4, 768);
+        else if (g_count_dense == 16) dense(ransac_count_mfma_kernel<false, 512, 4, 0, 640>, 512, 4, 640);
+        else if (g_count_dense == 17) dense(ransac_count_mfma_kernel<false, 512, 4, 0, 672>, 512, 4, 672);
+        else if (g_count_dense == 18) dense(ransac_count_mfma_kernel<false, 512, 2, 0, 672>, 512, 2, 672);
         else
 #endif
         if (stats)

@@ -21,7 +21,7 @@ def test_committed_bench_line_has_every_contract_field():
     # executed-work table per kernel, registers / LDS / occupancy from the runtime (mvs_kernel_info_get)
     pk = r["per_kernel"]
     assert r["kernel"] in pk and abs(pk[r["kernel"]]["ms"] - r["launch_ms"]) < 1e-6
-    for name in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel<false, 256, 8, 0>", "ransac_finish_mfma_kernel<false>",
+    for name in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel<false, 512, 4, 0, 672>", "ransac_finish_mfma_kernel<false>",
                  "ransac_finish_upper_kernel<false>", "ransac_exact_list_kernel<1264>", "match_mfma_kernel"):
         assert name in pk and pk[name]["ms"] > 0 and pk[name]["registers_runtime"] > 0, name
     w = r["work"]

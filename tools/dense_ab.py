@@ -17,8 +17,8 @@ b = capi.Batch(ctx, P, 2000, 32)
 b.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
 prm = capi.default_params(num_hypotheses=50000, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
 lib = capi.lib()
-names = {1: "product default", 10: "256 x 8, plain", 11: "384 x 6, plain", 12: "256 x 8, pipelined", 13: "384 x 6, pipelined",
-         14: "512 x 4, pipelined", 15: "512 x 4, plain"}
+names = {1: "product default", 10: "256 x 8, plain", 15: "512 x 4, plain", 16: "512 x 4, plain, 640-point chunks (2 workgroups per CU)",
+         17: "512 x 4, plain, 672-point chunks", 18: "512 x 2, plain, 672-point chunks"}
 ref = None
 out = {}
 for rep in range(2):
