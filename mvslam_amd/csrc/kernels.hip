@@ -2172,8 +2172,22 @@ __global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
     for (int i = tid; i < kSortBins; i += 256)
         s_hist[i] = 0;
     __syncthreads();
-    for (int e = tid; e < n; e += 256)
-        atomicAdd(&s_hist[min(max(cntp[in[e]], 0), kSortBins - 1)], 1);
+    // (four entries per thread and trip: the loads of a trip are independent, so the entry -> count round trips overlap; one
+    // entry per trip was 49 dependent pairs of round trips per thread and pass, most of this kernel's 0.14 ms)
+    for (int e0 = tid; e0 < n; e0 += 1024) {
+        uint32_t hh[4];
+        int cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            hh[k] = in[min(e0 + 256 * k, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            cc[k] = cntp[hh[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e0 + 256 * k < n)
+                atomicAdd(&s_hist[min(max(cc[k], 0), kSortBins - 1)], 1);
+    }
     __syncthreads();
     // exclusive prefix over the bins in DESCENDING order of the count: thread t owns a run of consecutive bins from the top
     constexpr int per = (kSortBins + 255) / 256;
@@ -2200,9 +2214,19 @@ __global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
         }
     }
     __syncthreads();
-    for (int e = tid; e < n; e += 256) {
-        const uint32_t h = in[e];
-        out[atomicAdd(&s_hist[min(max(cntp[h], 0), kSortBins - 1)], 1)] = h;
+    for (int e0 = tid; e0 < n; e0 += 1024) {
+        uint32_t hh[4];
+        int cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            hh[k] = in[min(e0 + 256 * k, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            cc[k] = cntp[hh[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e0 + 256 * k < n)
+                out[atomicAdd(&s_hist[min(max(cc[k], 0), kSortBins - 1)], 1)] = hh[k];
     }
 }
 
@@ -2390,6 +2414,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
 // in 100 k workgroups of which all but ~4 k left at once.  Grid (P, kFinUpperWg): a workgroup strides over the pair's batches.
 // Rows past M in the last tile are staged as NaN monomials: their accumulators are NaN, bit 30 set, never counted.
 constexpr int kFinUpperWg = 8;
+constexpr int kFinUpperChunk = 768;   // points staged per pass (512: three workgroups per CU, no faster)
 template <bool STATS>
 __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_upper_kernel(BatchDev b,
                                                                                                                        RunParams rp)
@@ -2411,7 +2436,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     const uint32_t *clist = b.clist + ((size_t)b.n_pairs + pair) * Hp;   // sorted by ransac_list_sort_kernel
     const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint4 *s_op = reinterpret_cast<uint4 *>(s_cpts);
-    uint4 *s_win = s_op + (size_t)kDenseChunk * 4 + w * kDenseWin;
+    uint4 *s_win = s_op + (size_t)kFinUpperChunk * 4 + w * kDenseWin;
     const PairBox bx = load_box(b, pair);
     const float X1 = (float)fmax(dabs(bx.x1lo), dabs(bx.x1hi)) * (1.f + 0x1p-22f);
     const float Y1 = (float)fmax(dabs(bx.y1lo), dabs(bx.y1hi)) * (1.f + 0x1p-22f);
@@ -2420,8 +2445,8 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long evals = 0;
-    for (int c0 = n1; c0 < Mr; c0 += kDenseChunk) {
-        const int nc = min(kDenseChunk, Mr - c0);
+    for (int c0 = n1; c0 < Mr; c0 += kFinUpperChunk) {
+        const int nc = min(kFinUpperChunk, Mr - c0);
         __syncthreads();
         for (int i = tid; i < nc; i += kFinishThreads) {
             uint4 o[2][2];
@@ -3556,7 +3581,7 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.name = "ransac_finish_upper_kernel<false>";
         d.fn = reinterpret_cast<const void *>(ransac_finish_upper_kernel<false>);
         d.threads = kFinishThreads;
-        d.dynamic_lds = (size_t)kDenseChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
+        d.dynamic_lds = (size_t)kFinUpperChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacCountMfma:
         d.name = "ransac_count_mfma_kernel<false, 512, 4, 0, 672>";
@@ -3845,7 +3870,7 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
                 hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, dim3(n_active, 1), dim3(kFinishThreads), (size_t)kDenseChunk * 64,
                                    stream, b, rp, 0);
             if (fin_grid.y > 1) {
-                const size_t lds_up = (size_t)kDenseChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
+                const size_t lds_up = (size_t)kFinUpperChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
                 if (lt) lt->mark(kKRansacCountFinishRest);
                 if (stats)
                     hipLaunchKernelGGL(ransac_finish_upper_kernel<true>, dim3(n_active, kFinUpperWg), dim3(kFinishThreads), lds_up,
