@@ -304,6 +304,13 @@ def roofline_object(table, stats, traffic, traffic_src):
                            "part (profiles/r01_fp64_issue_microbench.txt): the clock drops to ~1.87 GHz under fp64 load"}
 
 
+def make_ctx(capi, dev, args):
+    ctx = capi.Context(dev)
+    if getattr(args, "one_stream", False):
+        ctx.set_half_batches(False)
+    return ctx
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the rows either side of the path, one bounded leg each
 # ---------------------------------------------------------------------------------------------------------------------
@@ -311,7 +318,7 @@ def bench_sequence(capi, synth, np, dev, args):
     """BASELINE configs[4]: 1000-frame synthetic sequence, per frame match + two-view + PnP + triangulate, no BA."""
     frames, kp, hyp, pnp_hyp = args.seq_frames, args.kp, args.hyp, 100   # 100 = the reference's iterationsCount
     seq = synth.make_sequence(frames, n_kp=kp)
-    ctx = capi.Context(dev)
+    ctx = make_ctx(capi, dev, args)
     s = capi.Sequence(ctx, frames, kp, 32)
     s.upload(0, seq["desc"], seq["kp"], seq["n_kp"], seq["K"])
     prm = capi.default_params(num_hypotheses=hyp, sampler=capi.SAMPLER_PHILOX, seed=synth.SEED_BASE, max_error_sq=1e-2)
@@ -417,7 +424,7 @@ def bench_extract(capi, np, dev, args, images=64, width=640, height=480):
         return np.clip(img, 0, 255).astype(np.uint8)
 
     imgs = np.stack([textured(100 + i, height, width) for i in range(images)])
-    ctx = capi.Context(dev)
+    ctx = make_ctx(capi, dev, args)
     prm = capi.default_orb_params(nfeatures=args.kp)
     out_k = ctx.extract(imgs, prm)
     kernel_ms = ctx.extract_time(steps=10)
@@ -457,7 +464,7 @@ def bench_sensitivity(capi, synth, np, dev, args, pairs=64):
     inlier threshold, 64 pairs per cell, full keypoint and hypothesis counts.  Per cell: pairs/s of the whole path (HIP
     events around 3 passes), the share of the hypotheses that went through the exact solve, the pairs per mode as the
     probe decided, the share of a pair's matches the dense counting phase had to cover (n1 / M), best count."""
-    ctx = capi.Context(dev)
+    ctx = make_ctx(capi, dev, args)
     batch = capi.Batch(ctx, pairs, args.kp, 32)
     cells = []
     t_all = time.perf_counter()
@@ -511,6 +518,8 @@ def main():
                     "whole batch through pinned host buffers, double-buffered): reported as pcie_inclusive_pairs_per_s -- what "
                     "a host C++ caller of the boundary sees --, never as `value`")
     ap.add_argument("--pcie-naive", action="store_true", help="also time the synchronous pageable-memory variant")
+    ap.add_argument("--one-stream", action="store_true", help="every launch on the context's one stream (default: a batch of "
+                    ">= 64 pairs runs as two halves on two streams, mvs_ctx_set_half_batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
     ap.add_argument("--no-ref-threshold", action="store_true", help="skip the reference-threshold leg (profiling runs: "
@@ -562,7 +571,7 @@ def main():
                      seed=synth.SEED_BASE)
     prm = capi.default_params(sampler=capi.SAMPLER_PHILOX, min_inliers=8, **params_kw)
 
-    ctx = capi.Context(dev)
+    ctx = make_ctx(capi, dev, args)
     batch = capi.Batch(ctx, n_local, args.kp, 32)
     batch.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"],
                  data["global_index"])
@@ -668,6 +677,10 @@ def main():
                             % (n_local, args.kp, args.hyp),
                 "pairs_per_gpu": n_local, "keypoints": args.kp, "hypotheses": args.hyp, "noise_px": args.noise_px,
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world,
+                "launch_plan": ("every launch covers the rank's whole batch, one stream (--one-stream)" if args.one_stream else
+                                "the rank's batch runs as two independent halves on two HIP streams (mvs_ctx_set_half_batches, "
+                                "default): the latency-bound kernels of one half run under the throughput-bound kernels of "
+                                "the other; the per-kernel table and `roofline` time whole-batch launches on one stream"),
                 "threshold_note": "headline threshold 1e-2 (a consensus set exists: ~1100 inliers per pair, every stage "
                                   "runs); SURVEY 8(d)'s literal 5e-2/K00/K11 is timed in `reference_threshold`",
                 "arithmetic_note": "results are the f64 contract's, bit for bit; the pre-screen's approximate F and the inlier "
@@ -753,7 +766,7 @@ def main():
             # (b) double-buffered: two batches on two contexts (streams), pinned host buffers (mvs_host_alloc),
             # asynchronous upload -> run -> asynchronous download; batch k+1's transfers overlap batch k's kernels.
             # Every step moves the full inputs host -> device and the full outputs device -> host.
-            ctx2 = capi.Context(dev)
+            ctx2 = make_ctx(capi, dev, args)
             lanes = []
             N = args.kp
             for cx in (ctx, ctx2):

@@ -94,6 +94,11 @@ mvs_status mvs_ctx_create(int device_id, mvs_ctx **out);
 mvs_status mvs_ctx_create_on_stream(int device_id, void *hip_stream, mvs_ctx **out); /* borrow a stream */
 void mvs_ctx_destroy(mvs_ctx *ctx);
 void *mvs_ctx_stream(mvs_ctx *ctx); /* hipStream_t the kernels are launched on */
+/* A batch of >= 64 pairs goes down the pipeline as two independent halves, the second on a context-owned side stream that is
+ * forked from and joined back into the context's stream inside the call (the caller sees one stream; results are identical:
+ * pairs are independent, estimator-RANSAC.cpp:76-84 runs per pair).  enable = 0 keeps every launch on the one stream.
+ * Default: enabled. */
+mvs_status mvs_ctx_set_half_batches(mvs_ctx *ctx, int enable);
 
 /* ---- single-shot entry points (host buffers; the reference's call surface) ------ */
 

@@ -131,7 +131,7 @@ EXPORTS = [
     "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
     "mvs_batch_upload_async", "mvs_batch_download_async", "mvs_host_alloc", "mvs_host_free", "mvs_image_pair",
     "mvs_batch_gather_results", "mvs_seq_time_stages", "mvs_batch_time_kernels", "mvs_kernel_info_get",
-    "mvs_extract_time",
+    "mvs_extract_time", "mvs_ctx_set_half_batches",
 ]
 
 
@@ -157,6 +157,8 @@ def lib():
         _lib.mvs_last_error.restype = C.c_char_p
         _lib.mvs_last_error.argtypes = [C.c_void_p]
         _lib.mvs_ctx_stream.restype = C.c_void_p
+        _lib.mvs_ctx_set_half_batches.restype = C.c_int
+        _lib.mvs_ctx_set_half_batches.argtypes = [C.c_void_p, C.c_int]
         _lib.mvs_ctx_stream.argtypes = [C.c_void_p]
         _lib.mvs_ctx_destroy.argtypes = [C.c_void_p]
         _lib.mvs_batch_destroy.argtypes = [C.c_void_p]
@@ -262,6 +264,10 @@ class Context:
     @property
     def stream(self):
         return lib().mvs_ctx_stream(self._h)
+
+    def set_half_batches(self, enable):
+        """Large batches as two halves on two streams (default) or every launch on the one stream."""
+        self._check(lib().mvs_ctx_set_half_batches(self._h, C.c_int(1 if enable else 0)), "mvs_ctx_set_half_batches")
 
     def _check(self, st, what, allow_no_model=False):
         if st == MVS_OK or (allow_no_model and st == MVS_NO_MODEL):

@@ -18,6 +18,12 @@ struct mvs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second queue of a large batch: its pairs go down the pipeline as two independent halves, one per stream, so that the
+    // latency-bound kernels of one half (list sort, exact solve of the few survivors, selection, ...) run under the
+    // throughput-bound kernels of the other (enqueue_pipeline).  Forked from / joined into `stream` with the two events.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool half_batches = true;
     std::string err;
     mvs_batch *scratch = nullptr;  // batch of one pair backing the single-shot entry points
     double *d_uv1 = nullptr, *d_uv2 = nullptr;
@@ -254,8 +260,8 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if (!b->d.dense_n1 && (st = dev_alloc(b, &b->d.dense_n1, P)) != MVS_OK) return st;
     if (!b->d.ccount && (st = dev_alloc(b, &b->d.ccount, P)) != MVS_OK) return st;
     if (!b->d.pcount && (st = dev_alloc(b, &b->d.pcount, P)) != MVS_OK) return st;
-    if (!b->d.m0list && (st = dev_alloc(b, &b->d.m0list, P + 1)) != MVS_OK) return st;
-    if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 2)) != MVS_OK) return st;
+    if (!b->d.m0list && (st = dev_alloc(b, &b->d.m0list, 2 * (P + 1))) != MVS_OK) return st;   // one list per half (batch_view)
+    if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 4)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
     dev_release(b, b->d.hyp_F);
     dev_release(b, b->d.hyp_r32);
@@ -270,6 +276,7 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     b->d.hyp_cnt = hc;
     b->d.xlist = xl;
     b->d.clist = cl;
+    b->d.clist2 = cl + P * Hp;
     b->d.max_groups = G;
     return MVS_OK;
 }
@@ -709,10 +716,11 @@ mvs_status mvs_ctx_create_on_stream(int device_id, void *hip_stream, mvs_ctx **o
             return MVS_ERR_NO_DEVICE;
         }
     }
-    if (hipMalloc((void **)&c->d_small, 64 * sizeof(double)) != hipSuccess) {
-        if (c->own_stream)
-            (void)hipStreamDestroy(c->stream);
-        delete c;
+    if (hipMalloc((void **)&c->d_small, 64 * sizeof(double)) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        mvs_ctx_destroy(c);
         return MVS_ERR_HIP;
     }
     *out = c;
@@ -739,12 +747,26 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->orb_graph) (void)hipGraphExecDestroy(ctx->orb_graph);
     if (ctx->d_orb) (void)hipFree(ctx->d_orb);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 void *mvs_ctx_stream(mvs_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+mvs_status mvs_ctx_set_half_batches(mvs_ctx *ctx, int enable)
+{
+    if (!ctx)
+        return MVS_ERR_INVALID_ARG;
+    ctx->half_batches = enable != 0;
+    return MVS_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // batches
@@ -835,6 +857,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.mode = nullptr;
     d.dense_n1 = nullptr;
     d.clist = nullptr;
+    d.clist2 = nullptr;
     d.ccount = nullptr;
     d.pcount = nullptr;
     d.m0list = nullptr;
@@ -998,21 +1021,74 @@ static mvs_status check_params(const mvs_params *p)
     return MVS_OK;
 }
 
+// Pairs [first, first + count) of a batch as a batch of their own: every per-pair array advanced to its first pair, the two
+// per-launch scalars (work-list length, mode-0 pair list) given a slot per half.  The kernels index by the pair's position
+// in the launch, so they need no change; flat record indices (xlist) are relative to the view's hyp_F.
+static BatchDev batch_view(const BatchDev &b, int first, int count, int half)
+{
+    BatchDev v = b;
+    const size_t f = (size_t)first, N = (size_t)b.max_kp, Hp = (size_t)b.max_groups * kHypPerBlock;
+    v.n_pairs = count;
+    v.desc1 += f * N * b.desc_words; v.desc2 += f * N * b.desc_words;
+    v.kp1 += f * N * 2; v.kp2 += f * N * 2;
+    v.oct1 += f * N; v.oct2 += f * N;
+    v.n1 += f; v.n2 += f;
+    v.Kinv += f * 9; v.K += f * 9; v.gidx += f;
+    v.knn_train += f * N; v.knn_dist += f * N;
+    v.M += f; v.matches += f * N; v.pts += f * N * 4;
+    v.wgbest += f * b.max_groups;
+    v.hyp_F += f * Hp * kHypRec; v.hyp_r32 += f * Hp * kHypRec32;
+    v.hyp_okf += f * Hp; v.hyp_cnt += f * Hp;
+    v.bound += f; v.box += f * 8; v.mode += f;
+    v.clist += f * Hp; v.clist2 += f * Hp;
+    v.ccount += f; v.pcount += f; v.dense_n1 += f;
+    v.m0list += (size_t)half * ((size_t)b.n_pairs + 1);
+    v.xlist += f * Hp;
+    v.xcount += 2 * half;
+    v.cand_pts += f * 4 * N * 3; v.fin += f; v.inl += f * N; v.okf += f * 4 * N;
+    v.results += f; v.mask += f * N; v.points += f * N * 3; v.point_idx += f * N;
+    return v;
+}
+
+constexpr int kHalvesMinPairs = 64;   // a batch of at least this many pairs runs as two halves on two streams
+
+static void enqueue_stages(const BatchDev &d, const RunParams &rp, int n_active, bool stats, hipStream_t s, hipEvent_t *ev,
+                           LaunchTimer *lt)
+{
+    if (ev) (void)hipEventRecord(ev[0], s);
+    launch_match_topk(d, rp, n_active, s, lt);
+    if (ev) (void)hipEventRecord(ev[1], s);
+    launch_match_compact(d, rp, n_active, s, lt);
+    if (ev) (void)hipEventRecord(ev[2], s);
+    launch_ransac(d, rp, n_active, stats, s, lt);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    launch_finalize(d, rp, n_active, kFinalizeFull, s, lt);
+    if (ev) (void)hipEventRecord(ev[4], s);
+}
+
 static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_active, bool stats, hipEvent_t *ev,
                                    LaunchTimer *lt = nullptr)
 {
-    hipStream_t s = b->ctx->stream;
-    if (ev) (void)hipEventRecord(ev[0], s);
-    launch_match_topk(b->d, rp, n_active, s, lt);
-    if (ev) (void)hipEventRecord(ev[1], s);
-    launch_match_compact(b->d, rp, n_active, s, lt);
-    if (ev) (void)hipEventRecord(ev[2], s);
-    launch_ransac(b->d, rp, n_active, stats, s, lt);
-    if (ev) (void)hipEventRecord(ev[3], s);
-    launch_finalize(b->d, rp, n_active, kFinalizeFull, s, lt);
-    if (ev) (void)hipEventRecord(ev[4], s);
+    mvs_ctx *ctx = b->ctx;
+    hipStream_t s = ctx->stream;
+    const bool halves = n_active >= kHalvesMinPairs && !stats && !ev && !lt && !b->d.hyp_count && ctx->half_batches;
+    if (!halves) {
+        enqueue_stages(b->d, rp, n_active, stats, s, ev, lt);
+    } else {
+        // two independent halves: the second on the side stream, after everything already queued on the main stream, and
+        // joined back into it (the caller's next operation on the main stream sees both).  Measured on the bench batch:
+        // 2 parts +2.2 % pairs/s, +10 % frames/s on the sequence; 3 and 4 parts, a 40:60 split and a lower or higher
+        // priority of the side stream are all within noise of or below two equal halves.
+        const int na = (n_active + 1) / 2;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        enqueue_stages(batch_view(b->d, 0, na, 0), rp, na, false, s, nullptr, nullptr);
+        enqueue_stages(batch_view(b->d, na, n_active - na, 1), rp, n_active - na, false, ctx->side, nullptr, nullptr);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    }
     if (lt) lt->end();
-    HIP_TRY(b->ctx, hipGetLastError());
+    HIP_TRY(ctx, hipGetLastError());
     return MVS_OK;
 }
 

@@ -2167,7 +2167,7 @@ __global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
         return;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     const uint32_t *in = b.clist + (size_t)pair * Hp;
-    uint32_t *out = b.clist + ((size_t)b.n_pairs + pair) * Hp;
+    uint32_t *out = b.clist2 + (size_t)pair * Hp;
     const int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
     for (int i = tid; i < kSortBins; i += 256)
         s_hist[i] = 0;
@@ -2258,7 +2258,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
         s_lmax = -1;
     const int n1 = b.dense_n1[pair];
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const uint32_t *clist = b.clist + ((size_t)b.n_pairs + pair) * Hp;   // sorted by ransac_list_sort_kernel
+    const uint32_t *clist = b.clist2 + (size_t)pair * Hp;   // sorted by ransac_list_sort_kernel
     const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int ew = e0 + w * 64;   // first list entry of the wavefront (two blocks of 32)
     int h[2], ucnt0[2];
@@ -2433,7 +2433,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     if (n1 >= Mr)
         return;   // the dense phase saw every point: the counts are complete
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const uint32_t *clist = b.clist + ((size_t)b.n_pairs + pair) * Hp;   // sorted by ransac_list_sort_kernel
+    const uint32_t *clist = b.clist2 + (size_t)pair * Hp;   // sorted by ransac_list_sort_kernel
     const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint4 *s_op = reinterpret_cast<uint4 *>(s_cpts);
     uint4 *s_win = s_op + (size_t)kFinUpperChunk * 4 + w * kDenseWin;

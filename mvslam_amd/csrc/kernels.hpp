@@ -73,6 +73,7 @@ struct BatchDev {
     int32_t *mode;       // [P] 0: every hypothesis is solved exactly; 1: pre-screened, counted in single precision; 2: pre-
                          // screened, counted in double precision
     uint32_t *clist;     // [P][max_groups * 256] hypotheses of the pair the dense counting phase left alive (for the finish)
+    uint32_t *clist2;    // [P][max_groups * 256] the same list sorted by partial count (ransac_list_sort_kernel)
     int32_t *ccount;     // [P] their number
     int32_t *pcount;     // [P] entries of the pair's candidate list for the selection (ransac_survivors_kernel -> ransac_select_kernel;
                          // the list itself reuses the first half of clist, which is dead after the list sort)

@@ -420,6 +420,45 @@ def test_batch_ragged_and_empty_pairs(ctx):
     _check_batch_against_oracle(sub, sub_out, prm, n1[keep], n2[keep])
 
 
+@pytest.mark.parametrize("count,thr", [(65, 1e-2), (129, 1e-2), (64, 0.0), (97, 1e-3)])
+def test_half_batches_on_two_streams_equal_one_stream(ctx, count, thr):
+    """A batch of >= 64 pairs runs as two halves on two streams (mvs_ctx_set_half_batches; pairs are independent,
+    estimator-RANSAC.cpp:76-84 runs per pair): every output byte equals the one-stream run's, for odd counts, ragged and
+    empty pairs in either half, at the bench threshold, the reference's and one in between; the first, the middle (first
+    pair of the second half) and the last pair are checked against the oracle."""
+    n_kp, H = 400, 2048
+    data = synth.make_batch(300, count, n_kp=n_kp)
+    n1, n2 = data["n1"].copy(), data["n2"].copy()
+    half = (count + 1) // 2
+    n1[1], n2[half + 1], n1[count - 2] = 0, 5, 123      # an empty image, a pair with < 8 matches, a ragged one
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=91, max_error_sq=thr)
+    outs = []
+    for halves in (True, False, True):
+        ctx.set_half_batches(halves)
+        try:
+            b = capi.Batch(ctx, count, n_kp, 32)
+            b.upload(0, data["desc1"], data["kp1"], n1, data["desc2"], data["kp2"], n2, data["K"], data["global_index"])
+            b.run(prm)
+            b.sync()
+            outs.append(b.download())
+            b.close()
+        finally:
+            ctx.set_half_batches(True)
+    for other in outs[1:]:
+        for k in ("results", "mask", "point_idx", "points", "matches"):
+            res = outs[0]["results"]
+            if k == "results":
+                assert outs[0][k].tobytes() == other[k].tobytes()
+                continue
+            for i in range(count):
+                n = int(res["n_matches"][i]) if k in ("mask", "matches") else int(res["n_points"][i])
+                assert outs[0][k][i][:n].tobytes() == other[k][i][:n].tobytes(), (k, i)
+    keep = [0, half, count - 1]
+    sub = {k: v[keep] for k, v in data.items()}
+    sub_out = {k: v[keep] for k, v in outs[0].items()}
+    _check_batch_against_oracle(sub, sub_out, prm, n1[keep], n2[keep])
+
+
 def test_full_size_pair_50k_hypotheses(ctx):
     """BASELINE config 2: one 2000-keypoint pair, 50 000 hypotheses, checked against the oracle end to end."""
     prm = capi.default_params(num_hypotheses=50000, sampler=capi.SAMPLER_PHILOX, seed=0x5EED0000, max_error_sq=1e-2)

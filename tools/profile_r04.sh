@@ -6,15 +6,19 @@ export TMPDIR=/tmp
 TAG=${1:-r04}
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-single-pair --no-pcie"
+# --one-stream: every launch covers the whole batch, as in bench.py's live per-kernel table (mvs_batch_time_kernels); the default
+# run sends two half batches down two streams, whose launches overlap each other (a per-launch duration is then not a property
+# of the kernel).  stats_halves is the default command shape for comparison.
+B="python3 bench.py --no-cpu-baseline --no-single-pair --no-pcie --one-stream"
 # per-kernel times of the driver's command shape, one leg per CSV
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_main -o s -- $B --no-ref-threshold --sections main --steps 10 --warmup 2 > $O/bench_under_rocprof_main.json 2> $O/stats_main.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_halves -o s -- python3 bench.py --no-cpu-baseline --no-single-pair --no-pcie --no-ref-threshold --sections main --steps 10 --warmup 2 > $O/bench_under_rocprof_halves.json 2> $O/stats_halves.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_refthr -o s -- $B --sections main --steps 3 --warmup 1 > $O/bench_under_rocprof_refthr.json 2> $O/stats_refthr.err || exit 1
 for S in sequence refine extract; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$S -o s -- $B --no-ref-threshold --sections main,$S --steps 2 --warmup 1 > $O/bench_under_rocprof_$S.json 2> $O/stats_$S.err || exit 1
 done
 # counters (128 pairs per launch), one group per pass; FETCH_SIZE and WRITE_SIZE each alone (MI355X_MICROARCH.md: TCC slots)
-PB="python3 bench.py --no-cpu-baseline --no-single-pair --no-ref-threshold --no-pcie --sections main"
+PB="python3 bench.py --no-cpu-baseline --no-single-pair --no-ref-threshold --no-pcie --one-stream --sections main"
 for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
          "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INST_CYCLES_SALU" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" \
          "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR"; do

@@ -10,7 +10,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 g = "gpurun_out/prof_%s/" % tag
-for leg in ("main", "refthr", "sequence", "refine", "extract"):
+for leg in ("main", "halves", "refthr", "sequence", "refine", "extract"):
     shutil.copy(g + "stats_%s/s_kernel_stats.csv" % leg, "profiles/r04_rocprofv3_kernel_stats_%s.csv" % leg)
     shutil.copy(g + "bench_under_rocprof_%s.json" % leg, "profiles/bench_r04_under_rocprof_%s.json" % leg)
 shutil.copy(g + "%s_pmc_summary.json" % tag, "profiles/r04_pmc_summary.json")
