@@ -1078,7 +1078,11 @@ static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_acti
         // two independent halves: the second on the side stream, after everything already queued on the main stream, and
         // joined back into it (the caller's next operation on the main stream sees both).  Measured on the bench batch:
         // 2 parts +2.2 % pairs/s, +10 % frames/s on the sequence; 3 and 4 parts, a 40:60 split and a lower or higher
-        // priority of the side stream are all within noise of or below two equal halves.
+        // priority of the side stream are all within noise of or below two equal halves.  The kernel trace shows the heavy
+        // kernels of the two halves serialising or sharing the chip at the same total rate and the two latency-bound tails
+        // (list sort ... selection ... triangulation, ~0.8 ms per half whatever its size) largely coinciding; holding the
+        // second half's counting back with an event until the first half's dense phase has drained puts it under the first
+        // half's tail but leaves the second tail exposed: same step time within 1 % (measured, not kept).
         const int na = (n_active + 1) / 2;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
