@@ -260,6 +260,7 @@ static mvs_status ensure_groups(mvs_batch *b, int num_hypotheses)
     if (!b->d.dense_n1 && (st = dev_alloc(b, &b->d.dense_n1, P)) != MVS_OK) return st;
     if (!b->d.ccount && (st = dev_alloc(b, &b->d.ccount, P)) != MVS_OK) return st;
     if (!b->d.pcount && (st = dev_alloc(b, &b->d.pcount, P)) != MVS_OK) return st;
+    if (!b->d.cpos && (st = dev_alloc(b, &b->d.cpos, P * kSortBins)) != MVS_OK) return st;
     if (!b->d.m0list && (st = dev_alloc(b, &b->d.m0list, 2 * (P + 1))) != MVS_OK) return st;   // one list per half (batch_view)
     if (!b->d.xcount && (st = dev_alloc(b, &b->d.xcount, 4)) != MVS_OK) return st;
     dev_release(b, b->d.wgbest);
@@ -858,6 +859,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.dense_n1 = nullptr;
     d.clist = nullptr;
     d.clist2 = nullptr;
+    d.cpos = nullptr;
     d.ccount = nullptr;
     d.pcount = nullptr;
     d.m0list = nullptr;
@@ -1040,7 +1042,7 @@ static BatchDev batch_view(const BatchDev &b, int first, int count, int half)
     v.hyp_F += f * Hp * kHypRec; v.hyp_r32 += f * Hp * kHypRec32;
     v.hyp_okf += f * Hp; v.hyp_cnt += f * Hp;
     v.bound += f; v.box += f * 8; v.mode += f;
-    v.clist += f * Hp; v.clist2 += f * Hp;
+    v.clist += f * Hp; v.clist2 += f * Hp; v.cpos += f * kSortBins;
     v.ccount += f; v.pcount += f; v.dense_n1 += f;
     v.m0list += (size_t)half * ((size_t)b.n_pairs + 1);
     v.xlist += f * Hp;

@@ -2153,8 +2153,8 @@ void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStre
 
 // The pair's list in the order of the dense phase's counts, largest first (counting sort on the count, one workgroup per
 // pair; the sorted list is the second half of clist).  The finish then meets the likely winners in its first batches.
-constexpr int kSortBins = kMaxKp + 1;
-__global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
+constexpr int kSortThreads = 1024;   // (256 threads: 0.10 ms per 512 pairs, a chain of entry -> count round trips per thread)
+__global__ __launch_bounds__(kSortThreads) void ransac_list_sort_kernel(BatchDev b)
 {
     __shared__ int s_hist[kSortBins];
     __shared__ int s_scan[256];
@@ -2169,65 +2169,76 @@ __global__ __launch_bounds__(256) void ransac_list_sort_kernel(BatchDev b)
     const uint32_t *in = b.clist + (size_t)pair * Hp;
     uint32_t *out = b.clist2 + (size_t)pair * Hp;
     const int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
-    for (int i = tid; i < kSortBins; i += 256)
+    for (int i = tid; i < kSortBins; i += kSortThreads)
         s_hist[i] = 0;
     __syncthreads();
     // (four entries per thread and trip: the loads of a trip are independent, so the entry -> count round trips overlap; one
     // entry per trip was 49 dependent pairs of round trips per thread and pass, most of this kernel's 0.14 ms)
-    for (int e0 = tid; e0 < n; e0 += 1024) {
+    for (int e0 = tid; e0 < n; e0 += 4 * kSortThreads) {
         uint32_t hh[4];
         int cc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            hh[k] = in[min(e0 + 256 * k, n - 1)];
+            hh[k] = in[min(e0 + kSortThreads * k, n - 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             cc[k] = cntp[hh[k]];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (e0 + 256 * k < n)
+            if (e0 + kSortThreads * k < n)
                 atomicAdd(&s_hist[min(max(cc[k], 0), kSortBins - 1)], 1);
     }
     __syncthreads();
-    // exclusive prefix over the bins in DESCENDING order of the count: thread t owns a run of consecutive bins from the top
+    // exclusive prefix over the bins in DESCENDING order of the count: thread t < 256 owns a run of consecutive bins from the top
     constexpr int per = (kSortBins + 255) / 256;
     int run = 0;
-    for (int k = 0; k < per; ++k) {
-        const int bin = kSortBins - 1 - (tid * per + k);
-        run += bin >= 0 ? s_hist[bin] : 0;
+    if (tid < 256) {
+        for (int k = 0; k < per; ++k) {
+            const int bin = kSortBins - 1 - (tid * per + k);
+            run += bin >= 0 ? s_hist[bin] : 0;
+        }
+        s_scan[tid] = run;
     }
-    s_scan[tid] = run;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-        const int v = tid >= o ? s_scan[tid - o] : 0;
+        const int v = tid < 256 && tid >= o ? s_scan[tid - o] : 0;
         __syncthreads();
-        s_scan[tid] += v;
+        if (tid < 256)
+            s_scan[tid] += v;
         __syncthreads();
     }
-    int off = s_scan[tid] - run;
-    for (int k = 0; k < per; ++k) {
-        const int bin = kSortBins - 1 - (tid * per + k);
-        if (bin >= 0) {
-            const int c = s_hist[bin];
-            s_hist[bin] = off;
-            off += c;
+    if (tid < 256) {
+        int off = s_scan[tid] - run;
+        for (int k = 0; k < per; ++k) {
+            const int bin = kSortBins - 1 - (tid * per + k);
+            if (bin >= 0) {
+                const int c = s_hist[bin];
+                s_hist[bin] = off;
+                off += c;
+            }
         }
     }
     __syncthreads();
-    for (int e0 = tid; e0 < n; e0 += 1024) {
+    for (int e0 = tid; e0 < n; e0 += 4 * kSortThreads) {
         uint32_t hh[4];
         int cc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            hh[k] = in[min(e0 + 256 * k, n - 1)];
+            hh[k] = in[min(e0 + kSortThreads * k, n - 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             cc[k] = cntp[hh[k]];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (e0 + 256 * k < n)
+            if (e0 + kSortThreads * k < n)
                 out[atomicAdd(&s_hist[min(max(cc[k], 0), kSortBins - 1)], 1)] = hh[k];
     }
+    __syncthreads();
+    // every bin's offset has moved to the END of its run: s_hist[c] = entries with a count >= c.  Counts never exceed the
+    // points the dense phase saw (<= M): the finish asks for c <= M only
+    int32_t *cp = b.cpos + (size_t)pair * kSortBins;
+    for (int i = tid; i <= min(M, kSortBins - 1); i += kSortThreads)
+        cp[i] = s_hist[i];
 }
 
 // The FINISH on the matrix cores.  What the dense phase could not drop against the PILOT's bound (a quarter of the
@@ -2413,10 +2424,11 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
 // ransac_finish_mfma_kernel here: every point against both thresholds with five packed instructions per two accumulators,
 // in 100 k workgroups of which all but ~4 k left at once.  Grid (P, kFinUpperWg): a workgroup strides over the pair's batches.
 // Rows past M in the last tile are staged as NaN monomials: their accumulators are NaN, bit 30 set, never counted.
-constexpr int kFinUpperWg = 8;
+constexpr int kFinUpperWg = 4;
+constexpr int kFinUpperThreads = 512;   // 8 wavefronts share the staged points: 4 wavefronts per SIMD at two workgroups per CU
 constexpr int kFinUpperChunk = 768;   // points staged per pass (512: three workgroups per CU, no faster)
 template <bool STATS>
-__global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_upper_kernel(BatchDev b,
+__global__ __launch_bounds__(kFinUpperThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_upper_kernel(BatchDev b,
                                                                                                                        RunParams rp)
 {
     extern __shared__ __attribute__((aligned(16))) double s_cpts[];
@@ -2424,17 +2436,24 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     const int M = min(b.M[pair], b.max_kp);
     if (M < 8 || b.mode[pair] != 1)
         return;
-    const int n_list = b.ccount[pair];
-    const int n_batches = (n_list + kFinishThreads - 1) / kFinishThreads;
-    if (1 + (int)blockIdx.y >= n_batches)
-        return;   // batch 0 belongs to ransac_finish_mfma_kernel
     const int n1 = b.dense_n1[pair];
     const int Mr = (M + 31) & ~31;
     if (n1 >= Mr)
         return;   // the dense phase saw every point: the counts are complete
+    const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Only a PREFIX of the sorted list can still reach the bound: an entry with partial count u over the first n1 points ends
+    // at u + (M - n1) at most, the list is sorted by u, and ransac_list_sort_kernel left the number of entries with u >= c in
+    // cpos[c].  The rest of the list (most of it: every hypothesis with 32 chance inliers among the first n1 points is on it)
+    // is not walked at all -- it used to cost one memory round trip per dead batch and chunk.
+    const int cmin = Bnow - (M - n1);
+    const int n_all = b.ccount[pair];
+    const int n_list = cmin <= 0 ? n_all : min(n_all, b.cpos[(size_t)pair * kSortBins + min(cmin, min(M, kSortBins - 1))]);
+    // (the first kFinishThreads entries belong to ransac_finish_mfma_kernel; batches of kFinUpperThreads entries from there)
+    const int n_batches = (max(n_list - kFinishThreads, 0) + kFinUpperThreads - 1) / kFinUpperThreads;
+    if ((int)blockIdx.y >= n_batches)
+        return;
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     const uint32_t *clist = b.clist2 + (size_t)pair * Hp;   // sorted by ransac_list_sort_kernel
-    const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint4 *s_op = reinterpret_cast<uint4 *>(s_cpts);
     uint4 *s_win = s_op + (size_t)kFinUpperChunk * 4 + w * kDenseWin;
     const PairBox bx = load_box(b, pair);
@@ -2445,10 +2464,34 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long evals = 0;
+    // The entries of a batch sit behind dependent global round trips (list entry -> its count and record).  Only the list's live
+    // prefix is walked (n_list above), so nearly every batch goes on: its count AND record are requested one batch ahead, the list
+    // entry two, and the first requests of a chunk go out before the chunk's points are staged (the kernel waited in s_waitcnt for
+    // 76 % of its wavefront cycles: profiles/r04_pmc_summary.json)
+    struct Ent {
+        int h, u;
+        bool have;
+        float4 q0, q1, q2;
+    };
+    auto fetch_h = [&](int batch, Ent &en) __attribute__((always_inline)) {
+        const int e = kFinishThreads + batch * kFinUpperThreads + w * 64 + lane;   // this lane's list entry
+        en.have = batch < n_batches && e < n_list;
+        en.h = (int)clist[en.have ? e : 0];   // (unconditional load of a clamped index: no wait at the select)
+    };
+    auto fetch_rest = [&](Ent &en) __attribute__((always_inline)) {
+        const size_t rec = (size_t)pair * Hp + (en.have ? en.h : 0);
+        en.u = b.hyp_cnt[rec];   // upper count over the points seen so far
+        const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_r32 + rec * kHypRec32);
+        en.q0 = fr4[0], en.q1 = fr4[1], en.q2 = fr4[2];
+    };
     for (int c0 = n1; c0 < Mr; c0 += kFinUpperChunk) {
         const int nc = min(kFinUpperChunk, Mr - c0);
+        Ent nxt, nn;   // next batch: everything; the one after: its list entry
+        fetch_h(blockIdx.y, nxt);
+        fetch_h(blockIdx.y + gridDim.y, nn);
+        fetch_rest(nxt);   // (a later chunk re-reads the count this lane stored in the chunk before: same thread, program order)
         __syncthreads();
-        for (int i = tid; i < nc; i += kFinishThreads) {
+        for (int i = tid; i < nc; i += kFinUpperThreads) {
             uint4 o[2][2];
             if (c0 + i < M) {
                 const double4 pd = src[c0 + i];
@@ -2468,27 +2511,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
         }
         __syncthreads();
         const int left0 = M - c0;   // points of the pair not yet seen when this chunk starts (>= 1)
-        // the entries of a batch sit behind dependent global round trips (list entry -> its count -> its record): the list
-        // entries are requested two batches ahead and the counts one (the kernel waited in s_waitcnt for 76 % of its
-        // wavefront cycles: profiles/r04_pmc_summary.json)
-        struct Ent {
-            int h, u;
-            bool have;
-        };
-        auto fetch_h = [&](int batch, Ent &en) __attribute__((always_inline)) {
-            const int e = batch * kFinishThreads + w * 64 + lane;   // this lane's list entry
-            en.have = batch < n_batches && e < n_list;
-            en.h = (int)clist[en.have ? e : 0];   // (unconditional load of a clamped index: no wait at the select)
-        };
-        auto fetch_rest = [&](Ent &en) __attribute__((always_inline)) {
-            const size_t rec = (size_t)pair * Hp + (en.have ? en.h : 0);
-            en.u = b.hyp_cnt[rec];   // upper count over the points seen so far
-        };
-        Ent nxt, nn;   // next batch: everything; the one after: its list entry
-        fetch_h(1 + blockIdx.y, nxt);
-        fetch_h(1 + blockIdx.y + gridDim.y, nn);
-        fetch_rest(nxt);
-        for (int batch = 1 + blockIdx.y; batch < n_batches; batch += gridDim.y) {
+        for (int batch = blockIdx.y; batch < n_batches; batch += gridDim.y) {
             const Ent cur = nxt;
             nxt.have = nn.have;
             nxt.h = nn.h;
@@ -2502,10 +2525,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
             if (__ballot(on_l) == 0ull)
                 continue;   // (wave-uniform) none of the 64 entries can still reach the bound
             {
-                // (the records only for the batches that go on: most leave at the test above, and fetching every batch's
-                // records ahead of time doubled this kernel's time)
-                const float4 *fr4 = reinterpret_cast<const float4 *>(b.hyp_r32 + rec_l * kHypRec32);
-                const float4 q0 = fr4[0], q1 = fr4[1], q2 = fr4[2];
+                const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2;
                 const float fr[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
                 float sc = dense_scale(q2.y, dense_T(fr, X1, Y1, X2, Y2), on_l);
                 float big = 0.f;
@@ -3580,8 +3600,8 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
     case kKRansacCountFinishRest:
         d.name = "ransac_finish_upper_kernel<false>";
         d.fn = reinterpret_cast<const void *>(ransac_finish_upper_kernel<false>);
-        d.threads = kFinishThreads;
-        d.dynamic_lds = (size_t)kFinUpperChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
+        d.threads = kFinUpperThreads;
+        d.dynamic_lds = (size_t)kFinUpperChunk * 64 + (size_t)(kFinUpperThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacCountMfma:
         d.name = "ransac_count_mfma_kernel<false, 512, 4, 0, 672>";
@@ -3852,7 +3872,7 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
         if (lt) lt->mark(kKRansacCountFinish);
         const dim3 fin_grid(n_active, (H + kFinishThreads - 1) / kFinishThreads);   // workgroups past the list's end leave at once
         if (g_count_dense != 2)
-            hipLaunchKernelGGL(ransac_list_sort_kernel, dim3(n_active), dim3(256), 0, stream, b);
+            hipLaunchKernelGGL(ransac_list_sort_kernel, dim3(n_active), dim3(kSortThreads), 0, stream, b);
 #ifdef MVS_DEBUG_HOOKS
         if (g_count_dense == 2) {   // diagnostics: the vector finish (ransac_count32_kernel, phase 2)
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 2>), dim3(wg, n_active),
@@ -3870,13 +3890,13 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
                 hipLaunchKernelGGL(ransac_finish_mfma_kernel<false>, dim3(n_active, 1), dim3(kFinishThreads), (size_t)kDenseChunk * 64,
                                    stream, b, rp, 0);
             if (fin_grid.y > 1) {
-                const size_t lds_up = (size_t)kFinUpperChunk * 64 + (size_t)(kFinishThreads / 64) * kDenseWin * 16;
+                const size_t lds_up = (size_t)kFinUpperChunk * 64 + (size_t)(kFinUpperThreads / 64) * kDenseWin * 16;
                 if (lt) lt->mark(kKRansacCountFinishRest);
                 if (stats)
-                    hipLaunchKernelGGL(ransac_finish_upper_kernel<true>, dim3(n_active, kFinUpperWg), dim3(kFinishThreads), lds_up,
+                    hipLaunchKernelGGL(ransac_finish_upper_kernel<true>, dim3(n_active, kFinUpperWg), dim3(kFinUpperThreads), lds_up,
                                        stream, b, rp);
                 else
-                    hipLaunchKernelGGL(ransac_finish_upper_kernel<false>, dim3(n_active, kFinUpperWg), dim3(kFinishThreads), lds_up,
+                    hipLaunchKernelGGL(ransac_finish_upper_kernel<false>, dim3(n_active, kFinUpperWg), dim3(kFinUpperThreads), lds_up,
                                        stream, b, rp);
             }
         }

@@ -8,6 +8,7 @@
 namespace mvs {
 
 constexpr int kMaxKp = 4096;          // capacity limit of one image (LDS lists in finalize/compact)
+constexpr int kSortBins = kMaxKp + 1;  // counts 0 .. kMaxKp (ransac_list_sort_kernel)
 constexpr int kHypPerBlock = 256;     // hypotheses per RANSAC workgroup (one per lane, 4 waves)
 constexpr int kMaxDescWords = 16;     // descriptor <= 64 bytes
 constexpr int kHypRec = 10;           // doubles per hypothesis record: F[9], counting threshold (thr + band)
@@ -74,6 +75,8 @@ struct BatchDev {
                          // screened, counted in double precision
     uint32_t *clist;     // [P][max_groups * 256] hypotheses of the pair the dense counting phase left alive (for the finish)
     uint32_t *clist2;    // [P][max_groups * 256] the same list sorted by partial count (ransac_list_sort_kernel)
+    int32_t *cpos;       // [P][kSortBins] cpos[c] = entries of the sorted list with a partial count >= c (the sort's own
+                         // offsets): the finish reads how long the list's live prefix is instead of walking the dead rest
     int32_t *ccount;     // [P] their number
     int32_t *pcount;     // [P] entries of the pair's candidate list for the selection (ransac_survivors_kernel -> ransac_select_kernel;
                          // the list itself reuses the first half of clist, which is dead after the list sort)
