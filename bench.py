@@ -221,8 +221,9 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
             peak, bound = BF16_MFMA_PEAK_TFLOPS, "mfma_bf16"
         elif name.startswith("ransac_finish_mfma_kernel"):
             # the same tile product for the few per cent of the hypotheses the dense phase leaves: every point against the lower
-            # threshold, the points behind the dense phase against the upper one as well
-            ev = stats.get("score_evals_executed_mfma_finish", 0)
+            # threshold, the points behind the dense phase against the upper one as well; <., true> is the PILOT: the first 1024
+            # hypotheses of a pair on every point, both thresholds, ahead of the dense phase
+            ev = stats.get("score_evals_executed_mfma_pilot" if name.endswith(", true>") else "score_evals_executed_mfma_finish", 0)
             fl_alg = fl_exec = ev * PER_EVAL_MFMA
             e["evals_executed"] = int(ev)
             e["evals_executed_frac"] = round(ev / max(stats["score_evals"], 1), 4)
@@ -241,7 +242,7 @@ def kernel_table(capi, ctx, batch, prm, stats, n_local, steps=3):
         elif name.startswith("ransac_count_kernel") or name.startswith("ransac_count2_kernel"):
             ev64 = stats["score_evals_executed"] - stats["score_evals_executed_f32"] - \
                 stats.get("score_evals_executed_mfma", 0) - stats.get("score_evals_executed_mfma_finish", 0) - \
-                stats.get("score_evals_executed_mfma_rest", 0)
+                stats.get("score_evals_executed_mfma_rest", 0) - stats.get("score_evals_executed_mfma_pilot", 0)
             fl_alg = stats["score_evals"] * PER_EVAL
             fl_exec = ev64 * PER_EVAL
             e["evals_executed_frac"] = round(ev64 / max(stats["score_evals"], 1), 4)
@@ -296,6 +297,7 @@ def roofline_object(table, stats, traffic, traffic_src):
                  "evals_executed_mfma_dense": int(stats.get("score_evals_executed_mfma", 0)),
                  "evals_executed_mfma_finish": int(stats.get("score_evals_executed_mfma_finish", 0)),
                  "evals_executed_mfma_finish_rest": int(stats.get("score_evals_executed_mfma_rest", 0)),
+                 "evals_executed_mfma_pilot": int(stats.get("score_evals_executed_mfma_pilot", 0)),
                  "max_sweeps9": int(stats.get("max_sweeps9", 0)),
                  "dense_points_over_matches": round(stats["dense_points"] / stats["matches_mode1"], 3)
                  if stats.get("matches_mode1") else None},

@@ -283,6 +283,8 @@ typedef struct mvs_work_stats {
                                      every hypothesis is counted on before anything can be dropped) */
     int64_t score_evals_executed_mfma_rest; /* evaluations of the finish's second launch (upper counts of the rest of the list);
                                      included in score_evals_executed, not in score_evals_executed_mfma_finish */
+    int64_t score_evals_executed_mfma_pilot; /* evaluations of the matrix-core pilot (the first 1024 hypotheses of every pair in
+                                     mode 1 on every match, both bounds): included in score_evals_executed */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
 

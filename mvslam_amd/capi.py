@@ -109,7 +109,8 @@ class WorkStats(C.Structure):
                                                                  ("score_evals_executed_mfma", C.c_int64),
                                                                  ("score_evals_executed_mfma_finish", C.c_int64),
                                                                  ("max_sweeps9", C.c_int64), ("dense_points", C.c_int64),
-                                                                 ("matches_mode1", C.c_int64), ("score_evals_executed_mfma_rest", C.c_int64)]
+                                                                 ("matches_mode1", C.c_int64), ("score_evals_executed_mfma_rest", C.c_int64),
+                                                                 ("score_evals_executed_mfma_pilot", C.c_int64)]
 
 
 class KernelInfo(C.Structure):

@@ -839,7 +839,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     ALLOC(d.mask, P * N);
     ALLOC(d.points, P * N * 3);
     ALLOC(d.point_idx, P * N);
-    ALLOC(d.stats, 8);
+    ALLOC(d.stats, 16);
 #undef ALLOC
     if (st != MVS_OK) {
         mvs_batch_destroy(b);
@@ -1364,25 +1364,26 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
     b->d.hyp_count = nullptr;
     b->d.hyp_residual = nullptr;
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 8 * sizeof(unsigned long long), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d.stats, 0, 16 * sizeof(unsigned long long), s));
     st = enqueue_pipeline(b, to_run(*params), n_active, true, nullptr);
     if (st != MVS_OK)
         return st;
     HIP_TRY(ctx, sync_stream(ctx));
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIP_TRY(ctx, hipMemcpy(h, b->d.stats, sizeof(h), hipMemcpyDeviceToHost));
     std::vector<mvs_pair_result> res(n_active);
     HIP_TRY(ctx, hipMemcpy(res.data(), b->d.results, n_active * sizeof(mvs_pair_result), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     out->rotations9 = (int64_t)h[0];
     out->pairs9 = (int64_t)h[1];
-    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4] + h[5] + h[7]);   // double-, single-precision and matrix-core counting
+    out->score_evals_executed = (int64_t)(h[2] + h[3] + h[4] + h[5] + h[7] + h[8]);   // double-, single-precision and matrix-core counting
+    out->score_evals_executed_mfma_pilot = (int64_t)h[8];
     out->score_evals_executed_mfma_rest = (int64_t)h[7];
     out->score_evals_executed_f32 = (int64_t)h[3];
     out->score_evals_executed_mfma = (int64_t)h[4];
     out->score_evals_executed_mfma_finish = (int64_t)h[5];
     out->max_sweeps9 = (int64_t)h[6];
-    if (b->d.mode && b->d.xcount && h[2] + h[3] + h[4] + h[5] > 0) {   // the pre-screened stage ran: its bookkeeping
+    if (b->d.mode && b->d.xcount && h[2] + h[3] + h[4] + h[5] + h[8] > 0) {   // the pre-screened stage ran: its bookkeeping
         std::vector<int32_t> mode(n_active);
         uint32_t xc[2] = {0, 0};
         HIP_TRY(ctx, hipMemcpy(mode.data(), b->d.mode, n_active * sizeof(int32_t), hipMemcpyDeviceToHost));

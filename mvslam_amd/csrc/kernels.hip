@@ -1456,7 +1456,8 @@ __device__ __forceinline__ int count_pair32(const Rec32 &r, const float4 &A, con
     return __popcll(__ballot(__builtin_fabsf(e.x) < thr)) + __popcll(__ballot(__builtin_fabsf(e.y) < thr));
 }
 
-constexpr int kPilotHyp = 256;   // hypotheses of a pair the pilot counts in full
+constexpr int kPilotHyp = 256;   // hypotheses of a pair the (vector, diagnostics) pilot counts in full
+constexpr int kPilotMfmaHyp = 1024;   // ... and the matrix-core pilot (ransac_finish_mfma_kernel<., true>)
 // phase: 0 = the PILOT (hypotheses [0, kPilotHyp) counted in full: their best lower bound is the pair's first bound, from
 // which the dense phase derives how many points it has to look at); 2 = the FINISH (every hypothesis resumes behind the
 // points[0, n1) the dense matrix-core phase has already counted: hyp_cnt holds that partial upper-bound count); 1 = everything
@@ -1715,9 +1716,10 @@ constexpr int kDenseWin = 256;       // uint4 words of a wavefront's LDS window:
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ int dense_points(int M, int B0)
+constexpr int kDenseMargin = 64;   // points beyond M - B0 the dense phase covers for every hypothesis (multiple of 32)
+__device__ __forceinline__ int dense_points(int M, int B0, int margin)
 {
-    const int want = ((M - B0 + 32 + 31) / 32) * 32;
+    const int want = ((M - B0 + margin + 31) / 32) * 32;
     return max(0, min(want, (M / 32) * 32));
 }
 
@@ -1870,7 +1872,7 @@ __device__ __forceinline__ uint32_t dense_collect(const v16f &acc)
 }
 
 template <bool STATS, int THREADS, int BATCHES, int PIPE, int CHUNK = kDenseChunkD>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void ransac_count_mfma_kernel(BatchDev b, RunParams rp)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void ransac_count_mfma_kernel(BatchDev b, RunParams rp, int margin)
 {
     // LDS: the split monomials of a chunk of points as MFMA operands, [tile of 32 points][j][lane half][point] x 16 bytes:
     // the lanes of a wavefront read consecutive 16-byte words (no bank conflicts), two ds_read_b128 per tile; behind them one
@@ -1888,7 +1890,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4)))
     if (tid == 0)
         s_nlist = 0;   // (the first barrier of the chunk loop orders it)
     const int B0 = b.bound[pair];   // final since the pilot launch has completed
-    const int n1 = dense_points(M, B0);
+    const int n1 = dense_points(M, B0, margin);
     if (blockIdx.x == 0 && tid == 0)
         b.dense_n1[pair] = n1;
     const int H = rp.num_hypotheses;
@@ -2250,7 +2252,12 @@ __global__ __launch_bounds__(kSortThreads) void ransac_list_sort_kernel(BatchDev
 // partial counts).  An entry that is dropped can never matter: its upper bound is below a lower bound of another hypothesis.
 // ransac_survivors_kernel compares U with the final bound as before.  The points past M in the last tile are staged as zero
 // monomials: their residual is exactly 0, so each is counted once by every positive threshold and subtracted again.
-template <bool STATS>
+// PILOT (round 4): the same kernel over the pair's FIRST kPilotMfmaHyp hypotheses instead of list entries -- both counts over
+// every point, nothing assumed about them: the largest lower bound is the pair's first bound B0, from which the dense phase
+// derives how many points it has to look at.  Round 3's pilot counted 256 hypotheses in packed binary32 vector code (0.13 ms per
+// 512 pairs); four times as many on the matrix cores cost less and find a better B0 (the dense phase's work is M - B0 + 32
+// points for every hypothesis).
+template <bool STATS, bool PILOT = false>
 __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void ransac_finish_mfma_kernel(BatchDev b,
                                                                                                                      RunParams rp,
                                                                                                                      int batch0)
@@ -2261,13 +2268,15 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
     const int M = min(b.M[pair], b.max_kp);
     if (M < 8 || b.mode[pair] != 1)
         return;
-    const int n_list = b.ccount[pair];
+    const int n_list = PILOT ? min(rp.num_hypotheses, (int)gridDim.y * kFinishThreads) : b.ccount[pair];   // (the pilot's grid says how many)
     const int e0 = (batch0 + blockIdx.y) * kFinishThreads;   // first list entry of the workgroup
     if (e0 >= n_list)
         return;
     if (tid == 0)
         s_lmax = -1;
-    const int n1 = b.dense_n1[pair];
+    // (pilot: only the LOWER bounds matter -- the first bound of the pair --, so every point takes the branch in front of n1:
+    // one indicator per accumulator instead of two, no exit tests: there is no bound yet to test against)
+    const int n1 = PILOT ? ((M + 31) & ~31) : b.dense_n1[pair];
     const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
     const uint32_t *clist = b.clist2 + (size_t)pair * Hp;   // sorted by ransac_list_sort_kernel
     const int Bnow = __hip_atomic_load(b.bound + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2277,6 +2286,12 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int e = ew + 32 * c + col;
+        if (PILOT) {   // hypothesis e itself; only records the pre-screen certified (state: approximate F) take part
+            h[c] = e < n_list ? e : 0;
+            ucnt0[c] = 0;
+            on[c] = e < n_list && b.hyp_okf[(size_t)pair * Hp + h[c]] == kPsApprox;
+            continue;
+        }
         h[c] = e < n_list ? (int)clist[e] : 0;
         ucnt0[c] = b.hyp_cnt[(size_t)pair * Hp + h[c]];   // the dense phase's count over [0, n1)
         // still able to reach the bound as it stands now?
@@ -2394,14 +2409,15 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
         L -= lpos[c] ? npad : 0;
         if (half == 0 && on[c]) {
             const size_t rec = (size_t)pair * Hp + h[c];
-            b.hyp_cnt[rec] = ucnt0[c] + U;   // + the dense phase's count over [0, n1)
+            if (!PILOT)
+                b.hyp_cnt[rec] = ucnt0[c] + U;   // + the dense phase's count over [0, n1)
             if (!wave_dead)
                 lbest = max(lbest, L);
         }
         if (STATS && b.stats) {
             const unsigned long long ma = __ballot(wave_live && half == 0);   // a live wavefront computes all its columns
             if (lane == 0 && ma)
-                atomicAdd(&b.stats[5], (unsigned long long)__popcll(ma) * (unsigned long long)(32 * ntile));
+                atomicAdd(&b.stats[PILOT ? 8 : 5], (unsigned long long)__popcll(ma) * (unsigned long long)(32 * ntile));
         }
     }
 #pragma unroll
@@ -2425,6 +2441,7 @@ __global__ __launch_bounds__(kFinishThreads) __attribute__((amdgpu_waves_per_eu(
 // in 100 k workgroups of which all but ~4 k left at once.  Grid (P, kFinUpperWg): a workgroup strides over the pair's batches.
 // Rows past M in the last tile are staged as NaN monomials: their accumulators are NaN, bit 30 set, never counted.
 constexpr int kFinUpperWg = 4;
+constexpr int kFinUpperTest = 2;        // tiles of 32 points between two exit tests of a wavefront (a power of two)
 constexpr int kFinUpperThreads = 512;   // 8 wavefronts share the staged points: 4 wavefronts per SIMD at two workgroups per CU
 constexpr int kFinUpperChunk = 768;   // points staged per pass (512: three workgroups per CU, no faster)
 template <bool STATS>
@@ -2561,9 +2578,11 @@ __global__ __launch_bounds__(kFinUpperThreads) __attribute__((amdgpu_waves_per_e
             const int nt = nc >> 5;
             int t = 0;
             for (; t < nt; ++t) {
-                if (t > 0 && (t & 7) == 0) {
-                    // exit test every 256 points: the list is sorted, the 64 entries of a wavefront are of one quality and
-                    // die together.  A dead entry keeps an upper count below the bound (what it has + what is left < bound)
+                if (t > 0 && (t & (kFinUpperTest - 1)) == 0) {
+                    // exit test every 64 points: the list is sorted, the 64 entries of a wavefront are of one quality and
+                    // die together -- and most of the live prefix sits just above the cut (a few dozen counts of slack),
+                    // so most wavefronts leave at the first or second test (every 256 points: 0.30 ms, 977 M evaluations).
+                    // A dead entry keeps an upper count below the bound (what it has + what is left < bound)
                     bool any = false;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
@@ -3586,13 +3605,13 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.dynamic_lds = count_lds_bytes(max_kp);
         break;
     case kKRansacCountPilot:
-        d.name = "ransac_count32_kernel<768, 4, 4, 0, false>";
-        d.fn = reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>);
-        d.threads = kCnt32Threads;
-        d.dynamic_lds = count32_lds_bytes(max_kp);
+        d.name = "ransac_finish_mfma_kernel<false, true>";   // the pilot
+        d.fn = reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false, true>);
+        d.threads = kFinishThreads;
+        d.dynamic_lds = (size_t)kDenseChunk * 64;
         break;
     case kKRansacCountFinish:
-        d.name = "ransac_finish_mfma_kernel<false>";
+        d.name = "ransac_finish_mfma_kernel<false, false>";
         d.fn = reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>);
         d.threads = kFinishThreads;
         d.dynamic_lds = (size_t)kDenseChunk * 64;
@@ -3687,6 +3706,8 @@ hipError_t prepare_kernels()
 #endif
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true>),
+                         reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false, true>),
+                         reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true, true>),
                          reinterpret_cast<const void *>(ransac_finish_upper_kernel<false>),
                          reinterpret_cast<const void *>(ransac_finish_upper_kernel<true>),
                          reinterpret_cast<const void *>(ransac_select_kernel)};
@@ -3794,7 +3815,17 @@ static void launch_pruned_scoring(const BatchDev &b, const RunParams &rp, int n_
 #ifdef MVS_DEBUG_HOOKS
 static int g_count_dense = 1;   // 1 = pilot + dense matrix-core phase + matrix-core finish; diagnostics: 0 = one
                                 // ransac_count32 launch, 2 = pilot + dense phase + the vector finish (ransac_count32, phase 2)
-void set_count_dense(int v) { g_count_dense = v; }
+static int g_dense_margin = kDenseMargin;   // diagnostics: mvs_debug_set_count_dense(1000 + margin)
+static int g_pilot_hyp = kPilotMfmaHyp;     // diagnostics: mvs_debug_set_count_dense(100000 + hypotheses of the pilot)
+void set_count_dense(int v)
+{
+    if (v >= 100000)
+        g_pilot_hyp = v - 100000;
+    else if (v >= 1000)
+        g_dense_margin = v - 1000;
+    else
+        g_count_dense = v;
+}
 static int g_force_mode = -1;   // diagnostics: -1 = the probe decides, 0 / 1 = every pair exact / pre-screened
 void set_prescreen_force(int m) { g_force_mode = m; }
 
@@ -3805,6 +3836,8 @@ void launch_prescreen_only(const BatchDev &b, const RunParams &rp, int n_active,
 }
 #else
 constexpr int g_count_dense = 1;
+constexpr int g_dense_margin = kDenseMargin;
+constexpr int g_pilot_hyp = kPilotMfmaHyp;
 constexpr int g_force_mode = -1;
 #endif
 
@@ -3818,7 +3851,10 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
     int wg = (512 + n_active - 1) / n_active;
     wg = std::max(wg, 4);
     wg = std::min(wg, std::max(1, (n_groups4 + wpw - 1) / wpw));
-    const size_t lds_cnt = count_lds_bytes(b.max_kp), lds_c32 = count32_lds_bytes(b.max_kp);
+    const size_t lds_cnt = count_lds_bytes(b.max_kp);
+#ifdef MVS_DEBUG_HOOKS
+    const size_t lds_c32 = count32_lds_bytes(b.max_kp);   // the vector counting kernels are diagnostics-only since round 4
+#endif
     // counting: single precision for the pairs in mode 1, double precision for the others (each launch's workgroups leave
     // at once for the pairs of the other kind)
     // single-precision counting of the pairs in mode 1, three launches: pilot (the first 256 hypotheses in full -> the pair's
@@ -3838,19 +3874,26 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
     } else
 #endif
     {
-        const int wg_pilot = std::max(1, std::min(wg, (kPilotHyp / kCnt32Slots) / (kCnt32Threads / 64)));
         if (lt) lt->mark(kKRansacCountPilot);
-        if (stats)
-            hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>), dim3(wg_pilot, n_active),
-                               dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
-        else
+        const dim3 pilot_grid(n_active, (std::min(H, g_pilot_hyp) + kFinishThreads - 1) / kFinishThreads);
+#ifdef MVS_DEBUG_HOOKS
+        if (g_count_dense == 3) {   // diagnostics: round 3's vector pilot over the first 256 hypotheses
+            const int wg_pilot = std::max(1, std::min(wg, (kPilotHyp / kCnt32Slots) / (kCnt32Threads / 64)));
             hipLaunchKernelGGL((ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>), dim3(wg_pilot, n_active),
                                dim3(kCnt32Threads), lds_c32, stream, b, rp, wg_pilot);
+        } else
+#endif
+        if (stats)
+            hipLaunchKernelGGL((ransac_finish_mfma_kernel<true, true>), pilot_grid, dim3(kFinishThreads), (size_t)kDenseChunk * 64,
+                               stream, b, rp, 0);
+        else
+            hipLaunchKernelGGL((ransac_finish_mfma_kernel<false, true>), pilot_grid, dim3(kFinishThreads), (size_t)kDenseChunk * 64,
+                               stream, b, rp, 0);
         if (lt) lt->mark(kKRansacCountMfma);
         auto dense = [&](auto kern, int threads, int batches, int chunk = kDenseChunkD) {
             const size_t lds = (size_t)chunk * 64 + (size_t)(threads / 64) * kDenseWin * 16;
             const dim3 grid(((H + threads - 1) / threads + batches - 1) / batches, n_active);
-            hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, b, rp);
+            hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, b, rp, g_dense_margin);
         };
 #ifdef MVS_DEBUG_HOOKS
         // A/B of the dense phase's shape: mvs_debug_set_count_dense(10 + k)

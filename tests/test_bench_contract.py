@@ -21,12 +21,13 @@ def test_committed_bench_line_has_every_contract_field():
     # executed-work table per kernel, registers / LDS / occupancy from the runtime (mvs_kernel_info_get)
     pk = r["per_kernel"]
     assert r["kernel"] in pk and abs(pk[r["kernel"]]["ms"] - r["launch_ms"]) < 1e-6
-    for name in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel<false, 512, 4, 0, 672>", "ransac_finish_mfma_kernel<false>",
+    for name in ("ransac_prescreen_kernel", "ransac_count_mfma_kernel<false, 512, 4, 0, 672>", "ransac_finish_mfma_kernel<false, false>",
+                 "ransac_finish_mfma_kernel<false, true>",
                  "ransac_finish_upper_kernel<false>", "ransac_exact_list_kernel<1264>", "match_mfma_kernel"):
         assert name in pk and pk[name]["ms"] > 0 and pk[name]["registers_runtime"] > 0, name
     w = r["work"]
     assert w["evals_executed"] == w["evals_executed_f32"] + w["evals_executed_mfma_dense"] + w["evals_executed_mfma_finish"] + \
-        w["evals_executed_mfma_finish_rest"]
+        w["evals_executed_mfma_finish_rest"] + w["evals_executed_mfma_pilot"]
     assert 0 < w["max_sweeps9"] <= 30                      # assumption A1 of the pre-screen's bound, monitored by every bench run
     assert w["exact_solves"] + w["prescreened_only"] == w["hypotheses"]
     c = d["cpu_baseline"]
