@@ -20,7 +20,14 @@ for d in sys.argv[3:]:
             acc[names[disp]][ctr].append(v)
 kern = {k: {c: sum(v) / len(v) for c, v in ctrs.items()} for k, ctrs in acc.items()}
 # the stage's own launches: not the instrumented replay (the <..., true> variants and the fused ransac_kernel of mvs_batch_stats)
-stage = [k for k in kern if ("ransac_" in k or "pair_prepare" in k) and "<true" not in k and ", true" not in k and "ransac_kernel<" not in k]
+# (ransac_finish_mfma_kernel<false, true> is the product's PILOT: its second argument is not the instrumentation switch)
+def replay(k):
+    if "ransac_kernel<" in k or "<true" in k:
+        return True
+    return ", true" in k and "ransac_finish_mfma_kernel<false, true>" not in k
+
+
+stage = [k for k in kern if ("ransac_" in k or "pair_prepare" in k) and not replay(k)]
 hbm = sum((2 * kern[k].get("FETCH_SIZE", 0.0) + kern[k].get("WRITE_SIZE", 0.0)) * 1024 for k in stage)
 json.dump({"source": "rocprofv3 --pmc (one counter group per pass), bench.py --steps 1 --warmup 0 --pairs %d "
                      "--no-cpu-baseline --no-single-pair --no-ref-threshold" % pairs,
