@@ -262,7 +262,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
     }
     double v[8][9];   // v[k][k..8]: reflector k (entries below k are never touched)
     double rlast[kPsTri - kPsParked];
-    double rd[8], beta[8];
+    double rd[8], beta[8];   // rd: RECIPROCALS of R's diagonal
     double S = 0.0;   // ||A||_F^2
     bool piv_ok = !tiny;
 #pragma unroll
@@ -311,12 +311,18 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         for (int i = j; i < 9; ++i)
             ss = dfma(col[i], col[i], ss);
         piv_ok = piv_ok && (ss >= 0x1p-190);    // a (nearly) dependent row: no certificate; also keeps every divisor inside
-        const double nrm = sqrt_fast_nz(ss);    // the range of the unscaled sequences
+        double hn;                              // the range of the unscaled sequences
+        const double nrm = sqrt_fast_nz_h(ss, hn);   // hn ~ 1 / (2 nrm), a by-product of the square root's own sequence
         const double x0 = col[j];
         const double alpha = x0 >= 0.0 ? -nrm : nrm;
         const double vv = nrm * (nrm + dabs(x0));    // = v.v / 2
-        rd[j] = alpha;
-        beta[j] = recip_guarded(vv);
+        // 1 / R_jj for the triangular inverse below: 2 hn and one Newton step against nrm itself (relative error < 3 u
+        // whatever the seed's last bits were) -- the pivots used to be divided out again there, eight reciprocal
+        // sequences of eleven instructions each
+        double iv = hn + hn;
+        iv = dfma(iv, dfma(-nrm, iv, 1.0), iv);
+        rd[j] = x0 >= 0.0 ? -iv : iv;                // = 1 / alpha
+        beta[j] = rcp_bound(vv);                     // within 2^-49 of 1 / vv: (iii)'s eps_beta <= 28 u
         v[j][j] = x0 - alpha;                        // v0: same sign as x0, no cancellation
 #pragma unroll
         for (int i = j + 1; i < 9; ++i)
@@ -356,7 +362,7 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         double inv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            inv[i] = recip_guarded(rd[i]);
+            inv[i] = rd[i];   // the reciprocal pivots, from the QR loop
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double y[8];
@@ -374,15 +380,16 @@ MVS_DEV int prescreen_hypothesis(const double *P, int (&idx)[8], double *park, c
         }
     }
     const double yf = sqrt_bound(y2sum) * (1.0 + 1e-12);  // (y2sum >= 1 / pivot^2 >= 2^-380; a zero pivot fails piv_ok)
-    // residual of n~ against the rows of A -- a priori: with A^T + E = Q~ [R^; 0] (||E||_F <= 176 u ||A||_F, Q~ within 250 u of
+    // residual of n~ against the rows of A -- a priori: with A^T + E = Q~ [R^; 0] (||E||_F <= 176 u ||A||_F, Q~ within 510 u of
     // orthogonal: DESIGN.md 4.3e (iii)) and n~ = the computed Q~ e_9 (eight reflector applications, <= 176 u of rounding),
-    // A n~ = [R^T 0] Q~^T n~ - E^T n~ and Q~^T n~ = e_9 up to 500 u + 176 u, so || A n~ || <= 852 u ||A||_F + 176 u ||A||_F.
+    // A n~ = [R^T 0] Q~^T n~ - E^T n~ and Q~^T n~ = e_9 up to 1020 u + 176 u, so || A n~ || <= 1372 u ||A||_F + 176 u ||A||_F
+    // = 1548 u ||A||_F = 1.72e-13 ||A||_F <= 1.8e-13 sqrtS.
     // (The first version measured it from a second gather of the sample: 208 flop and eight loads per hypothesis for a term
     // that is five orders of magnitude below eta_J.)
-    const double rho = 1.2e-13 * sqrtS;
-    // sigma_8(A) >= (1 - z) / ||R^-1||_F (1 - 250 u) - 176 u ||A||_F
-    const double z = 12.0 * kPsU * sqrtS * yf;
-    const double sig8 = (1.0 - z) * rcp_bound(yf) * (1.0 - 1e-13) - 4e-14 * sqrtS;   // (250 u + the reciprocal's 2^-49 < 1e-13)
+    const double rho = 1.8e-13 * sqrtS;
+    // sigma_8(A) >= (1 - z) / ||R^-1||_F (1 - 510 u) - 176 u ||A||_F
+    const double z = 16.0 * kPsU * sqrtS * yf;
+    const double sig8 = (1.0 - z) * rcp_bound(yf) * (1.0 - 1e-13) - 4e-14 * sqrtS;   // (510 u + the reciprocal's 2^-49 < 1e-13)
     const double rg = rcp_bound(sig8);   // (NaN / inf for sig8 <= 0: the certificate is refused below)
     const double eta_j = 1.01 * kPsTauC * S * (rg * rg) + kPsEtaQ;   // (1.01 * 2.0e-12 is 13 % above 2.001 (8000 u + 8.01 u))
     const double eta_a = 1.5 * rho * rg + 1e-13;

@@ -8,7 +8,7 @@ samples.  The product path never imports this file.
 
 Per sample (8 point pairs, Hartley-normalised exactly like the exact path):
   A (8 x 9)  ->  Householder QR of A^T (9 x 8)  ->  n~ = Q e_9 (unit null vector), R (8 x 8 upper triangular)
-  rho = 1.2e-13 ||A||_F >= ||A n~||   a-priori residual of the Householder null vector (the model asserts it)
+  rho = 1.8e-13 ||A||_F >= ||A n~||   a-priori residual of the Householder null vector (the model asserts it)
   sigma8_lb <= sigma_8(A)             from ||R^-1||_F (explicit triangular inverse, backward-stable solve)
   eta_J  = 1.01 tau' / sigma8_lb^2 + 4e-12,   tau' = 2e-12 ||A||_F^2      exact path's null vector vs the true one
   eta_A  = 1.5 rho / sigma8_lb + 1e-13                                     approximate null vector vs the true one
@@ -136,13 +136,13 @@ def prescreen(x1, y1, x2, y2, bbox, v3=None):
     A = design(a1, b1, a2, b2)
     S = float((A * A).sum()) * (1 + 1e-12)
     n, R = householder_null(A)
-    rho = 1.2e-13 * np.sqrt(S)     # a-priori bound of ||A n~|| for the Householder null vector (1028 u ||A||_F)
+    rho = 1.8e-13 * np.sqrt(S)     # a-priori bound of ||A n~|| for the Householder null vector (1548 u ||A||_F: beta within 28 u)
     assert float(np.sqrt(((A @ n) ** 2).sum())) <= rho
     yf, _ = tri_inverse_fro(R)
     rf = float(np.sqrt((R * R).sum()))
     if not np.isfinite(yf):
         return out
-    z = 12.0 * U * rf * yf
+    z = 16.0 * U * rf * yf         # (the device's pivot reciprocals are within 3 u, not correctly rounded)
     if not (z < 0.5):
         return out
     sig8 = (1.0 - z) / yf * (1 - 1e-13) - 4e-14 * np.sqrt(S)
