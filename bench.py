@@ -695,6 +695,9 @@ def main():
                 "algorithmic_bytes_per_pair": int(bytes_pair),
                 "match_kernel_GBs": round(2 * args.kp * 32 * n_local / (kern_ms["match_topk"] * 1e-3) / 1e9, 2)},
             "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
+            "kernel_ms_note": "stage times of whole-batch launches on one stream (events between the stages); with two half "
+                              "batches on two streams (`ms_per_step`, the default) the stages of the halves overlap, so these do "
+                              "not add up to the step",
             "work": {"avg_matches": round(m_avg, 1), "avg_inliers": round(float(res["n_inliers"].mean()), 1),
                      "avg_points": round(float(res["n_points"].mean()), 1), "valid_pairs": int(res["valid"].sum()),
                      "rotations9_per_hyp": round(stats["rotations9"] / max(stats["hypotheses"], 1), 2),
