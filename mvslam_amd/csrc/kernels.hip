@@ -3536,6 +3536,15 @@ void set_split_min_pairs(int v) { kSplitMinPairs = v; }
 constexpr int kSplitMinPairs = 3;  // one or two pairs stay on the fused kernel (latency: fewer launches)
 #endif
 
+// Which launches take the pre-screened stage: three or more pairs; two pairs when their hypotheses fill the chip more than once
+// on the fused kernel (2 x 50 000: 0.35 ms against 0.40, profiles/r04_single_pair_paths.json); one pair never (0.32 against 0.25:
+// the stage is a chain of latencies there).  (Diagnostics: a split minimum other than 3 is taken literally.)
+static bool prescreened_launch(int n_active, int H)
+{
+    return n_active >= kSplitMinPairs || (kSplitMinPairs == 3 && n_active == 2 && 2 * ((H + kHypPerBlock - 1) / kHypPerBlock) > 256);
+}
+
+
 constexpr int kCnt32Threads = 768;
 constexpr int kCnt32Slots = 4;     // hypotheses a wavefront carries at a time
 constexpr int kCnt32Ppl = 4;       // single-precision counting: four points per lane and block (scalar work per evaluation halves)
@@ -3985,13 +3994,13 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
 static void launch_ransac_product(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream,
                                   LaunchTimer *lt, dim3 grid, dim3 block)
 {
-    const bool split_ok = !stats && b.hyp_F && n_active >= kSplitMinPairs;
+    const bool split_ok = !stats && b.hyp_F && prescreened_launch(n_active, rp.num_hypotheses);
     if (!split_ok || b.hyp_count) {
         if (!stats)
             launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
         else
             launch_ransac_var<120>(b, rp, grid, block, true, stream, lt);
-        if (stats && b.hyp_F && !b.hyp_count && n_active >= kSplitMinPairs)
+        if (stats && b.hyp_F && !b.hyp_count && prescreened_launch(n_active, rp.num_hypotheses))
             launch_prescreened(b, rp, n_active, stream, nullptr, true);   // + the product path's own counters
     } else {
         launch_prescreened(b, rp, n_active, stream, lt, false);
@@ -4006,7 +4015,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     launch_ransac_product(b, rp, n_active, stats, stream, lt, grid, block);
 #else
     // diagnostics build: the experiment ladder of rounds 1-2 behind mvs_debug_set_ransac_variant (tools/ab_ransac.py)
-    const bool split_ok = !stats && b.hyp_F && n_active >= kSplitMinPairs;
+    const bool split_ok = !stats && b.hyp_F && prescreened_launch(n_active, rp.num_hypotheses);
     switch (g_ransac_variant) {
     case 9000: launch_ransac_product(b, rp, n_active, stats, stream, lt, grid, block); break;
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream, lt); break;
@@ -4044,7 +4053,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
                 launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
             else
                 launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
-            if (stats && b.hyp_F && !b.hyp_count && n_active >= kSplitMinPairs && g_ransac_variant == 1784) {
+            if (stats && b.hyp_F && !b.hyp_count && prescreened_launch(n_active, rp.num_hypotheses) && g_ransac_variant == 1784) {
                 // the instrumented replay also runs the product path once with the counting kernel's evaluation counter
                 // (stats[2]): the roofline quotes EXECUTED evaluations for the pruned kernel, not the H x M it avoids
                 hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active),

@@ -468,6 +468,31 @@ def test_full_size_pair_50k_hypotheses(ctx):
     assert r["valid"] and r["n_matches"] > 1400 and r["n_points"] > 900
 
 
+def test_two_full_size_pairs_take_the_prescreened_stage(ctx):
+    """Two pairs x 50 000 hypotheses run on the pre-screened stage (round 4: their hypotheses fill the chip more than once on
+    the fused kernel); one pair and two pairs with few hypotheses stay on the fused kernel.  Same records either way: each pair
+    alone (fused) == inside the two-pair launch (pre-screened) == the oracle."""
+    n_kp, H = 2000, 50000
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=0x5EED0000, max_error_sq=1e-2)
+    data, out = _run_batch(ctx, 700, 2, n_kp, prm)
+    _check_batch_against_oracle(data, out, prm)
+    b1 = capi.Batch(ctx, 1, n_kp, 32)
+    for i in range(2):
+        sl = slice(i, i + 1)
+        b1.upload(0, data["desc1"][sl], data["kp1"][sl], data["n1"][sl], data["desc2"][sl], data["kp2"][sl], data["n2"][sl],
+                  data["K"][sl], data["global_index"][sl])
+        b1.run(prm)
+        b1.sync()
+        assert b1.download(matches=False, mask=False, points=False)["results"][0].tobytes() == out["results"][i].tobytes()
+    b1.close()
+    st = None
+    b2 = capi.Batch(ctx, 2, n_kp, 32)
+    b2.upload(0, data["desc1"], data["kp1"], data["n1"], data["desc2"], data["kp2"], data["n2"], data["K"], data["global_index"])
+    st = b2.stats(prm)
+    b2.close()
+    assert st["pairs_mode"] == [0, 2, 0] and 0 < st["exact_solves"] < 2000      # the pre-screened stage's own bookkeeping
+
+
 def test_full_size_properties(ctx):
     """Size-independent properties at BASELINE sizes (no oracle): determinism, shard invariance (pair p gives the
     same result alone as inside a batch), mask/count consistency, cheirality of every returned point, sorted match
