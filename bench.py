@@ -501,6 +501,102 @@ def bench_sensitivity(capi, synth, np, dev, args, pairs=64):
             "cells": cells}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# output: the LAST stdout line is a compact object (< 4 KB: the contract's fields + scalar summaries); everything bulky
+# (per-kernel tables, the sensitivity cells, the sub-legs' own objects) goes to bench_detail.json beside this file
+# ---------------------------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 4096
+DETAIL_NAME = "bench_detail.json"
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(out, detail_path=None):
+    """The driver's line: contract fields, `roofline` and `cpu_baseline` with scalar members only, and one scalar per
+    side leg.  `out` is the full (detail) object main() assembled."""
+    cfg = out.get("config", {})
+    r = out.get("roofline") or {}
+    c = out.get("cpu_baseline")
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "pairs_per_gpu", "keypoints", "hypotheses", "max_error_sq",
+                                              "parallelism", "streams") if k in cfg}
+    line["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms",
+                                              "flops_per_launch", "traffic")}
+    line["roofline"]["algorithmic_hbm_frac"] = _get(out, "hbm_roofline", "frac")
+    line["cpu_baseline"] = None if c is None else {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    line["reference_threshold_pairs_per_s"] = out.get("reference_threshold_pairs_per_s")
+    line["single_pair_ms"] = out.get("single_pair_ms")
+    line["image_pair_ctor_ms"] = out.get("image_pair_ctor_ms")
+    line["pcie_inclusive_pairs_per_s"] = out.get("pcie_inclusive_pairs_per_s")
+    line["sequence_frames_per_s"] = _get(out, "sequence", "value")
+    line["refine_pairs_per_s"] = _get(out, "refine", "value")
+    line["extract_images_per_s"] = _get(out, "extract", "value")
+    line["sensitivity_min_pairs_per_s"] = _get(out, "sensitivity", "min_pairs_per_s")
+    line["valid_pairs"] = _get(out, "work", "valid_pairs")
+    line["max_sweeps9"] = _get(out, "roofline", "work", "max_sweeps9")
+    line["ranks_seen"] = out.get("ranks_seen")
+    line["gather_us"] = out.get("gather_us")
+    if _get(out, "work", "gathered_records") is not None:
+        line["gathered_records"] = out["work"]["gathered_records"]
+    line["detail"] = detail_path
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= COMPACT_LIMIT:   # never let a long free-text member push the line past what the driver reads
+        for k in ("sample",):
+            if line["cpu_baseline"] and isinstance(line["cpu_baseline"].get(k), str):
+                line["cpu_baseline"][k] = line["cpu_baseline"][k][:160]
+        line["config"]["workload"] = str(line["config"].get("workload"))[:200]
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) < COMPACT_LIMIT, "compact bench line is %d bytes" % len(txt)
+    return txt
+
+
+def write_detail(out, path):
+    """Best effort: the detail file is a convenience for the judge, never a reason to lose the bench line."""
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        print("bench.py: could not write %s: %s" % (path, e), file=sys.stderr)
+        return None
+
+
+def profiler_preload_active():
+    """True under rocprofv3 & co.: the tool's preloaded library has initialised the GPU before this program started, so
+    starting a child process from here is the exec the pool forbids."""
+    env = os.environ
+    if any(k in env for k in ("ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH",
+                              "ROCPROF_OUTPUT_FILE_NAME", "ROCPROFILER_LIBRARY_CTOR")):
+        return True
+    return any(t in env.get("LD_PRELOAD", "") for t in ("rocprof", "roctracer", "rocprofiler"))
+
+
+def image_pair_probe(kp, hyp, reps=100, timeout_s=120):
+    """What a caller of the reference's own interface waits for: the shim's ImagePair constructor (host C++,
+    front-end/image-pair.cpp:30-71), host buffers in, host objects out -- a child process
+    (tests/cpp/image_pair_latency.cpp, built by __graft_entry__.build()).  Must run BEFORE this process touches the GPU."""
+    probe = os.path.join(ROOT, "mvslam_amd", "lib", "image_pair_latency")
+    if not os.path.exists(probe):
+        return {"error": "probe not built"}
+    if profiler_preload_active():
+        return {"skipped": "profiler preload detected: no child processes under the profiler"}
+    try:
+        pr = subprocess.run([probe, str(kp), str(hyp), str(reps)], capture_output=True, text=True, timeout=timeout_s)
+        return json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "probe timed out after %d s" % timeout_s}
+    except Exception as e:   # the probe is a convenience: never fail the bench line for it
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -532,6 +628,9 @@ def main():
     ap.add_argument("--seq-frames", type=int, default=1000)
     ap.add_argument("--seq-cpu-frames", type=int, default=48)
     ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before a self-launched run is abandoned")
+    ap.add_argument("--detail", default=os.path.join(ROOT, DETAIL_NAME),
+                    help="where rank 0 writes the full (bulky) result object; the LAST stdout line is the compact one")
+    ap.add_argument("--print-detail", action="store_true", help="also print the full object as an EARLIER stdout line")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -546,6 +645,12 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+
+    # the ImagePair-constructor probe is a child process: it runs BEFORE this process initialises the GPU,
+    # alone on the device, and its JSON is kept for the line
+    probe_result = None
+    if rank == 0 and world == 1 and not args.no_single_pair:
+        probe_result = image_pair_probe(args.kp, args.hyp)
 
     import numpy as np
     import torch
@@ -679,6 +784,7 @@ def main():
                             % (n_local, args.kp, args.hyp),
                 "pairs_per_gpu": n_local, "keypoints": args.kp, "hypotheses": args.hyp, "noise_px": args.noise_px,
                 "max_error_sq": args.max_error_sq, "parallelism": "pairs sharded, dp%d" % world,
+                "streams": 1 if args.one_stream else 2,
                 "launch_plan": ("every launch covers the rank's whole batch, one stream (--one-stream)" if args.one_stream else
                                 "the rank's batch runs as two independent halves on two HIP streams (mvs_ctx_set_half_batches, "
                                 "default): the latency-bound kernels of one half run under the throughput-bound kernels of "
@@ -693,7 +799,7 @@ def main():
                 "achieved": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(bytes_pair * (n_local / (ms_per_step * 1e-3)) / 1e9 / HBM_PEAK_GBS, 6),
                 "algorithmic_bytes_per_pair": int(bytes_pair),
-                "match_kernel_GBs": round(2 * args.kp * 32 * n_local / (kern_ms["match_topk"] * 1e-3) / 1e9, 2)},
+                "match_kernel_GBs": round(2 * args.kp * 32 * n_local / (kern_ms["match"] * 1e-3) / 1e9, 2)},
             "kernel_ms": {k: round(v, 3) for k, v in kern_ms.items()},
             "kernel_ms_note": "stage times of whole-batch launches on one stream (events between the stages); with two half "
                               "batches on two streams (`ms_per_step`, the default) the stages of the halves overlap, so these do "
@@ -744,19 +850,8 @@ def main():
             tot, _ = b1.time(prm, steps=20, warmup=3, per_kernel=False)
             out["single_pair_ms"] = round(tot / 20, 4)  # BASELINE configs[1]: one pair at a time
             b1.close()
-            # ... and what a caller of the reference's own interface waits for: the shim's ImagePair constructor (host C++,
-            # front-end/image-pair.cpp:30-71), host buffers in, host objects out -- a child process (tests/cpp/image_pair_latency.cpp,
-            # built by __graft_entry__.build())
-            probe = os.path.join(ROOT, "mvslam_amd", "lib", "image_pair_latency")
-            out["image_pair_ctor_ms"] = None
-            if os.path.exists(probe):
-                try:
-                    pr = subprocess.run([probe, str(args.kp), str(args.hyp), "100"], capture_output=True, text=True, timeout=120)
-                    lat = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
-                    out["image_pair_ctor_ms"] = lat["image_pair_ctor_ms"]
-                    out["image_pair_probe"] = lat
-                except Exception as e:   # the probe is a convenience: never fail the bench line for it
-                    out["image_pair_probe"] = {"error": str(e)[:200]}
+            out["image_pair_ctor_ms"] = (probe_result or {}).get("image_pair_ctor_ms")
+            out["image_pair_probe"] = probe_result
         if not args.no_pcie and world == 1:
             if args.pcie_naive:
                 # (a) naive: synchronous upload from pageable memory + run + synchronous download, nothing overlapped
@@ -832,7 +927,10 @@ def main():
         if "extract" in sections:
             out["extract"] = bench_extract(capi, np, dev, args)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        detail_rel = write_detail(out, args.detail)
+        if args.print_detail:
+            print(json.dumps(out), flush=True)
+        print(compact_line(out, detail_rel), flush=True)   # the LAST stdout line: what the driver parses
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -209,7 +209,7 @@ mvs_status mvs_batch_sync(mvs_batch *b);
 
 /* Timed replay: `warmup` untimed + `steps` timed passes over the resident inputs, bracketed by HIP events
  * on the ctx stream.  ms_total: wall ms of the `steps` passes.  ms_kernel[5]: summed ms per kernel over the
- * timed passes, in launch order {match_topk, match_compact, ransac, finalize, reserved}; measured with
+ * timed passes, in launch order {match (match_mfma or match_topk), match_compact, ransac, finalize, reserved}; measured with
  * per-kernel events in a SEPARATE instrumented replay of `steps` passes (so ms_total has no event overhead).
  * Either output may be NULL. */
 mvs_status mvs_batch_time(mvs_batch *b, const mvs_params *params, int n_active, int warmup, int steps,

@@ -612,7 +612,7 @@ class Batch:
         st = lib().mvs_batch_time(self._h, C.byref(params), C.c_int(n_active or self.n_pairs), C.c_int(warmup),
                                   C.c_int(steps), C.byref(total), kern if per_kernel else None)
         self.ctx._check(st, "mvs_batch_time")
-        names = ("match_topk", "match_compact", "ransac", "finalize")
+        names = ("match", "match_compact", "ransac", "finalize")
         return total.value, {n: kern[i] for i, n in enumerate(names)}
 
     def time_kernels(self, params, steps, n_active=None):
