@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-/* 3 (round 4): mvs_work_stats grew (max_sweeps9, dense_points, matches_mode1, score_evals_executed_mfma_rest); every entry point
+/* 3 (round 4): mvs_work_stats grew by FIVE fields (max_sweeps9, dense_points, matches_mode1, score_evals_executed_mfma_rest,
+ * score_evals_executed_mfma_pilot; score_evals_executed is the sum of every executed-evaluation counter); every entry point
  * and every other struct is unchanged from version 2 */
 #define MVS_ABI_VERSION 3
 

@@ -1086,12 +1086,22 @@ static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_acti
         // second half's counting back with an event until the first half's dense phase has drained puts it under the first
         // half's tail but leaves the second tail exposed: same step time within 1 % (measured, not kept).
         const int na = (n_active + 1) / 2;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));          // nothing is on the side stream yet: a plain return is safe
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         enqueue_stages(batch_view(b->d, 0, na, 0), rp, na, false, s, nullptr, nullptr);
+        const hipError_t e_first = hipGetLastError();            // a launch failure of the first half, attributed to it
         enqueue_stages(batch_view(b->d, na, n_active - na, 1), rp, n_active - na, false, ctx->side, nullptr, nullptr);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        const hipError_t e_second = hipGetLastError();
+        // from here on work may be queued on the side stream: whatever fails, the caller's stream joins it before this call
+        // returns (a later download or a release of the groups must never race with the second half) -- ADVICE r4
+        hipError_t e_join = hipEventRecord(ctx->ev_join, ctx->side);
+        if (e_join == hipSuccess)
+            e_join = hipStreamWaitEvent(s, ctx->ev_join, 0);
+        if (e_join != hipSuccess)
+            (void)hipStreamSynchronize(ctx->side);               // no event edge: wait for the half on the host instead
+        HIP_TRY(ctx, e_first);
+        HIP_TRY(ctx, e_second);
+        HIP_TRY(ctx, e_join);
     }
     if (lt) lt->end();
     HIP_TRY(ctx, hipGetLastError());

@@ -3150,6 +3150,41 @@ __device__ __forceinline__ int block_compact(int n, int *s_tot, Pred pred, Emit 
     return basepos;
 }
 
+// triangulation of ONE (candidate c, inlier j): 4x4 DLT + SVD on the lane (sfm-solve.cpp:134-227), cheirality flag and point
+// into the candidate's scratch rows.  R / Rr / T: the candidate's raw and rectified rotation (row-major 9) and +-t.
+__device__ __forceinline__ void triangulate_item(const BatchDev &b, int pair, int c, int j, const double *R, const double *Rr,
+                                                 double t0, double t1, double t2)
+{
+    const size_t base = (size_t)pair * b.max_kp;
+    const int i = b.inl[base + j];
+    const double4 p = *reinterpret_cast<const double4 *>(b.pts + (base + i) * 4);
+    double At[4][4];  // At[col][row] of A
+    auto design = [&]() {
+        At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
+        At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
+        At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
+        At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
+    };
+    double X[4];
+    unsigned rot = 0, prs = 0;
+    bool bad = false;
+    design();
+    svd4_last_vt_row<true>(At, X, rot, prs, bad);
+    if (__builtin_expect(__any(bad), 0)) {   // a range guard of the unscaled sequences was violated: full sequences
+        design();
+        svd4_last_vt_row<false>(At, X, rot, prs, bad);
+    }
+    bool okp = !(dabs(X[3]) < kTol);
+    const double scale = 1.0 / X[3];
+    const double px = X[0] * scale, py = X[1] * scale, pz = X[2] * scale;
+    okp = okp && !(pz < kTol);
+    const double z2 = ((R[6] * px + R[7] * py) + R[8] * pz) + t2;
+    okp = okp && !(z2 < kTol);
+    b.okf[((size_t)pair * 4 + c) * b.max_kp + j] = okp ? 1 : 0;
+    double *dst = b.cand_pts + (((size_t)pair * 4 + c) * b.max_kp + j) * 3;
+    dst[0] = px; dst[1] = py; dst[2] = pz;
+}
+
 __global__ __launch_bounds__(kFinThreads) void finalize_model_kernel(BatchDev b, RunParams rp, int mode)
 {
     __shared__ double s_F[9], s_E[9];
@@ -3370,53 +3405,67 @@ __global__ __launch_bounds__(kFinThreads) void finalize_model_kernel(BatchDev b,
         fm->proceed = (go && n_inl > 0) ? 1 : 0;
         fm->n_inl = n_inl;
         fm->ncand = ncand;
+        fm->npre = min(n_inl, kFinThreads / ncand);
+        s_proceed = fm->proceed;
+    }
+    __syncthreads();   // (workgroup-scope fence: the lane-0 stores to *fm above are visible to the whole workgroup)
+    if (!s_proceed)
+        return;
+    // ---- the prefix: every candidate on the first 256 / ncand inliers (wavefront = candidate when there are four) ----
+    {
+        const int ncand = fm->ncand, npre = fm->npre;
+        const int per = kFinThreads / ncand;
+        const int c = tid / per, j = tid - c * per;
+        if (tid < 4)
+            s_tot[tid] = 0;
+        __syncthreads();
+        if (j < npre) {
+            const bool flip = (c & 1) != 0;
+            triangulate_item(b, pair, c, j, fm->R[c >> 1], fm->Rr[c >> 1], flip ? -fm->T[0] : fm->T[0],
+                             flip ? -fm->T[1] : fm->T[1], flip ? -fm->T[2] : fm->T[2]);
+            if (b.okf[((size_t)pair * 4 + c) * b.max_kp + j])
+                atomicAdd(&s_tot[c], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int best = -1, bc = 0;
+            for (int k = 0; k < ncand; ++k) {
+                fm->pre_cnt[k] = s_tot[k];
+                if (s_tot[k] > best) {
+                    best = s_tot[k];
+                    bc = k;
+                }
+            }
+            for (int k = ncand; k < 4; ++k)
+                fm->pre_cnt[k] = 0;
+            fm->best_c = bc;
+        }
     }
 }
 
-// triangulation: grid (ceil(4 * max_kp / 256), P); item = (candidate c, inlier j); 4x4 DLT + SVD per lane
-// (sfm-solve.cpp:134-227)
+// Lazy candidate evaluation (round 5).  recover_pose_and_points (sfm-solve.cpp:250-280) triangulates every inlier under all
+// four (R, t) candidates and keeps the one with strictly more points in front of both cameras, first candidate on ties.  Three
+// of the four lose by a wide margin on any real pair, and to know that a candidate loses it is enough that ALL its remaining
+// points could not lift it past the winner.  Every evaluated point is the contract's own arithmetic; only the number of points
+// evaluated for the losers changes:
+//   finalize_model   every candidate on the PREFIX (the first 256 / ncand inliers): pre_cnt[c]; best_c = its arg-max;
+//   triangulate      best_c on the rest of the inliers (grid (ceil(max_kp / 256), P));
+//   finalize_select  count* of best_c; a candidate c is COMPLETED there (rare) iff pre_cnt[c] + (n_inl - npre) > count*, or
+//                    == count* with c < best_c -- otherwise its full count is provably not the winner's and its prefix count
+//                    stands in for it in the reference's selection loop (strict >, candidate order), which picks the same winner.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void triangulate_kernel(BatchDev b)
 {
     const int pair = blockIdx.y;
     const FinModel *fm = b.fin + pair;
     if (!fm->proceed)
         return;
-    const int n_inl = fm->n_inl, ncand = fm->ncand;
-    const int it = blockIdx.x * 256 + threadIdx.x;
-    if (it >= ncand * n_inl)
+    const int j = fm->npre + blockIdx.x * 256 + threadIdx.x;
+    if (j >= fm->n_inl)
         return;
-    const size_t base = (size_t)pair * b.max_kp;
-    const int c = it / n_inl, j = it - c * n_inl;
-    const int i = b.inl[base + j];
-    const double *R = fm->R[c >> 1], *Rr = fm->Rr[c >> 1];
+    const int c = fm->best_c;
     const bool flip = (c & 1) != 0;
-    const double t0 = flip ? -fm->T[0] : fm->T[0], t1 = flip ? -fm->T[1] : fm->T[1], t2 = flip ? -fm->T[2] : fm->T[2];
-    const double4 p = *reinterpret_cast<const double4 *>(b.pts + (base + i) * 4);
-    double At[4][4];  // At[col][row] of A
-    auto design = [&]() {
-        At[0][0] = -1.0; At[1][0] = 0.0;  At[2][0] = p.x; At[3][0] = 0.0;
-        At[0][1] = 0.0;  At[1][1] = -1.0; At[2][1] = p.y; At[3][1] = 0.0;
-        At[0][2] = p.z * Rr[6] - Rr[0]; At[1][2] = p.z * Rr[7] - Rr[1]; At[2][2] = p.z * Rr[8] - Rr[2]; At[3][2] = p.z * t2 - t0;
-        At[0][3] = p.w * Rr[6] - Rr[3]; At[1][3] = p.w * Rr[7] - Rr[4]; At[2][3] = p.w * Rr[8] - Rr[5]; At[3][3] = p.w * t2 - t1;
-    };
-    double X[4];
-    unsigned rot = 0, prs = 0;
-    bool bad = false;
-    design();
-    svd4_last_vt_row<true>(At, X, rot, prs, bad);
-    if (__builtin_expect(__any(bad), 0)) {   // a range guard of the unscaled sequences was violated: full sequences
-        design();
-        svd4_last_vt_row<false>(At, X, rot, prs, bad);
-    }
-    bool okp = !(dabs(X[3]) < kTol);
-    const double scale = 1.0 / X[3];
-    const double px = X[0] * scale, py = X[1] * scale, pz = X[2] * scale;
-    okp = okp && !(pz < kTol);
-    const double z2 = ((R[6] * px + R[7] * py) + R[8] * pz) + t2;
-    okp = okp && !(z2 < kTol);
-    b.okf[((size_t)pair * 4 + c) * b.max_kp + j] = okp ? 1 : 0;
-    double *dst = b.cand_pts + (((size_t)pair * 4 + c) * b.max_kp + j) * 3;
-    dst[0] = px; dst[1] = py; dst[2] = pz;
+    triangulate_item(b, pair, c, j, fm->R[c >> 1], fm->Rr[c >> 1], flip ? -fm->T[0] : fm->T[0], flip ? -fm->T[1] : fm->T[1],
+                     flip ? -fm->T[2] : fm->T[2]);
 }
 
 __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b)
@@ -3442,24 +3491,40 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
     mvs_pair_result *res = b.results + pair;
     const int n_inl = fm->n_inl, ncand = fm->ncand;
     const uint8_t *okf = b.okf + (size_t)pair * 4 * b.max_kp;
+    // ---- candidate selection: strictly more points wins, order (Ra,t),(Ra,-t),(Rb,t),(Rb,-t) (sfm-solve.cpp:259-281).
+    // best_c has been triangulated on every inlier, the others on the prefix only (see triangulate_kernel): count* first,
+    // then any candidate whose remaining points could still lift it to the winner's place is completed here (rare).
+    const int npre = fm->npre, bc = fm->best_c, rem = n_inl - npre;
+    auto count_rest = [&](int c) {   // points of candidate c behind the prefix, added to s_cnt[c]
+        int cnt = 0;
+        for (int j = npre + tid; j < n_inl; j += kFinThreads)
+            cnt += okf[(size_t)c * b.max_kp + j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            cnt += __shfl_xor(cnt, o);
+        if ((tid & 63) == 0 && cnt)
+            atomicAdd(&s_cnt[c], cnt);
+    };
     if (tid < 4)
-        s_cnt[tid] = 0;
+        s_cnt[tid] = tid < ncand ? fm->pre_cnt[tid] : 0;
     __syncthreads();
-    // ---- candidate selection: strictly more points wins, order (Ra,t),(Ra,-t),(Rb,t),(Rb,-t) (sfm-solve.cpp:259-281)
+    count_rest(bc);
+    __syncthreads();
     {
-        int cnt[4] = {0, 0, 0, 0};
-        for (int j = tid; j < n_inl; j += kFinThreads) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                cnt[c] += (c < ncand) ? okf[(size_t)c * b.max_kp + j] : 0;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-                cnt[c] += __shfl_xor(cnt[c], o);
-            if ((tid & 63) == 0 && cnt[c])
-                atomicAdd(&s_cnt[c], cnt[c]);
+        const int cstar = s_cnt[bc];
+        for (int c = 0; c < ncand; ++c) {
+            if (c == bc)
+                continue;
+            const int ub = fm->pre_cnt[c] + rem;
+            if (!(ub > cstar || (ub == cstar && c < bc)))
+                continue;            // cannot take best_c's place whatever its remaining points do (workgroup-uniform)
+            const bool flip = (c & 1) != 0;
+            for (int j0 = npre; j0 < n_inl; j0 += kFinThreads)
+                if (j0 + tid < n_inl)
+                    triangulate_item(b, pair, c, j0 + tid, fm->R[c >> 1], fm->Rr[c >> 1], flip ? -fm->T[0] : fm->T[0],
+                                     flip ? -fm->T[1] : fm->T[1], flip ? -fm->T[2] : fm->T[2]);
+            __syncthreads();         // (workgroup-scope fence: the flags just written are read by other lanes below)
+            count_rest(c);
         }
     }
     __syncthreads();
@@ -4085,7 +4150,7 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
     if (lt) lt->mark(kKFinModel);
     hipLaunchKernelGGL(finalize_model_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b, rp, mode);
     if (lt) lt->mark(kKTriangulate);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((4 * b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((b.max_kp + 255) / 256, n_active), dim3(256), 0, stream, b);
     if (lt) lt->mark(kKFinSelect);
     hipLaunchKernelGGL(finalize_select_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b);
 }

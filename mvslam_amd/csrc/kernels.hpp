@@ -31,7 +31,10 @@ struct FinModel {
     int32_t n_inl;
     int32_t ncand;
     int32_t proceed;
-    int32_t pad;
+    int32_t npre;        // inliers [0, npre) are triangulated under EVERY candidate by finalize_model (the prefix)
+    int32_t pre_cnt[4];  // points of the prefix in front of both cameras, per candidate
+    int32_t best_c;      // candidate with the largest prefix count (lowest index on ties): the one triangulate completes
+    int32_t pad[3];
 };
 
 // Resident state of a batch (all device pointers).  P pairs, capacity N keypoints per image.

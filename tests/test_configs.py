@@ -46,6 +46,20 @@ def _batch512():
     return _BATCH512["d"]
 
 
+
+def _check_eval_counters(st):
+    """score_evals_executed is the sum of every executed-evaluation counter (ABI 3: five matrix-core / binary32 parts + the
+    double-precision remainder, which is not exported on its own and must come out non-negative) -- ADVICE r4."""
+    parts = (st["score_evals_executed_f32"] + st["score_evals_executed_mfma"] + st["score_evals_executed_mfma_finish"] +
+             st["score_evals_executed_mfma_rest"] + st["score_evals_executed_mfma_pilot"])
+    f64 = st["score_evals_executed"] - parts
+    assert f64 >= 0, st
+    if st["pairs_mode"][0] == 0 and st["pairs_mode"][2] == 0:
+        assert f64 == 0, st          # every pair counted on the matrix cores: nothing left for the double-precision kernel
+    if st["pairs_mode"][1] == 0:
+        assert parts == 0 and f64 > 0, st
+    return f64
+
 def test_config3_batch512(ctx):
     from mvslam_amd import capi
 
@@ -139,6 +153,7 @@ def test_low_inlier_pairs_through_the_multi_chunk_counting(ctx):
     st = b.stats(prm)
     b.close()
     assert st["pairs_mode"][1] >= 4 and st["score_evals_executed_mfma"] > 0 and st["score_evals_executed_mfma_finish"] > 0
+    _check_eval_counters(st)
 
     def ref(i):
         p = pairs[i]
@@ -347,6 +362,7 @@ def test_high_outlier_pairs_at_full_size(ctx):
         out = b.download()
         st = b.stats(prm)
         assert (out["results"]["n_matches"] > 1900).all()
+        _check_eval_counters(st)
         assert st["pairs_mode"][0] == 0 and st["pairs_mode"][1] + st["pairs_mode"][2] == P      # pre-screened, one way or the other
         if thr == 2e-4:
             assert st["pairs_mode"][2] == P        # the matrix cores' 2^-14 T term is beyond this threshold: double-precision counting

@@ -315,6 +315,77 @@ def test_recover_pose_cube_kat(ctx):
     assert helpers.rel_err(got["R1to2"], R) <= TIGHT and helpers.rel_err(got["points"], pts) <= TIGHT
 
 
+def test_recover_pose_lazy_candidates_ties_and_wrong_prefix(ctx):
+    """Round 5: the losers of recover_pose_and_points (sfm-solve.cpp:250-280) are triangulated on a prefix only and completed
+    only while their remaining points could still take the winner's place.  Constructed correspondence lists, each point
+    chosen by the candidates it survives under (from the oracle's own triangulate_points per candidate):
+    exact ties between two candidates (the first in candidate order must win, strict '>' of :273), a tie at the top between a
+    later prefix-best and an earlier candidate, a prefix that favours the wrong candidate, and nobody surviving."""
+    rig = helpers.two_camera_rig("L", rpy=(0.3, -0.2, 0.1), scale=0.5, se3_2to1=(1, 0.2, -0.1, 0.02, 0.05, -0.03))
+    R12, t12 = rig["T1to2"]
+    E = helpers.skew(t12) @ R12
+    Ra, Rb, t = o.decompose_essential(E)
+    cands = [(Ra, t), (Ra, -t), (Rb, t), (Rb, -t)]
+    rng = np.random.default_rng(55)
+    p1s, p2s = [], []
+    for R, tt in cands:   # true correspondences of points in front of both cameras under THIS candidate (wide angle: Rb looks back)
+        X = np.column_stack([rng.uniform(-20, 20, 200000), rng.uniform(-20, 20, 200000), rng.uniform(0.05, 6, 200000)])
+        Y = X @ R.T + tt
+        keep = Y[:, 2] > 0.05
+        X, Y = X[keep][:3000], Y[keep][:3000]
+        p1s.append(X[:, :2] / X[:, 2:3])
+        p2s.append(Y[:, :2] / Y[:, 2:3])
+    pool1 = np.concatenate(p1s + [rng.uniform(-0.6, 0.6, size=(60000, 2))])   # + random pairs: a few survive under nobody
+    pool2 = np.concatenate(p2s + [rng.uniform(-0.6, 0.6, size=(60000, 2))])
+    surv = np.zeros((4, len(pool1)), dtype=bool)
+    for c, (R, tt) in enumerate(cands):
+        _, idx = o.triangulate_points(R, tt, pool1, pool2)
+        surv[c, idx] = True
+    only = [np.flatnonzero(surv[c] & (surv.sum(0) == 1)) for c in range(4)]   # points surviving under candidate c alone
+    none = np.flatnonzero(surv.sum(0) == 0)
+    assert min(len(x) for x in only) >= 600 and len(none) >= 40
+    K = np.eye(3)
+
+    def run(spec):
+        """spec: list of (candidate or None, count) runs, in order."""
+        used = [0, 0, 0, 0, 0]
+        sel = []
+        for c, n in spec:
+            src = none if c is None else only[c]
+            k = 4 if c is None else c
+            sel.extend(src[used[k]:used[k] + n].tolist())
+            used[k] += n
+        sel = np.array(sel)
+        p1, p2 = pool1[sel], pool2[sel]
+        got = ctx.recover_pose(E, p1, p2, K)
+        ok, R, tt, pts, idx = o.recover_pose_and_points(E, p1, p2)
+        assert got["ok"] == ok
+        if ok:
+            assert got["n_points"] == len(idx) and np.array_equal(got["point_idx"], idx)
+            assert helpers.rel_err(got["R1to2"], R) <= TIGHT and helpers.rel_err(got["points"], pts) <= TIGHT
+        return got, (R, tt, idx)
+
+    # exact tie between candidates 1 and 3, both beyond the prefix: the earlier one wins
+    got, (R, tt, idx) = run([(1, 300), (3, 300), (0, 50)])
+    assert len(idx) == 300 and np.array_equal(R, Ra) and np.array_equal(tt, -t)
+    # the prefix (64 inliers per candidate) sees only candidate 2, the total ties 2 with 0: candidate 0 (earlier) wins -> completed
+    got, (R, tt, idx) = run([(2, 200), (0, 200)])
+    assert len(idx) == 200 and np.array_equal(R, Ra) and np.array_equal(tt, t)
+    # the prefix favours candidate 3 (64 of 64), candidate 1 wins on the whole list
+    got, (R, tt, idx) = run([(3, 70), (1, 500), (None, 10)])
+    assert len(idx) == 500 and np.array_equal(R, Ra) and np.array_equal(tt, -t)
+    # the prefix-best wins by exactly one point over a candidate that appears only behind the prefix
+    got, (R, tt, idx) = run([(2, 150), (0, 149)])
+    assert len(idx) == 150 and np.array_equal(R, Rb)
+    # ... and loses by one
+    got, (R, tt, idx) = run([(2, 150), (0, 151)])
+    assert len(idx) == 151 and np.array_equal(R, Ra)
+    # fewer inliers than the prefix; nobody survives at all (recover_pose_and_points returns false)
+    run([(1, 5), (0, 4)])
+    got, _ = run([(None, 40)])
+    assert not got["ok"]
+
+
 @pytest.mark.parametrize("m,H,noise,thr", [(60, 256, 1e-4, 1e-3), (400, 1500, 2e-4, 2e-3), (1600, 700, 1e-3, 1e-2)])
 def test_two_view_random_scenes(ctx, m, H, noise, thr):
     rng = np.random.default_rng(m)
