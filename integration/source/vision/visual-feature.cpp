@@ -11,6 +11,7 @@
 #include <iostream>
 
 #include "mvslam-hip-glue.hpp"
+#include <unordered_map>
 
 namespace mvSLAM
 {
@@ -81,10 +82,21 @@ VisualFeature::~VisualFeature() {}
 
 bool VisualFeature::equivalent_to(const VisualFeature &other) const
 {
-    if (size() != other.size())
+    // the reference's semantics (visual-feature.cpp:141-167): both valid, equally many keypoints, and the two keypoint sets
+    // agree as sets of cv::KeyPoint::hash() values with every hash of *this met exactly once in `other` -- order is free
+    if (!valid() || !other.valid() || size() != other.size())
         return false;
-    for (size_t i = 0; i < size(); ++i)
-        if (m_keypoints[i] != other.m_keypoints[i])   // operator!= of base/image.hpp:50-51
+    std::unordered_map<size_t, size_t> seen_in_other;
+    for (const auto &kp : m_keypoints)
+        seen_in_other.emplace(kp.hash(), 0);
+    for (const auto &kp : other.m_keypoints) {
+        const auto it = seen_in_other.find(kp.hash());
+        if (it == seen_in_other.end())
+            return false;
+        ++it->second;
+    }
+    for (const auto &entry : seen_in_other)
+        if (entry.second != 1)
             return false;
     return true;
 }

@@ -902,8 +902,8 @@ public:
     static Params get_default_params() { return Params{10, false}; }  // image-pair.cpp:17-28
     ImagePair(const Frame &base_frame_, const Frame &pair_frame_, const CameraIntrinsics &K,
               const Params &params = get_default_params())
-        : valid(false), match_inlier_count(0), match_inlier_ssd(0), error(0), m_state(State::INVALID),
-          m_base(&base_frame_), m_pair(&pair_frame_), m_K(K)
+        : valid(false), match_inlier_count(0), match_inlier_ssd(0), error(infinity), m_state(State::INVALID),
+          m_base(&base_frame_), m_pair(&pair_frame_), m_K(K), m_params(params)   // error(infinity): image-pair.cpp:41
     {
         assert(base_frame_.id != pair_frame_.id);
         // match(base = train, pair = query) -> gather -> sfm_solve (image-pair.cpp:57-65,116-174) as ONE device pass
@@ -976,6 +976,30 @@ public:
         }
         return valid;
     }
+    // image-pair.cpp:77-114: would (base_frame, new_frame) make a better pair?  A light-weight reconstruction of the
+    // candidate; it must not have fewer inliers nor a smaller descriptor SSD than this pair (the reference's two tests as
+    // written, :96-100), is then refined, and replaces *this only if its refined error is below this pair's `error`
+    // (infinity until refine() has run, :41).  `new_frame` must outlive the pair, as the frames of the constructor do.
+    bool update(const Frame &new_frame)
+    {
+        if (new_frame.id == m_base->id || new_frame.id == m_pair->id)
+            return false;
+        Params params = m_params;
+        params.refine_structure_in_constructor = false;
+        ImagePair new_image_pair(*m_base, new_frame, m_K, params);
+        if (!new_image_pair.valid)
+            return false;
+        if (new_image_pair.match_inlier_count < match_inlier_count || new_image_pair.match_inlier_ssd < match_inlier_ssd)
+            return false;
+        new_image_pair.refine();          // (result ignored as in :103: a failed refinement leaves error = infinity)
+        if (new_image_pair.error < error) {
+            std::swap(*this, new_image_pair);
+            return true;
+        }
+        return false;
+    }
+    const Frame &base_frame() const { return *m_base; }
+    const Frame &pair_frame() const { return *m_pair; }
     State state() const { return m_state; }
     bool valid;
     uint32_t match_inlier_count;
@@ -990,6 +1014,7 @@ private:
     State m_state;
     const Frame *m_base, *m_pair;
     CameraIntrinsics m_K;
+    Params m_params;
 };
 
 }  // namespace mvSLAM

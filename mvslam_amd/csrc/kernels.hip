@@ -154,17 +154,24 @@ constexpr int kMmThreads = 256;
 constexpr int kMmQpw = 64;                           // queries per wavefront: two 32-column blocks share every A fragment read
 constexpr int kMmQueries = kMmQpw * (kMmThreads / 64);   // 256 queries per workgroup
 constexpr int kMmRowBytes = 256 + 16;                // unpacked row of a train tile, padded: ds_read_b128 of 32 rows spread over the banks
+constexpr int kMmKeyShift = 12;                      // key = distance field << 12 | train index: one int8 product (64 x -128) is -(2 << 12)
+static_assert(kMaxKp <= (1 << kMmKeyShift), "the train index must fit below the distance field of a match_mfma key");
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// 16 bits -> 16 bytes of 0 / 1 (element j = bit j)
+// 16 bits -> 16 bytes (element j = bit j), each byte 0 or 1 << SH.  A nibble times (0x00204081 << SH) has bit i of the nibble at
+// positions i + SH + 7 k (k = 0..3: no two terms meet, no carries; the highest is 3 + SH + 21 <= 31 for SH <= 7); the mask
+// keeps bit SH of every byte.  SH = 6: the train operand (0 / 64); SH = 7: the query operand (0 / 0x80 = -128 as int8), so that
+// one product is -8192 = -(2 << 12): the accumulator counts the dot product in units of the key's distance field (below).
+template <int SH>
 __device__ __forceinline__ v4i unpack16(uint32_t bits)
 {
+    constexpr uint32_t mul = 0x00204081u << SH, msk = 0x01010101u << SH;
     v4i r;
-    r.x = (int)((((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u);
-    r.y = (int)((((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u);
-    r.z = (int)((((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u);
-    r.w = (int)((((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u);
+    r.x = (int)((((bits >> 0) & 0xfu) * mul) & msk);
+    r.y = (int)((((bits >> 4) & 0xfu) * mul) & msk);
+    r.z = (int)((((bits >> 8) & 0xfu) * mul) & msk);
+    r.w = (int)((((bits >> 12) & 0xfu) * mul) & msk);
     return r;
 }
 
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
                                                                                                             double max_dist)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][32 * kMmRowBytes];   // unpacked train tiles (double buffer)
-    __shared__ __attribute__((aligned(16))) uint32_t s_key[2][32];                        // (|t| + 256) << 16 | train index
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[2][32];                        // (|t| + 256) << 12 | train index
     __shared__ uint32_t s_k0[2][kMmThreads], s_k1[2][kMmThreads];
     const int pair = blockIdx.y;
     const int n1 = min(b.n1[pair], b.max_kp), n2 = min(b.n2[pair], b.max_kp);
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             qn[c] += __popc(d[s8]);
-            Bf[c][s8] = unpack16(d[s8] >> (16 * half));
+            Bf[c][s8] = unpack16<7>(d[s8] >> (16 * half));
         }
     }
     const uint32_t *tr = b.desc1 + base * 8;
@@ -204,15 +211,15 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
         const int tr_i = t * 32 + row;
         const uint32_t bits = tr_i < n1 ? tr[(size_t)tr_i * 8 + dw] : 0u;
         unsigned char *dst = &s_tile[buf][row * kMmRowBytes + dw * 32];
-        *reinterpret_cast<v4i *>(dst) = unpack16(bits);
-        *reinterpret_cast<v4i *>(dst + 16) = unpack16(bits >> 16);
+        *reinterpret_cast<v4i *>(dst) = unpack16<6>(bits);
+        *reinterpret_cast<v4i *>(dst + 16) = unpack16<6>(bits >> 16);
         // the tile's key bases: |t| of the row, summed over its 8 dwords (8 adjacent lanes)
         int tn = __popc(bits);
         tn += __shfl_xor(tn, 1);
         tn += __shfl_xor(tn, 2);
         tn += __shfl_xor(tn, 4);
         if (dw == 0)
-            s_key[buf][row] = tr_i < n1 ? (((uint32_t)(tn + 256) << 16) | (uint32_t)tr_i) : 0xffffffffu;
+            s_key[buf][row] = tr_i < n1 ? (((uint32_t)(tn + 256) << kMmKeyShift) | (uint32_t)tr_i) : 0xffffffffu;
     };
     const int n_tiles = (n1 + 31) / 32;
     uint32_t k0[2] = {kKeyNone, kKeyNone}, k1[2] = {kKeyNone, kKeyNone};
@@ -222,27 +229,33 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
         const int buf = t & 1;
         if (t + 1 < n_tiles)
             stage(t + 1, buf ^ 1);
-        v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        // The accumulators START as the rows' key bases and the products are -(2 << 12) per common bit, so the tile product
+        // leaves the finished keys: key = ((|t| + 256 - 2 dot) << 12 | index) -- no vector instruction per element beyond the
+        // insertion itself (round 4: one v_mad_i32_i24 per element on top; 96 -> 64 vector instructions per tile pair).
+        // accumulator: column = lane & 31 (this lane's query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (the train):
+        // registers 4 g4 .. 4 g4 + 3 are rows 8 g4 + 4 half + (0 .. 3), whose key bases are 16 consecutive bytes.  Rows past
+        // the end have all-zero bits and the base 0xffffffff: the key stays kKeyNone, never selected.
+        v16i kb;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const v4i kb4 = *reinterpret_cast<const v4i *>(&s_key[buf][8 * g4 + 4 * half]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                kb[4 * g4 + e] = kb4[e];
+        }
+        v16i acc0, acc1;
         const unsigned char *arow = &s_tile[buf][col * kMmRowBytes + half * 16];   // A: row = lane & 31, k = 16 half + j
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             const v4i Af = *reinterpret_cast<const v4i *>(arow + s8 * 32);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[0][s8], acc0, 0, 0, 0);   // two independent accumulation chains
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[1][s8], acc1, 0, 0, 0);
+            // two independent accumulation chains; the first step of each reads the key bases as its C operand
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[0][s8], s8 == 0 ? kb : acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[1][s8], s8 == 0 ? kb : acc1, 0, 0, 0);
         }
-        // accumulator: column = lane & 31 (this lane's query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (the train)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            // registers 4 g4 .. 4 g4 + 3 are rows 8 g4 + 4 half + (0 .. 3): their key bases are 16 consecutive bytes
-            const v4i kb4 = *reinterpret_cast<const v4i *>(&s_key[buf][8 * g4 + 4 * half]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g4 + e, kb = kb4[e];
-                // key = kb - (dot << 17) (v_mad_i32_i24; exact: 0 <= dot <= 256); rows past the end have all-zero bits
-                // (dot = 0) and kb = 0xffffffff: never selected
-                key_insert(k0[0], k1[0], (uint32_t)(__mul24(acc0[r], -(1 << 17)) + kb));
-                key_insert(k0[1], k1[1], (uint32_t)(__mul24(acc1[r], -(1 << 17)) + kb));
-            }
+        for (int r = 0; r < 16; ++r) {
+            key_insert(k0[0], k1[0], (uint32_t)acc0[r]);
+            key_insert(k0[1], k1[1], (uint32_t)acc1[r]);
         }
         __syncthreads();
     }
@@ -262,10 +275,10 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
             uint32_t m0 = k0[c], m1 = k1[c];
             key_insert(m0, m1, s_k0[c][tid + 32]);
             key_insert(m0, m1, s_k1[c][tid + 32]);
-            // distance = (key >> 16) - 256 + |q|
-            const int D0 = m0 == kKeyNone ? 0x7fffffff : (int)(m0 >> 16) - 256 + qn[c];
-            const int D1 = m1 == kKeyNone ? 0x7fffffff : (int)(m1 >> 16) - 256 + qn[c];
-            const int I0 = m0 == kKeyNone ? -1 : (int)(m0 & 0xffffu);
+            // distance = (key >> 12) - 256 + |q|
+            const int D0 = m0 == kKeyNone ? 0x7fffffff : (int)(m0 >> kMmKeyShift) - 256 + qn[c];
+            const int D1 = m1 == kKeyNone ? 0x7fffffff : (int)(m1 >> kMmKeyShift) - 256 + qn[c];
+            const int I0 = m0 == kKeyNone ? -1 : (int)(m0 & ((1u << kMmKeyShift) - 1u));
             // Lowe ratio in double on float distances (visual-feature.cpp:67-68)
             const float f0 = (float)D0, f1 = (float)D1;
             const bool check1 = (double)f0 < ratio * (double)f1;

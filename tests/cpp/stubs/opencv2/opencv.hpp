@@ -51,6 +51,7 @@ struct KeyPoint {
     int octave, class_id;
     KeyPoint();
     KeyPoint(float x, float y, float size_, float angle_ = -1, float response_ = 0, int octave_ = 0, int class_id_ = -1);
+    size_t hash() const;
 };
 struct DMatch {
     int queryIdx, trainIdx, imgIdx;

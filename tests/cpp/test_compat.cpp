@@ -322,6 +322,67 @@ static void image_pair_refine()
     ASSERT_TRUE(refined.error > 0 && refined.T_pair_to_base_covar(0, 0) > 0);
 }
 
+static void image_pair_update()
+{   // ImagePair::update (front-end/image-pair.cpp:77-114; caller: VisualOdometer::add_frame): same frame ids -> false; a
+    // candidate with fewer inliers -> false; a candidate at least as good whose refined error beats this pair's -> swapped in
+    std::mt19937 g(11);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::normal_distribution<double> Npx(0.0, 0.3);
+    const int n = 300;
+    CameraIntrinsics K = Matrix3Type::Identity();
+    K(0, 0) = K(1, 1) = 525; K(0, 2) = 320; K(1, 2) = 240;
+    std::vector<Point3> X;
+    for (int i = 0; i < n; ++i) X.emplace_back(2 * U(g), 1.5 * U(g), 6 + 3 * U(g));
+    std::vector<std::vector<uint8_t>> rows(n, std::vector<uint8_t>(32));
+    for (auto &r : rows) for (auto &b : r) b = (uint8_t)(g() & 0xff);
+    // frame k sees the cloud from pose k; `keep` of its features carry their point's descriptor (one bit flipped per frame),
+    // the others a fresh random one (no partner anywhere)
+    auto make_frame = [&](uint32_t id, const SE3 &pose, int keep) {
+        auto ip = PinholeCamera(K, pose).project_points(X);
+        std::vector<KeyPoint> kp(n);
+        Mat8u d;
+        d.cols = 32;
+        for (int i = 0; i < n; ++i) {
+            kp[i] = KeyPoint{{(float)(ip[i].x + Npx(g)), (float)(ip[i].y + Npx(g))}, 31, 0, 0, 0, -1};
+            std::vector<uint8_t> row = rows[i];
+            if (i < keep)
+                row[(i + id) % 32] ^= (uint8_t)(1u << (id % 8));
+            else
+                for (auto &b : row) b = (uint8_t)(g() & 0xff);
+            d.push_back_row(row.data());
+        }
+        return Frame{id, VisualFeature(kp, d, 640, 480)};
+    };
+    const SE3 P2 = SE3::exp(Vector6Type{0.3, 0.02, 0.01, 0.01, 0.03, -0.02}).inverse();
+    const SE3 P3 = SE3::exp(Vector6Type{0.45, -0.03, 0.02, -0.01, 0.02, 0.015}).inverse();
+    const Frame f1 = make_frame(1, SE3(), n), f2 = make_frame(2, P2, 220), f3 = make_frame(3, P3, n), f4 = make_frame(4, P3, 120);
+    hip::ransac_config().num_hypotheses = 512;
+    hip::ransac_config().sampler = MVS_SAMPLER_PHILOX;
+    hip::ransac_config().seed = 3;
+    hip::ransac_config().max_error_sq = 1e-2;
+    ImagePair pair(f1, f2, K, ImagePair::get_default_params());
+    ASSERT_TRUE(pair.valid && pair.state() == ImagePair::State::RECONSTRUCTED && pair.error == infinity);
+    const uint32_t count12 = pair.match_inlier_count;
+    ASSERT_TRUE(count12 > 150 && count12 <= 220);
+    ASSERT_TRUE(!pair.update(f1) && !pair.update(f2));                 // the pair's own frames (:80-84)
+    ASSERT_TRUE(!pair.update(f4));                                     // fewer inliers than (1, 2) (:96-100)
+    ASSERT_TRUE(pair.pair_frame().id == 2 && pair.match_inlier_count == count12 && pair.state() == ImagePair::State::RECONSTRUCTED);
+    ASSERT_TRUE(pair.update(f3));                                      // more inliers, larger SSD, refined error < infinity
+    ASSERT_TRUE(pair.pair_frame().id == 3 && pair.base_frame().id == 1 && pair.state() == ImagePair::State::REFINED);
+    ASSERT_TRUE(pair.match_inlier_count > count12 && pair.error < infinity && pair.error > 0);
+    ASSERT_TRUE(pair.matched_points_covar.size() == pair.matched_points.size());
+    const Vector6Type want = P3.inverse().ln(), got = pair.T_pair_to_base.ln();
+    double er = 0;
+    for (int i = 3; i < 6; ++i) er += sqr(got[i] - want[i]);
+    ASSERT_TRUE(er < 1e-5);
+    // the same candidate again: (1, 3) against itself has equal counts and SSD, its refined error is not below its own
+    const Frame f5 = make_frame(5, P3, n);
+    const ScalarType err13 = pair.error;
+    const bool again = pair.update(f5);
+    ASSERT_TRUE(again ? pair.error < err13 : pair.error == err13);
+    hip::ransac_config() = hip::RansacConfig();
+}
+
 static void ba_frame_pose_and_point_two_frames()
 {   // the reference's own BA entry point (vision/ba.hpp:25-36) shaped like VisualOdometer::track_refine: frame 7 anchored
     // at its own pose, frame 9 regularised, even point ids with priors, odd ones without, one observation missing
@@ -420,6 +481,7 @@ int main()
         RUN(sfm_refine_L_shape);
         RUN(pnp_refine_L_shape);
         RUN(image_pair_refine);
+        RUN(image_pair_update);
         RUN(ba_frame_pose_and_point_two_frames);
         RUN(visual_feature_extract_and_match);
     } catch (const std::exception &e) {

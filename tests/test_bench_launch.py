@@ -7,6 +7,7 @@ carries (contiguous blocks of pairs per rank, one all-ga
 import json
 import os
 import subprocess
+import tempfile
 import sys
 import time
 
@@ -80,17 +81,24 @@ def test_two_rank_bench_through_the_plain_entry_point():
     env = dict(os.environ, MVS_BENCH_ONE_DEVICE="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
+    detail = os.path.join(tempfile.mkdtemp(prefix="mvs_bench_"), "detail.json")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "8",
-                        "--hyp", "512", "--kp", "500", "--steps", "2", "--warmup", "1", "--launch-timeout", "600"],
+                        "--hyp", "512", "--kp", "500", "--steps", "2", "--warmup", "1", "--launch-timeout", "600",
+                        "--detail", detail],
                        env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    line = [ln for ln in p.stdout.splitlines() if ln.strip()][-1]      # the LAST stdout line is the compact one
+    assert len(line) < 4096
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["ranks_seen"] == [0, 1]
-    assert d["work"]["gathered_records"] == 2 * 8
+    assert d["gathered_records"] == 2 * 8
     assert d["gather_us"] > 0
-    r = d["ms_per_step_ranks"]
-    assert 0 < r["min"] <= r["max"] and abs(r["max"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"] + 1.0
     assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
-    assert "cpu_baseline" not in d        # rank 0 at N = 1 only
+    assert d["cpu_baseline"] is None        # rank 0 at N = 1 only
+    assert d["detail"] == detail
+    full = json.load(open(detail))           # the bulky object beside it
+    assert full["work"]["gathered_records"] == 2 * 8 and full["value"] == d["value"]
+    r = full["ms_per_step_ranks"]
+    assert 0 < r["min"] <= r["max"] and abs(r["max"] - d["ms_per_step"]) < 0.5 * d["ms_per_step"] + 1.0
+    assert "cpu_baseline" not in full
