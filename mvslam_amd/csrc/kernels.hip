@@ -159,24 +159,42 @@ static_assert(kMaxKp <= (1 << kMmKeyShift), "the train index must fit below the 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// 16 bits -> 16 bytes (element j = bit j), each byte 0 or 1 << SH.  A nibble times (0x00204081 << SH) has bit i of the nibble at
-// positions i + SH + 7 k (k = 0..3: no two terms meet, no carries; the highest is 3 + SH + 21 <= 31 for SH <= 7); the mask
-// keeps bit SH of every byte.  SH = 6: the train operand (0 / 64); SH = 7: the query operand (0 / 0x80 = -128 as int8), so that
-// one product is -8192 = -(2 << 12): the accumulator counts the dot product in units of the key's distance field (below).
+// 16 bits -> 16 bytes (element j = bit j), each byte 0 or 1 << SH.  A nibble times 0x00204081 has bit i of the nibble at
+// positions i + 7 k (k = 0..3: no two terms meet, no carries); the mask keeps bit 0 of every byte, the shift moves it to bit
+// SH.  SH = 6: the train operand (0 / 64); SH = 7: the query operand (0 / 0x80 = -128 as int8), so that one product is
+// -8192 = -(2 << 12): the accumulator counts the dot product in units of the key's distance field (below).  The product is a
+// 4-bit by 22-bit one: v_mul_u32_u24 (full rate; v_mul_lo_u32 issues at a quarter of it -- eight of them per thread and tile
+// were a third of the staging's issue slots).
 template <int SH>
 __device__ __forceinline__ v4i unpack16(uint32_t bits)
 {
-    constexpr uint32_t mul = 0x00204081u << SH, msk = 0x01010101u << SH;
     v4i r;
-    r.x = (int)((((bits >> 0) & 0xfu) * mul) & msk);
-    r.y = (int)((((bits >> 4) & 0xfu) * mul) & msk);
-    r.z = (int)((((bits >> 8) & 0xfu) * mul) & msk);
-    r.w = (int)((((bits >> 12) & 0xfu) * mul) & msk);
+    r.x = (int)((__umul24((bits >> 0) & 0xfu, 0x00204081u) & 0x01010101u) << SH);
+    r.y = (int)((__umul24((bits >> 4) & 0xfu, 0x00204081u) & 0x01010101u) << SH);
+    r.z = (int)((__umul24((bits >> 8) & 0xfu, 0x00204081u) & 0x01010101u) << SH);
+    r.w = (int)((__umul24((bits >> 12) & 0xfu, 0x00204081u) & 0x01010101u) << SH);
     return r;
 }
 
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// CAPPED (round 5): the caller's max_dist >= 0 makes most keys irrelevant.  A query passes iff D0 <= max_dist and
+// D0 < ratio * D1 (visual-feature.cpp:67-68); with C = the smallest integer whose ratio * C exceeds max_dist (host, the same
+// float -> double expression as below), any D1 >= C passes the ratio test for every D0 <= max_dist, and any D0 >= C fails the
+// distance test.  So only keys with a distance below C can change the result: the accumulators of a tile are reduced to group
+// minima (v_min3_u32: 10 instructions per 16 keys instead of 32) and a group is inserted -- in full, so the lane's two smallest
+// RELEVANT keys are always exact -- only when some lane of the wavefront sees a relevant key in it (a query has one true
+// partner among 2000 random rows: 0.4 of the blocks take the slow path, for one group of four).  Keys at or above the cap that
+// ride along are real keys of real rows: wherever they end up in the top two they stand for "some distance >= C", which is
+// what the exact list would show there too.  Match lists stay byte-identical (tests/test_gpu_parity.py::test_match_*).
+template <bool CAPPED>
 __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8))) void match_mfma_kernel(BatchDev b, double ratio,
-                                                                                                            double max_dist)
+                                                                                                            double max_dist, int cap_dist)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[2][32 * kMmRowBytes];   // unpacked train tiles (double buffer)
     __shared__ __attribute__((aligned(16))) uint32_t s_key[2][32];                        // (|t| + 256) << 12 | train index
@@ -223,6 +241,8 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
     };
     const int n_tiles = (n1 + 31) / 32;
     uint32_t k0[2] = {kKeyNone, kKeyNone}, k1[2] = {kKeyNone, kKeyNone};
+    // relevant keys of this lane's two queries: distance = (key >> 12) - 256 + |q| < cap_dist
+    const uint32_t capk[2] = {(uint32_t)(cap_dist + 256 - qn[0]) << kMmKeyShift, (uint32_t)(cap_dist + 256 - qn[1]) << kMmKeyShift};
     stage(0, 0);
     __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
@@ -252,10 +272,31 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 8
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[0][s8], s8 == 0 ? kb : acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af, Bf[1][s8], s8 == 0 ? kb : acc1, 0, 0, 0);
         }
+        if (!CAPPED) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            key_insert(k0[0], k1[0], (uint32_t)acc0[r]);
-            key_insert(k0[1], k1[1], (uint32_t)acc1[r]);
+            for (int r = 0; r < 16; ++r) {
+                key_insert(k0[0], k1[0], (uint32_t)acc0[r]);
+                key_insert(k0[1], k1[1], (uint32_t)acc1[r]);
+            }
+        } else {
+            auto lazy = [&](const v16i &acc, uint32_t &a0, uint32_t &a1, uint32_t cap) {
+                uint32_t g[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    g[q4] = min(umin3((uint32_t)acc[4 * q4], (uint32_t)acc[4 * q4 + 1], (uint32_t)acc[4 * q4 + 2]), (uint32_t)acc[4 * q4 + 3]);
+                const uint32_t tm = min(umin3(g[0], g[1], g[2]), g[3]);
+                if (__any(tm < cap)) {       // wave-uniform: some lane has a relevant key in this tile
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        if (__any(g[q4] < cap)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                key_insert(a0, a1, (uint32_t)acc[4 * q4 + e]);
+                        }
+                }
+            };
+            lazy(acc0, k0[0], k1[0], capk[0]);
+            lazy(acc1, k0[1], k1[1], capk[1]);
         }
         __syncthreads();
     }
@@ -3643,10 +3684,10 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
     KernelDesc d{nullptr, nullptr, 0, 0};
     switch (id) {
     case kKMatchTopk:
-        d.name = desc_words == 4 ? "match_topk_kernel<4>" : desc_words == 16 ? "match_topk_kernel<16>" : "match_mfma_kernel";
+        d.name = desc_words == 4 ? "match_topk_kernel<4>" : desc_words == 16 ? "match_topk_kernel<16>" : "match_mfma_kernel<true>";
         d.fn = desc_words == 4    ? reinterpret_cast<const void *>(match_topk_kernel<4>)
                : desc_words == 16 ? reinterpret_cast<const void *>(match_topk_kernel<16>)
-                                  : reinterpret_cast<const void *>(match_mfma_kernel);
+                                  : reinterpret_cast<const void *>(match_mfma_kernel<true>);
         d.threads = desc_words == 8 ? kMmThreads : 1024;
         break;
     case kKMatchCompact:
@@ -3816,6 +3857,19 @@ void set_match_mfma(int v) { g_match_mfma = v; }
 constexpr int g_match_mfma = 1;
 #endif
 
+// The cap of match_mfma_kernel<true>: the smallest integer distance C with ratio * C > max_dist, evaluated exactly as the
+// kernel evaluates the ratio test (float distance -> double); -1 when the call has no distance limit (max_dist < 0), no usable
+// ratio, or a limit so wide that random rows would reach it (Hamming distances of unrelated 256-bit descriptors are 128 +- 8).
+static int match_cap_distance(double ratio, double max_dist)
+{
+    if (!(max_dist >= 0.0) || !(ratio > 0.0))
+        return -1;
+    for (int c = 0; c <= 96; ++c)
+        if (ratio * (double)(float)c > max_dist)
+            return c;
+    return -1;
+}
+
 void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hipStream_t stream, LaunchTimer *lt)
 {
     const dim3 grid((b.max_kp + 63) / 64, n_active), block(1024);
@@ -3828,10 +3882,14 @@ void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hip
         // per 512 pairs), but a long serial walk when there are only a handful of workgroups -- one pair: 60 us against 22 for
         // the vector kernel with its 64 queries per workgroup.  Below two workgroups per CU the vector kernel runs.
         const int mm_groups = ((b.max_kp + kMmQueries - 1) / kMmQueries) * n_active;
-        if (g_match_mfma == 2 || (g_match_mfma == 1 && mm_groups >= 512))
-            hipLaunchKernelGGL(match_mfma_kernel, dim3((b.max_kp + kMmQueries - 1) / kMmQueries, n_active), dim3(kMmThreads), 0,
-                               stream, b, ratio, md);
-        else
+        if (g_match_mfma == 2 || (g_match_mfma == 1 && mm_groups >= 512)) {
+            const dim3 mgrid((b.max_kp + kMmQueries - 1) / kMmQueries, n_active);
+            const int cap = match_cap_distance(ratio, md);
+            if (cap >= 0)
+                hipLaunchKernelGGL(match_mfma_kernel<true>, mgrid, dim3(kMmThreads), 0, stream, b, ratio, md, cap);
+            else
+                hipLaunchKernelGGL(match_mfma_kernel<false>, mgrid, dim3(kMmThreads), 0, stream, b, ratio, md, 0);
+        } else
             hipLaunchKernelGGL(match_topk_kernel<8>, grid, block, 0, stream, b, ratio, md);
         break;
     }

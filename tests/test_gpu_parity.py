@@ -44,7 +44,11 @@ def test_match_matrix_core_kernel_batch_bit_exact(ctx):
     """The int8-GEMM matcher (match_mfma_kernel) serves 256-bit descriptors once a batch has enough workgroups for it
     (>= 512: two per CU); the single-shot tests above run the vector kernel.  A batch of 64 ragged pairs (64 x 8 = 512
     workgroups): random descriptors with planted near-duplicates, exact duplicates in the train set (ties: the smaller
-    train index must win), distances at the ratio boundary -- match lists byte-identical to the oracle for every pair."""
+    train index must win), distances at the ratio boundary -- match lists byte-identical to the oracle for every pair.
+    Round 5: with a distance limit the kernel only inserts keys below a cap C (smallest C with ratio * C > max_dist) --
+    planted (d0, d1) partner pairs sit on every side of C and of max_dist, and the batch runs under five (ratio, max_dist)
+    settings: the reference's (0.7, 10), no limit (the uncapped kernel), a wide limit (C = 92: random rows get close),
+    a tight one, and zero."""
     rng = np.random.default_rng(4242)
     P, N = 64, 2000
     n1 = rng.integers(2, N + 1, size=P).astype(np.int32)
@@ -64,22 +68,50 @@ def test_match_matrix_core_kernel_batch_bit_exact(ctx):
         if n1[p] > 50:
             d1[p, 40] = d1[p, 3]                                  # duplicate train rows
             d1[p, 17] = d1[p, 3]
+    # two partners at exact distances (fa, fb) from a query: a fresh row with fa / fb DISJOINT flipped bits
+    combos = [(10, 14), (10, 15), (10, 16), (11, 15), (11, 16), (9, 13), (7, 10), (7, 11), (10, 10), (0, 1), (14, 15), (15, 16),
+              (10, 100), (3, 4), (3, 5), (2, 4), (64, 91), (64, 92), (64, 93), (63, 90), (65, 93), (40, 57), (40, 58), (0, 0),
+              (1, 1), (44, 63), (45, 64)]
+    planted = 0
+    for p in range(P):
+        if n1[p] < 700 or n2[p] < 700:
+            continue
+        for i, (fa, fb) in enumerate(combos):
+            row = rng.integers(0, 256, size=32, dtype=np.uint8)
+            bits = rng.permutation(256)[:fa + fb]
+            ra, rb = row.copy(), row.copy()
+            for bit in bits[:fa]:
+                ra[bit >> 3] ^= np.uint8(1 << (bit & 7))
+            for bit in bits[fa:]:
+                rb[bit >> 3] ^= np.uint8(1 << (bit & 7))
+            # the nearer partner sometimes at the higher train index, in different 32-row tiles and lane halves
+            ia, ib = 500 + 5 * i, 503 + 5 * i + 37 * (i % 3)
+            if i % 2:
+                ia, ib = ib, ia
+            d1[p, ia], d1[p, ib], d2[p, 600 + i] = ra, rb, row
+            planted += 1
+    assert planted > 500
     kp = np.zeros((P, N, 2), dtype=np.float32)
     kp[..., 0] = rng.uniform(0, 640, size=(P, N))
     kp[..., 1] = rng.uniform(0, 480, size=(P, N))
     K = np.tile(synth.K_DEFAULT.reshape(1, 9), (P, 1))
     b = capi.Batch(ctx, P, N, 32)
     b.upload(0, d1, kp, n1, d2, kp, n2, K, np.arange(P, dtype=np.int64))
-    prm = capi.default_params(num_hypotheses=64, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-2)
-    b.run(prm)
-    b.sync()
-    out = b.download(mask=False, points=False)
+    for ratio, max_dist in ((0.7, 10.0), (0.7, -1.0), (0.7, 64.0), (0.9, 3.0), (0.7, 0.0)):
+        prm = capi.default_params(num_hypotheses=64, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-2, ratio=ratio,
+                                  max_dist=max_dist)
+        b.run(prm)
+        b.sync()
+        out = b.download(mask=False, points=False)
+        total = 0
+        for p in range(P):
+            ref = o.match_visual_features(d1[p, :n1[p]], d2[p, :n2[p]], ratio, max_dist)
+            m = int(out["results"][p]["n_matches"])
+            assert m == len(ref), (ratio, max_dist, p, m, len(ref))
+            assert out["matches"][p][:m].tobytes() == ref.tobytes(), (ratio, max_dist, p)
+            total += m
+        assert total > 1000, (ratio, max_dist, total)
     b.close()
-    for p in range(P):
-        ref = o.match_visual_features(d1[p, :n1[p]], d2[p, :n2[p]], prm.ratio, prm.max_dist)
-        m = int(out["results"][p]["n_matches"])
-        assert m == len(ref), (p, m, len(ref))
-        assert out["matches"][p][:m].tobytes() == ref.tobytes(), p
 
 
 def test_match_ties_canonical_order(ctx):
