@@ -31,7 +31,9 @@ extern "C" {
 /* 3 (round 4): mvs_work_stats grew by FIVE fields (max_sweeps9, dense_points, matches_mode1, score_evals_executed_mfma_rest,
  * score_evals_executed_mfma_pilot; score_evals_executed is the sum of every executed-evaluation counter); every entry point
  * and every other struct is unchanged from version 2 */
-#define MVS_ABI_VERSION 3
+/* 4 (round 5): two entry points added -- mvs_batch_device_state (read-only diagnostics view, below) and mvs_batch_run_points
+ * (a batch of sfm_solve calls on caller-supplied point pairs); nothing else changed */
+#define MVS_ABI_VERSION 4
 
 typedef enum mvs_status {
     MVS_OK = 0,
@@ -208,6 +210,17 @@ void mvs_host_free(void *p);
 mvs_status mvs_batch_run(mvs_batch *b, const mvs_params *params, int n_active);
 mvs_status mvs_batch_sync(mvs_batch *b);
 
+/* A batch of sfm_solve calls (vision/sfm.hpp:30-35; vision/sfm-solve.cpp:285-368) on caller-supplied matched image points:
+ * what mvs_batch_run does behind the matcher (normalise -> 8-point RANSAC -> E -> decomposition -> triangulation), for pairs
+ * [0, n_active).  uv1 / uv2: HOST memory, [n_active][max_kp][2] doubles, row k of pair p = match k in the base / pair frame;
+ * m[p] = matches of pair p (0 .. max_kp; fewer than 8 -> the pair comes back invalid, estimator-RANSAC.cpp:25-29).  Uses
+ * the intrinsics and sampler key offsets resident in the batch (mvs_batch_upload accepts null descriptor / keypoint pointers
+ * to set only K and global_index).  The host buffers are free again when the call returns; the kernels are asynchronous on
+ * the ctx stream.  Afterwards mvs_batch_download returns results / mask / points / point_idx as usual (point_idx indexes the
+ * rows of uv1 / uv2) and cleared match rows. */
+mvs_status mvs_batch_run_points(mvs_batch *b, const mvs_params *params, int n_active, const double *uv1, const double *uv2,
+                                const int32_t *m);
+
 /* Timed replay: `warmup` untimed + `steps` timed passes over the resident inputs, bracketed by HIP events
  * on the ctx stream.  ms_total: wall ms of the `steps` passes.  ms_kernel[5]: summed ms per kernel over the
  * timed passes, in launch order {match (match_mfma or match_topk), match_compact, ransac, finalize, reserved}; measured with
@@ -288,6 +301,13 @@ typedef struct mvs_work_stats {
                                      mode 1 on every match, both bounds): included in score_evals_executed */
 } mvs_work_stats;
 mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active, mvs_work_stats *out);
+
+/* Diagnostics: a read-only, opaque view of the batch's device-resident state (the library's internal table of device pointers
+ * and capacities, prefixed by its size and the ABI version).  Nothing is launched, copied on the device or modified; call
+ * mvs_batch_sync first.  Its one consumer is the audit of libmvslam_hip_dbg.so (same sources, same process), which replays
+ * every hypothesis exactly and checks the decisions THIS library's kernels left in device memory
+ * (tests/audit_gpu_check.py).  dst == NULL: *size receives the number of bytes needed. */
+mvs_status mvs_batch_device_state(mvs_batch *b, void *dst, size_t capacity, size_t *size);
 
 /* Device pointer + pitch of the fixed-size result records (mvs_pair_result[n_pairs]) so a caller can hand them
  * to a collective (RCCL all-gather of poses) without a host round trip. */

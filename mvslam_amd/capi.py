@@ -132,8 +132,29 @@ EXPORTS = [
     "mvs_ba_refine", "mvs_seq_download_trajectory", "mvs_batch_upload_octaves", "mvs_seq_upload_octaves",
     "mvs_batch_upload_async", "mvs_batch_download_async", "mvs_host_alloc", "mvs_host_free", "mvs_image_pair",
     "mvs_batch_gather_results", "mvs_seq_time_stages", "mvs_batch_time_kernels", "mvs_kernel_info_get",
-    "mvs_extract_time", "mvs_ctx_set_half_batches",
+    "mvs_extract_time", "mvs_ctx_set_half_batches", "mvs_batch_device_state", "mvs_batch_run_points",
 ]
+
+
+_dbg = None
+
+
+def dbg_lib():
+    """The diagnostics library, loaded SIDE BY SIDE with the product one (its own handle, its own copy of every symbol): the
+    tests let the product binary run the stage and hand its device state to this library's audit (mvs_debug_audit_state)."""
+    global _dbg
+    if _dbg is None:
+        if not os.path.exists(DBG_LIB_PATH):
+            raise RuntimeError("libmvslam_hip_dbg.so is missing (%s): make -C mvslam_amd/csrc" % DBG_LIB_PATH)
+        _dbg = C.CDLL(DBG_LIB_PATH)
+        _dbg.mvs_last_error.restype = C.c_char_p
+        _dbg.mvs_last_error.argtypes = [C.c_void_p]
+        _dbg.mvs_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        _dbg.mvs_ctx_destroy.argtypes = [C.c_void_p]
+        _dbg.mvs_debug_audit_state.restype = C.c_int
+        _dbg.mvs_debug_audit_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]
+    return _dbg
 
 
 class MvsError(RuntimeError):
@@ -602,6 +623,42 @@ class Batch:
     def run(self, params, n_active=None):
         st = lib().mvs_batch_run(self._h, C.byref(params), C.c_int(n_active or self.n_pairs))
         self.ctx._check(st, "mvs_batch_run")
+
+    def upload_intrinsics(self, first, K, global_index=None, count=None):
+        """only K (+ the sampler key offsets) of pairs [first, first + count): what run_points() needs resident"""
+        K = _f64(K)
+        count = count or (K.size // 9 if K.size > 9 else self.n_pairs - first)
+        if K.size == 9:
+            K = np.tile(K.reshape(1, 9), (count, 1))
+        K = np.ascontiguousarray(K.reshape(count, 9))
+        gi = None if global_index is None else np.ascontiguousarray(global_index, dtype=np.int64)
+        st = lib().mvs_batch_upload(self._h, C.c_int(first), C.c_int(count), None, None, None, None, None, None,
+                                    _ptr(K, C.c_double), _ptr(gi, C.c_int64))
+        self.ctx._check(st, "mvs_batch_upload")
+
+    def run_points(self, params, uv1, uv2, m):
+        """a batch of sfm_solve calls on matched image points: uv1 / uv2 [count][<= max_kp][2], m [count] (mvs_batch_run_points)"""
+        m = np.ascontiguousarray(m, dtype=np.int32)
+        count, N = len(m), self.max_kp
+
+        def pad(a):
+            a = _f64(a)
+            out = np.zeros((count, N, 2))
+            out[:, :a.shape[1]] = a.reshape(count, -1, 2)
+            return out
+
+        u1, u2 = pad(uv1), pad(uv2)
+        st = lib().mvs_batch_run_points(self._h, C.byref(params), C.c_int(count), _ptr(u1, C.c_double), _ptr(u2, C.c_double),
+                                        _ptr(m, C.c_int32))
+        self.ctx._check(st, "mvs_batch_run_points")
+
+    def device_state(self):
+        """opaque bytes of the batch's device-resident state (mvs_batch_device_state): for the diagnostics library's audit"""
+        n = C.c_size_t(0)
+        self.ctx._check(lib().mvs_batch_device_state(self._h, None, C.c_size_t(0), C.byref(n)), "mvs_batch_device_state")
+        buf = (C.c_ubyte * n.value)()
+        self.ctx._check(lib().mvs_batch_device_state(self._h, buf, n, C.byref(n)), "mvs_batch_device_state")
+        return buf
 
     def sync(self):
         self.ctx._check(lib().mvs_batch_sync(self._h), "mvs_batch_sync")

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.hpp"
@@ -24,6 +25,7 @@ struct mvs_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool half_batches = true;
+    int cu_count = 256;   // hipDeviceAttributeMultiprocessorCount of `device` (mvs_ctx_create); MI355X: 256
     std::string err;
     mvs_batch *scratch = nullptr;  // batch of one pair backing the single-shot entry points
     double *d_uv1 = nullptr, *d_uv2 = nullptr;
@@ -58,6 +60,7 @@ struct mvs_batch {
     mvs_ctx *ctx = nullptr;
     BatchDev d{};
     std::vector<void *> allocs;
+    double *uv1 = nullptr, *uv2 = nullptr;   // [n_pairs][max_kp][2] staging of mvs_batch_run_points (first use)
     int hyp_table_cap = 0;  // capacity of the optional per-hypothesis tables
     int32_t *allocs_hc = nullptr;
     double *allocs_hr = nullptr;
@@ -541,6 +544,61 @@ int mvs_debug_audit(mvs_batch *b, const mvs_params *params, int n_active, int ph
     return MVS_OK;
 }
 
+// The same audit over the device state of ANOTHER library instance's batch (mvs_batch_device_state of libmvslam_hip.so, loaded
+// in the same process): the product binary ran the stage, this library only replays every hypothesis exactly and compares.
+// phase 1: the stage's decisions; phase 2: the records as the product's pre-screen wrote them and the stage left them (every
+// record still in state kPsApprox: (B) on every match, U >= c_J >= L) -- phase 0's checks WITHOUT re-running the pre-screen.
+int mvs_debug_audit_state(mvs_ctx *ctx, const void *state, size_t state_bytes, const mvs_params *params, int n_active, int phase,
+                          unsigned long long counters[16], int32_t *maxc, int32_t *bound, int32_t *mode)
+{
+    struct Blob {
+        uint64_t bytes, abi;
+        BatchDev d;
+    };
+    if (!ctx || !state || !params || !counters || (phase != 1 && phase != 2))
+        return MVS_ERR_INVALID_ARG;
+    Blob blob;
+    if (state_bytes != sizeof(Blob))
+        return MVS_ERR_INVALID_ARG;
+    std::memcpy(&blob, state, sizeof(Blob));
+    if (blob.bytes != sizeof(Blob) || blob.abi != (uint64_t)MVS_ABI_VERSION)
+        return MVS_ERR_INVALID_ARG;   // not the same build
+    const BatchDev &d = blob.d;
+    if (n_active < 1 || n_active > d.n_pairs || (params->num_hypotheses + kHypPerBlock - 1) / kHypPerBlock > d.max_groups)
+        return MVS_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const RunParams rp = to_run(*params);
+    unsigned long long *dc = nullptr;
+    int32_t *dm = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dc, 16 * sizeof(unsigned long long)));
+    if (hipMalloc((void **)&dm, (size_t)n_active * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(dc);
+        return MVS_ERR_HIP;
+    }
+    hipError_t e = hipMemsetAsync(dc, 0, 16 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dm, 0xff, (size_t)n_active * sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess)
+        e = launch_audit(d, rp, n_active, phase == 2 ? 0 : 1, dc, dm, ctx->stream);
+    if (e == hipSuccess)
+        e = sync_stream(ctx);
+    if (e == hipSuccess)
+        e = hipMemcpy(counters, dc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && maxc)
+        e = hipMemcpy(maxc, dm, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && bound)
+        e = hipMemcpy(bound, d.bound, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && mode)
+        e = hipMemcpy(mode, d.mode, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dc);
+    (void)hipFree(dm);
+    if (e != hipSuccess) {
+        ctx->err = std::string("mvs_debug_audit_state: ") + hipGetErrorString(e);
+        return MVS_ERR_HIP;
+    }
+    return MVS_OK;
+}
+
 // overwrite the ideal-camera points of one pair: pts4 = m x (x1, y1, x2, y2) doubles (the matcher's output is bypassed)
 int mvs_debug_set_points(mvs_batch *b, int pair, int m, const double *pts4)
 {
@@ -705,7 +763,9 @@ mvs_status mvs_ctx_create_on_stream(int device_id, void *hip_stream, mvs_ctx **o
     }
     {
         // the scoring, refinement and extraction kernels are laid out for the 160 KB of LDS a gfx950 compute unit has
-        int lds = 0;
+        int lds = 0, cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+            c->cu_count = cus;
         const hipError_t e1 = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id);
         const hipError_t e2 = e1 == hipSuccess && lds >= 160 * 1024 ? prepare_kernels() : hipErrorInvalidDevice;
         if (e2 != hipSuccess) {
@@ -797,6 +857,7 @@ static mvs_status batch_create_impl(mvs_ctx *ctx, int n_pairs, int max_kp, int d
     d.max_kp = max_kp;
     d.desc_words = desc_bytes / 4;
     d.max_groups = 0;
+    d.cu_count = ctx->cu_count;
     const size_t P = n_pairs, N = max_kp;
     mvs_status st = MVS_OK;
     uint32_t *desc1, *desc2;
@@ -1055,12 +1116,14 @@ static BatchDev batch_view(const BatchDev &b, int first, int count, int half)
 constexpr int kHalvesMinPairs = 64;   // a batch of at least this many pairs runs as two halves on two streams
 
 static void enqueue_stages(const BatchDev &d, const RunParams &rp, int n_active, bool stats, hipStream_t s, hipEvent_t *ev,
-                           LaunchTimer *lt)
+                           LaunchTimer *lt, bool with_match = true)
 {
     if (ev) (void)hipEventRecord(ev[0], s);
-    launch_match_topk(d, rp, n_active, s, lt);
+    if (with_match)
+        launch_match_topk(d, rp, n_active, s, lt);
     if (ev) (void)hipEventRecord(ev[1], s);
-    launch_match_compact(d, rp, n_active, s, lt);
+    if (with_match)
+        launch_match_compact(d, rp, n_active, s, lt);
     if (ev) (void)hipEventRecord(ev[2], s);
     launch_ransac(d, rp, n_active, stats, s, lt);
     if (ev) (void)hipEventRecord(ev[3], s);
@@ -1069,13 +1132,13 @@ static void enqueue_stages(const BatchDev &d, const RunParams &rp, int n_active,
 }
 
 static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_active, bool stats, hipEvent_t *ev,
-                                   LaunchTimer *lt = nullptr)
+                                   LaunchTimer *lt = nullptr, bool with_match = true)
 {
     mvs_ctx *ctx = b->ctx;
     hipStream_t s = ctx->stream;
     const bool halves = n_active >= kHalvesMinPairs && !stats && !ev && !lt && !b->d.hyp_count && ctx->half_batches;
     if (!halves) {
-        enqueue_stages(b->d, rp, n_active, stats, s, ev, lt);
+        enqueue_stages(b->d, rp, n_active, stats, s, ev, lt, with_match);
     } else {
         // two independent halves: the second on the side stream, after everything already queued on the main stream, and
         // joined back into it (the caller's next operation on the main stream sees both).  Measured on the bench batch:
@@ -1088,9 +1151,9 @@ static mvs_status enqueue_pipeline(mvs_batch *b, const RunParams &rp, int n_acti
         const int na = (n_active + 1) / 2;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));          // nothing is on the side stream yet: a plain return is safe
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-        enqueue_stages(batch_view(b->d, 0, na, 0), rp, na, false, s, nullptr, nullptr);
+        enqueue_stages(batch_view(b->d, 0, na, 0), rp, na, false, s, nullptr, nullptr, with_match);
         const hipError_t e_first = hipGetLastError();            // a launch failure of the first half, attributed to it
-        enqueue_stages(batch_view(b->d, na, n_active - na, 1), rp, n_active - na, false, ctx->side, nullptr, nullptr);
+        enqueue_stages(batch_view(b->d, na, n_active - na, 1), rp, n_active - na, false, ctx->side, nullptr, nullptr, with_match);
         const hipError_t e_second = hipGetLastError();
         // from here on work may be queued on the side stream: whatever fails, the caller's stream joins it before this call
         // returns (a later download or a release of the groups must never race with the second half) -- ADVICE r4
@@ -1122,6 +1185,54 @@ mvs_status mvs_batch_run(mvs_batch *b, const mvs_params *params, int n_active)
     b->d.hyp_count = nullptr;
     b->d.hyp_residual = nullptr;
     return enqueue_pipeline(b, to_run(*params), n_active, false, nullptr);
+}
+
+// A batch of sfm_solve calls (vision/sfm.hpp:30-35, sfm-solve.cpp:285-368) on caller-supplied point pairs: the matcher is
+// skipped, everything behind it is mvs_batch_run's (normalise -> RANSAC stage -> decomposition -> triangulation, half batches
+// on two streams included).  uv1 / uv2: HOST, [n_active][max_kp][2] doubles (image points of the base / pair frame, row k of
+// pair p = match k); m[p]: matches of pair p (0 .. max_kp).  The intrinsics and the sampler's key offsets are the resident
+// ones (mvs_batch_upload with null descriptor / keypoint pointers sets just K and global_index).  `matches` rows of the
+// batch are cleared (there is no match list: point k IS match k); results / mask / points / point_idx as after mvs_batch_run.
+mvs_status mvs_batch_run_points(mvs_batch *b, const mvs_params *params, int n_active, const double *uv1, const double *uv2,
+                                const int32_t *m)
+{
+    if (!b || !uv1 || !uv2 || !m || n_active < 1 || n_active > b->d.n_pairs)
+        return MVS_ERR_INVALID_ARG;
+    mvs_status st = check_params(params);
+    if (st != MVS_OK)
+        return st;
+    const size_t N = (size_t)b->d.max_kp;
+    for (int p = 0; p < n_active; ++p)
+        if (m[p] < 0 || m[p] > (int)N)
+            return MVS_ERR_CAPACITY;
+    mvs_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    st = ensure_groups(b, params->num_hypotheses);
+    if (st != MVS_OK)
+        return st;
+    if (!b->uv1) {   // staging for the image points, allocated on first use and owned by the batch
+        const size_t bytes = (size_t)b->d.n_pairs * N * 2 * sizeof(double);
+        void *a = nullptr, *c = nullptr;
+        HIP_TRY(ctx, hipMalloc(&a, bytes));
+        b->allocs.push_back(a);
+        HIP_TRY(ctx, hipMalloc(&c, bytes));
+        b->allocs.push_back(c);
+        b->uv1 = static_cast<double *>(a);
+        b->uv2 = static_cast<double *>(c);
+    }
+    hipStream_t s = ctx->stream;
+    const size_t pb = (size_t)n_active * N * 2 * sizeof(double);
+    HIP_TRY(ctx, hipMemcpyAsync(b->uv1, uv1, pb, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->uv2, uv2, pb, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d.M, m, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d.matches, 0, (size_t)n_active * N * sizeof(mvs_match), s));
+    // the host buffers are the caller's: they may change as soon as this call returns (pageable copies are staged by the
+    // runtime before hipMemcpyAsync returns; pinned ones are not) -- wait for the three copies, not for the kernels
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    launch_prep_points(b->d, b->uv1, b->uv2, n_active, s);
+    b->d.hyp_count = nullptr;
+    b->d.hyp_residual = nullptr;
+    return enqueue_pipeline(b, to_run(*params), n_active, false, nullptr, nullptr, false);
 }
 
 mvs_status mvs_batch_sync(mvs_batch *b)
@@ -1423,6 +1534,33 @@ mvs_status mvs_batch_stats(mvs_batch *b, const mvs_params *params, int n_active,
             out->score_evals += (int64_t)params->num_hypotheses * r.n_matches;
         }
     }
+    return MVS_OK;
+}
+
+
+// Read-only view of the batch's device-resident state for diagnostics (round 5): the bytes of the internal
+// BatchDev (device pointers + capacities, mvslam_amd/csrc/kernels.hpp), so that the audit in libmvslam_hip_dbg.so -- built from
+// the same sources -- can check what THIS library's kernels wrote, in place, in the same process.  Nothing is launched,
+// copied on the device or changed; the caller synchronises the batch first.  The layout is private: the blob starts with
+// its own size and the ABI version, which the consumer compares with its own.
+mvs_status mvs_batch_device_state(mvs_batch *b, void *dst, size_t capacity, size_t *size)
+{
+    struct Blob {
+        uint64_t bytes, abi;
+        BatchDev d;
+    };
+    static_assert(std::is_trivially_copyable<BatchDev>::value, "BatchDev is a POD of device pointers and sizes");
+    if (!b || !size)
+        return MVS_ERR_INVALID_ARG;
+    *size = sizeof(Blob);
+    if (!dst)
+        return MVS_OK;   // size query
+    if (capacity < sizeof(Blob))
+        return MVS_ERR_CAPACITY;
+    Blob blob{sizeof(Blob), (uint64_t)MVS_ABI_VERSION, b->d};
+    blob.d.hyp_count = nullptr;      // the optional per-hypothesis tables belong to the table entry points
+    blob.d.hyp_residual = nullptr;
+    std::memcpy(dst, &blob, sizeof(Blob));
     return MVS_OK;
 }
 

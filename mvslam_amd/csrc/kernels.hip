@@ -654,20 +654,6 @@ __device__ __forceinline__ void solve_record(const BatchDev &b, const RunParams 
         b.bound[pair] = 0;   // pruning bound of the scoring launch that follows on the stream
 }
 
-#ifdef MVS_DEBUG_HOOKS   // experiment ladder (variants 632 / 760 / 1656 / 1784): diagnostics build only
-template <int VAR>
-__global__ __launch_bounds__(256, 1) void ransac_solve_kernel(BatchDev b, RunParams rp, int respect_mode)
-{
-    const int pair = blockIdx.y, tid = threadIdx.x;
-    const int M = b.M[pair];
-    if (M < 8)
-        return;
-    if (respect_mode && b.mode[pair] != 0)
-        return;   // this pair's hypotheses are pre-screened (ransac_prescreen_kernel)
-    solve_record<VAR>(b, rp, pair, M, blockIdx.x * blockDim.x + tid);   // any block size that divides 256 (the launch picks it)
-}
-
-#endif  // MVS_DEBUG_HOOKS
 
 // The pairs the probe left in mode 0, in pair order: m0list[0] = their number, then the pairs (one workgroup; the pre-screened
 // stage's exact-solve launch walks this list instead of sending a workgroup per (pair, 64 hypotheses) that leaves at once --
@@ -716,362 +702,6 @@ __global__ __launch_bounds__(256, 1) void ransac_solve_list_kernel(BatchDev b, R
 constexpr int kCntSlots = 4;   // hypotheses a wavefront of the point-per-lane counting kernels carries at a time
 typedef __attribute__((address_space(4))) double CDouble;
 
-#ifdef MVS_DEBUG_HOOKS   // experiment ladder: hypothesis-per-lane scoring of stored records, A / V wavefront pairs, round 2's pruned
-// counting without per-hypothesis thresholds -- diagnostics build only (tools/ab_ransac.py)
-constexpr int kScoreChunk = 1024;   // points staged per pass: 32 KB of LDS -> 4 workgroups per CU
-__global__ __launch_bounds__(256) void ransac_score_kernel(BatchDev b, RunParams rp)
-{
-    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
-    const int M = b.M[pair];
-    WgBest *out = b.wgbest + (size_t)pair * b.max_groups + g;
-    if (M < 8) {  // estimator-RANSAC.cpp:25-29
-        if (tid == 0) {
-            out->count = -1;
-            out->hyp = 0xffffffffu;
-            out->residual = 0.0;
-        }
-        return;
-    }
-    const int H = rp.num_hypotheses;
-    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
-    const bool live = h < (uint32_t)H;
-    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const double *Fi = b.hyp_F + ((size_t)pair * Hp + h) * kHypRec;
-    double F[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-        F[k] = Fi[k];
-    const bool ok = b.hyp_okf[(size_t)pair * Hp + h] != 0;
-    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
-    __shared__ __attribute__((aligned(16))) double s_pts[kScoreChunk * 4];
-    const double thr = pair_max_error_sq(b, rp, pair);
-    int cnt = 0;
-    double res = 0.0;
-    for (int c0 = 0; c0 < M; c0 += kScoreChunk) {
-        const int n = min(kScoreChunk, M - c0);
-        __syncthreads();
-        const double2 *src = reinterpret_cast<const double2 *>(P + (size_t)c0 * 4);
-        double2 *dst = reinterpret_cast<double2 *>(s_pts);
-        for (int i = tid; i < 2 * n; i += kHypPerBlock)
-            dst[i] = src[i];
-        __syncthreads();
-        const double4 *L4 = reinterpret_cast<const double4 *>(s_pts);
-#pragma unroll 8
-        for (int i = 0; i < n; ++i) {   // same order and the same operations as the fused kernel: same bits
-            const double4 p = L4[i];
-            const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
-            const bool in = r < thr;
-            cnt += in ? 1 : 0;
-            res += in ? r : 0.0;   // NaN-safe (a NaN residual is no inlier and adds nothing, as in the reference)
-        }
-    }
-    if (!ok || !live) {
-        cnt = -1;
-        res = 0.0;
-    }
-    if (b.hyp_count && live) {
-        b.hyp_count[(size_t)pair * H + h] = cnt;
-        b.hyp_residual[(size_t)pair * H + h] = res;
-    }
-    // workgroup arg-best
-    Cand me{cnt, h, res};
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        Cand other;
-        other.cnt = __shfl_xor(me.cnt, o);
-        other.hyp = __shfl_xor(me.hyp, o);
-        other.res = __shfl_xor(me.res, o);
-        if (cand_better(other, me))
-            me = other;
-    }
-    __shared__ Cand s_c[4];
-    __shared__ uint32_t s_win;
-    if ((tid & 63) == 0)
-        s_c[tid >> 6] = me;
-    __syncthreads();
-    if (tid == 0) {
-        Cand best = s_c[0];
-#pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2)
-            if (cand_better(s_c[w2], best))
-                best = s_c[w2];
-        s_win = best.hyp;
-        out->count = best.cnt;
-        out->hyp = best.hyp;
-        out->residual = best.res;
-    }
-    __syncthreads();
-    if (h == s_win) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            out->F[k] = F[k];
-    }
-}
-
-// ---- A / V wavefront pairs (device_math.hpp: jacobi_A_wave / jacobi_V_wave) --------------------------------------------
-// grid (G, P) as ransac_solve_kernel, but 512 threads: wavefronts 0..3 solve the 256 hypotheses of the group (A role),
-// wavefronts 4..7 carry V^T of the same lanes (V role).  Wavefront w and w + 4 share a SIMD (wavefronts of a workgroup
-// are dealt round-robin to the four SIMDs), each needs <= 256 registers, so the SIMD holds two waves instead of one and
-// nothing lives in AGPRs.  Same F bits as ransac_solve_kernel (the rotations are the same operations in the same
-// order); a violated fast-math guard or a lost partner falls back to the single-wave solve of that wavefront.
-template <int VAR>
-__global__ __launch_bounds__(512, 1) void ransac_solve_av_kernel(BatchDev b, RunParams rp)
-{
-    __shared__ AvChannel s_ch[4];
-    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
-    const int M = b.M[pair];
-    if (M < 8)
-        return;
-    const int wave = tid >> 6, lane = tid & 63, role = wave >> 2, pidx = wave & 3;
-    if (tid < 4) {
-        AvChannel &c = s_ch[tid];
-#pragma unroll
-        for (int k = 0; k < kAvRing; ++k)
-            c.seq[k] = 0u;
-        c.cons = 0u;
-        c.abort = 0u;
-        c.fin_a = 0u;
-        c.fin_v = 0u;
-    }
-    __syncthreads();
-    AvChannel &ch = s_ch[pidx];
-    if (role == 1) {
-        jacobi_V_wave(ch, lane);
-        return;
-    }
-    const int H = rp.num_hypotheses;
-    const int ta = pidx * 64 + lane;
-    const uint32_t h = (uint32_t)g * kHypPerBlock + ta;
-    const uint32_t hh = h < (uint32_t)H ? h : (uint32_t)(H - 1);
-    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
-    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
-    double F[9];
-    bool bad = false, ok, alive;
-    {
-        int idx[8];
-        sample8(seed, hh, M, rp.sampler, idx);
-        double x1[8], y1[8], x2[8], y2[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double4 p = *reinterpret_cast<const double4 *>(P + (size_t)idx[k] * 4);
-            x1[k] = p.x; y1[k] = p.y; x2[k] = p.z; y2[k] = p.w;
-        }
-        EightNorm nm;
-        double f[9];
-        {
-            double At[9][9], W[9];
-            ok = eight_point_front(x1, y1, x2, y2, At, nm);
-            alive = jacobi_A_wave(At, W, ch, lane, bad);
-            int tag[9];
-            sort_tags_desc<9>(W, tag);
-            ch.tag8[lane] = tag[8];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0)
-            av_store(&ch.fin_a, 1u);
-        alive = alive && av_wait_ge(ch, &ch.fin_v, 1u);
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            f[k] = ch.f[k][lane];
-        bool bad3 = false;
-        eight_point_back<0>(f, nm, F, bad3);
-    }
-    if (__builtin_expect(__any(bad) || !alive, 0)) {
-        // a fast-math guard was violated (never for Hartley-normalised samples) or the partner was lost: this wavefront
-        // recomputes its 64 hypotheses alone with the compiler's fully scaled sqrt / div (spills to scratch: cold)
-        unsigned rot = 0, pairs = 0;
-        bool bad2 = false;
-        ok = solve_hypothesis<16>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad2);
-    }
-    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    double *Fo = b.hyp_F + ((size_t)pair * Hp + h) * kHypRec;
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-        Fo[k] = F[k];
-    Fo[9] = pair_max_error_sq(b, rp, pair);
-    b.hyp_okf[(size_t)pair * Hp + h] = ok ? kPsExact : kPsInvalid;
-    if (g == 0 && tid == 0)
-        b.bound[pair] = 0;
-}
-
-// ---- pruned scoring: ransac_count_kernel + ransac_select_kernel ------------------------------------------------------
-// The reference keeps the hypothesis with the most inliers, ties by the smaller residual sum, then by the smaller index
-// (estimator-RANSAC.cpp:76-84).  A hypothesis whose count can no longer reach a count that SOME hypothesis of the pair
-// has already achieved in full cannot be that winner, whatever its residual: it is dropped the moment
-//     count so far + points not yet visited  <  bound          (strict: ties stay in)
-// and the result is the same hypothesis, bit for bit, as scoring everything.  On the bench workload 97 % of the
-// hypotheses are contaminated and die after ~1/3 of the points.
-//
-// Mapping (the opposite of the solve): LANES ARE POINTS.  A wavefront takes four hypotheses at a time; their F are
-// wave-uniform (scalar loads of the 72-byte records the solve wrote, SGPR operands of v_fma_f64), each lane reads one
-// point of the current 64-point block from LDS and evaluates it for the hypotheses still alive, v_cmp writes the
-// inlier mask straight to an SGPR pair and s_bcnt1 counts it: 9 VALU instructions per 64 evaluations (the
-// hypothesis-per-lane scoring loop needs 15), no cross-lane traffic, and the exit test is scalar code.  Four
-// hypotheses in flight amortise the LDS read and keep the SALU / branch latency of the exit tests off the critical
-// path (the first attempt in round 1 had one hypothesis in flight and was latency-bound).
-// The bound is per pair: LDS copy per workgroup + one word in global memory (atomicMax, refreshed once per group
-// with the load issued a group ahead).  Which hypotheses get dropped depends on timing; the winner does not.
-// Residual sums are not accumulated here: ransac_select_kernel computes them, in the reference's index order, for the
-// hypotheses that tie at the final maximum only.
-
-__device__ __forceinline__ int count_block(const double (&F)[9], const double4 &p, double thr)
-{
-    const double r = epipolar_residual(F, p.x, p.y, p.z, p.w);
-    return __popcll(__ballot(r < thr));   // NaN (padding lanes, degenerate F) compares false
-}
-
-// PPL = points per lane and block (1: 64-point blocks, 2: 128-point blocks).  With two points per lane the scalar work per
-// (hypothesis, block) -- count add, exit test, slot skip: the scalar unit is shared by the four SIMDs and was ~70 % busy
-// with 8 scalar instructions per 9 vector ones -- is amortised over 18 vector instructions; a dying hypothesis is noticed
-// up to 64 points later.
-template <int CNT_THREADS, int PPL, bool STATS = false>
-__global__ __launch_bounds__(CNT_THREADS) void ransac_count_kernel(BatchDev b, RunParams rp, int wg_per_pair)
-{
-    // two planes of double2, [nblk * 64] each: (x1, y1) and (x2, y2), NaN padded.  A lane reads one element of each with
-    // ds_read_b128 at a 16-byte lane stride = 1 KB contiguous per wavefront: conflict-free (the AoS form, 32-byte
-    // stride, spent as many cycles in bank conflicts as the kernel was busy: profiles/r02_pmc_summary.json history)
-    extern __shared__ __attribute__((aligned(16))) double s_cpts[];
-    __shared__ int s_bound;
-    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int M = min(b.M[pair], b.max_kp);
-    if (M < 8)
-        return;
-    const int H = rp.num_hypotheses;
-    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    constexpr int BW = 64 * PPL;                  // points per block
-    const int nblk = (M + BW - 1) / BW;
-    double2 *s_p1 = reinterpret_cast<double2 *>(s_cpts);
-    double2 *s_p2 = s_p1 + nblk * BW;
-    {
-        const double4 *src = reinterpret_cast<const double4 *>(b.pts + (size_t)pair * b.max_kp * 4);
-        const double qnan = __builtin_nan("");
-        for (int i = tid; i < nblk * BW; i += CNT_THREADS) {
-            const double4 p = i < M ? src[i] : make_double4(qnan, qnan, qnan, qnan);
-            s_p1[i] = make_double2(p.x, p.y);
-            s_p2[i] = make_double2(p.z, p.w);
-        }
-    }
-    int *gbound = b.bound + pair;
-    if (tid == 0)
-        s_bound = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const double thr = pair_max_error_sq(b, rp, pair);
-    const double *Fp = b.hyp_F + (size_t)pair * Hp * kHypRec;
-    const uint32_t *okp = reinterpret_cast<const uint32_t *>(b.hyp_okf + (size_t)pair * Hp);
-    int32_t *cntp = b.hyp_cnt + (size_t)pair * Hp;
-    const double2 *L1 = s_p1 + lane, *L2 = s_p2 + lane;
-    const int n_groups = (H + kCntSlots - 1) / kCntSlots;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_waves = wg_per_pair * (CNT_THREADS / 64);
-    int B = 0;
-    unsigned long long visits = 0;   // STATS: (hypothesis, block) evaluations this wavefront executed
-    for (int g = blockIdx.x * (CNT_THREADS / 64) + wave; g < n_groups; g += n_waves) {
-        const int h0 = g * kCntSlots;
-        // the pair's bound as other workgroups see it: load now, use after this group
-        const int gb = __hip_atomic_load(gbound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        B = __builtin_amdgcn_readfirstlane(max(B, *(volatile int *)&s_bound));
-        // constant address space: wave-uniform scalar loads (s_load_dwordx16 through the scalar cache) instead of 18
-        // same-address vector loads per group, which kept the texture-address unit busier than the VALU.  The records
-        // were written by the solve launch; nothing writes them while this kernel runs.
-        double F0[9], F1[9], F2[9], F3[9];
-        const CDouble *f = (const CDouble *)(uintptr_t)(Fp + (size_t)h0 * kHypRec);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            F0[k] = f[k];
-            F1[k] = f[kHypRec + k];
-            F2[k] = f[2 * kHypRec + k];
-            F3[k] = f[3 * kHypRec + k];
-        }
-        // a v_fma_f64 takes one SGPR operand: keep the addend of the inner FMA (F[6..8]) in VGPRs for the whole group,
-        // otherwise it is copied there again for every block
-#pragma unroll
-        for (int k = 6; k < 9; ++k) {
-            asm volatile("" : "+v"(F0[k]));
-            asm volatile("" : "+v"(F1[k]));
-            asm volatile("" : "+v"(F2[k]));
-            asm volatile("" : "+v"(F3[k]));
-        }
-        const uint32_t ok4 = __builtin_amdgcn_readfirstlane(okp[g]);
-        unsigned alive = 0;
-#pragma unroll
-        for (int k = 0; k < kCntSlots; ++k)
-            alive |= (((ok4 >> (8 * k)) & 0xffu) != 0 && h0 + k < H) ? (1u << k) : 0u;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        // two register sets for the block's points, used alternately: the next block's points are requested before this
-        // block's arithmetic (the uniform branches keep the compiler from hoisting the loads) and the LDS round trip hides
-        // under the four slots; with one set plus a "next" set the loop carried eight v_mov_b64 per block, a fifth of
-        // its vector instructions once two of the four slots have died
-        double2 pa0[PPL], pb0[PPL], pa1[PPL], pb1[PPL];
-        auto load = [&](double2 (&pa)[PPL], double2 (&pb)[PPL], int blk) {
-            const int nb = min(blk, nblk - 1) * BW;
-#pragma unroll
-            for (int u = 0; u < PPL; ++u) {
-                pa[u] = L1[nb + u * 64];
-                pb[u] = L2[nb + u * 64];
-            }
-        };
-        auto process = [&](const double2 (&pa)[PPL], const double2 (&pb)[PPL], int blk) {
-            double4 p[PPL];
-#pragma unroll
-            for (int u = 0; u < PPL; ++u)
-                p[u] = make_double4(pa[u].x, pa[u].y, pb[u].x, pb[u].y);
-            const int need = B - max(M - (blk + 1) * BW, 0);   // a slot whose count stays below this cannot reach B
-            if (STATS)
-                visits += (unsigned)__builtin_popcount(alive);
-            if (alive & 1u) {
-#pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c0 += count_block(F0, p[u], thr);
-                if (c0 < need) alive &= ~1u;
-            }
-            if (alive & 2u) {
-#pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c1 += count_block(F1, p[u], thr);
-                if (c1 < need) alive &= ~2u;
-            }
-            if (alive & 4u) {
-#pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c2 += count_block(F2, p[u], thr);
-                if (c2 < need) alive &= ~4u;
-            }
-            if (alive & 8u) {
-#pragma unroll
-                for (int u = 0; u < PPL; ++u)
-                    c3 += count_block(F3, p[u], thr);
-                if (c3 < need) alive &= ~8u;
-            }
-        };
-        load(pa0, pb0, 0);
-        for (int blk = 0; blk < nblk && alive; blk += 2) {
-            load(pa1, pb1, blk + 1);
-            process(pa0, pb0, blk);
-            if (!(blk + 1 < nblk && alive))
-                break;
-            load(pa0, pb0, blk + 2);
-            process(pa1, pb1, blk + 1);
-        }
-        // a slot that is still alive has seen every point: its count is final
-        const int v0 = (alive & 1u) ? c0 : -1, v1 = (alive & 2u) ? c1 : -1;
-        const int v2 = (alive & 4u) ? c2 : -1, v3 = (alive & 8u) ? c3 : -1;
-        if (lane < kCntSlots)
-            cntp[h0 + lane] = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
-        const int cm = __builtin_amdgcn_readfirstlane(max(max(v0, v1), max(v2, v3)));
-        if (cm > B) {
-            B = cm;
-            if (lane == 0) {
-                atomicMax(&s_bound, cm);
-                __hip_atomic_fetch_max(gbound, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        B = max(B, __builtin_amdgcn_readfirstlane(gb));
-    }
-    if (STATS && lane == 0 && b.stats)
-        atomicAdd(&b.stats[2], visits * (unsigned long long)BW);   // executed (hypothesis, point) evaluations incl. padding
-}
-
-#endif  // MVS_DEBUG_HOOKS
 
 // ---- sound pre-screen of the hypotheses (prescreen.hpp) -------------------------------------------------
 // pair_prepare   grid P          bounding box of the pair's matches; probe of the first 64 hypotheses: a pair is pre-screened
@@ -1765,7 +1395,6 @@ constexpr int kFinishThreads = 256;  // finish: 4 wavefronts x 64 list entries
 constexpr int kDenseChunk = 768;     // points staged per pass (multiple of 32): 48 KB of split monomials
 constexpr int kDenseBatches = 4;     // batches of kDenseThreads hypotheses a workgroup takes over the points it has staged
 constexpr int kDenseChunkD = 672;    // points the DENSE phase stages per pass: 42 KB + 8 x 4 KB of windows + the list = 79.9 KB
-constexpr int kDensePipe = 0;        // 0: load -> MFMA -> count per tile; 2: three-stage software pipeline (measured slower)
 constexpr int kDenseWin = 256;       // uint4 words of a wavefront's LDS window: 64 records x 48 B in, 64 operands x 64 B out
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -1925,7 +1554,7 @@ __device__ __forceinline__ uint32_t dense_collect(const v16f &acc)
     return c;
 }
 
-template <bool STATS, int THREADS, int BATCHES, int PIPE, int CHUNK = kDenseChunkD>
+template <bool STATS, int THREADS, int BATCHES, int CHUNK = kDenseChunkD>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void ransac_count_mfma_kernel(BatchDev b, RunParams rp, int margin)
 {
     // LDS: the split monomials of a chunk of points as MFMA operands, [tile of 32 points][j][lane half][point] x 16 bytes:
@@ -2048,84 +1677,24 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4)))
             if (hw >= H)
                 continue;
             uint32_t nn[2] = {0u, 0u};   // accumulators NOT below the threshold
-            // Software pipeline over the point tiles, two accumulator sets: the four MFMAs of tile t + 1 are issued BEFORE the
-            // 36 vector instructions that count tile t, one MFMA per nine of them (sched_group_barrier), so that one wavefront
-            // keeps the matrix pipe and the vector pipe busy at the same time (without it a wavefront waited for its LDS reads,
-            // then for its MFMAs, then counted: 425 clocks per tile pair and SIMD against 192 of issue)
+            // One tile at a time: two LDS reads, four MFMAs, the count (18 plain vector instructions per accumulator set).  A
+            // three-stage software pipeline with two accumulator sets and sched_group_barrier was measured in round 4 and was
+            // SLOWER (1.31 / 1.83 / 1.47 ms for 256 x 8 / 384 x 6 / 512 x 4 against 1.11: its 136-149 registers cost a wavefront
+            // per SIMD, and the hardware already overlaps the pipes across wavefronts); the code is gone.
             const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const uint4 *qt = s_op + half * 32 + col;
             const int nt = nc >> 5;
-            if (PIPE == 0) {
-                for (int t = 0; t < nt; ++t) {
-                    const uint4 *q = qt + (size_t)t * 128;
-                    const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
-                    v16f a0, a1;
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], zero, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], zero, 0, 0, 0);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
-                    nn[0] += (uint32_t)__builtin_popcount(dense_collect(a0) & 0x55555555u);
-                    nn[1] += (uint32_t)__builtin_popcount(dense_collect(a1) & 0x55555555u);
-                }
-            } else {
-                // three stages: the A operands of tile t + 2 are requested from LDS, the MFMAs of tile t + 1 issue on operands that
-                // arrived a stage ago, the accumulators of tile t are counted
-                auto load_a = [&](int t, v8bf &A0, v8bf &A1) __attribute__((always_inline)) {
-                    const uint4 *q = qt + (size_t)t * 128;
-                    A0 = __builtin_bit_cast(v8bf, q[0]);
-                    A1 = __builtin_bit_cast(v8bf, q[64]);
-                };
-                auto issue = [&](const v8bf &A0, const v8bf &A1, v16f &a0, v16f &a1) __attribute__((always_inline)) {
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], zero, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], zero, 0, 0, 0);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
-                };
-                auto count = [&](const v16f &a0, const v16f &a1) __attribute__((always_inline)) {
-                    // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
-                    nn[0] += (uint32_t)__builtin_popcount(dense_collect(a0) & 0x55555555u);
-                    nn[1] += (uint32_t)__builtin_popcount(dense_collect(a1) & 0x55555555u);
-                };
-                auto interleave = [&]() __attribute__((always_inline)) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the two LDS reads of the tile after next
-    #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // nine vector instructions
-                    }
-                };
-                v16f x0, x1, y0, y1;
-                v8bf Ae0, Ae1, Ao0, Ao1;
-                if (nt > 0)
-                    load_a(0, Ae0, Ae1);
-                if (nt > 1)
-                    load_a(1, Ao0, Ao1);
-                if (nt > 0)
-                    issue(Ae0, Ae1, x0, x1);
-                int t = 0;
-                while (t < nt) {
-                    if (t + 2 < nt)
-                        load_a(t + 2, Ae0, Ae1);
-                    if (t + 1 < nt) {
-                        issue(Ao0, Ao1, y0, y1);
-                        count(x0, x1);
-                        interleave();
-                    } else {
-                        count(x0, x1);
-                    }
-                    if (++t >= nt)
-                        break;
-                    if (t + 2 < nt)
-                        load_a(t + 2, Ao0, Ao1);
-                    if (t + 1 < nt) {
-                        issue(Ae0, Ae1, x0, x1);
-                        count(y0, y1);
-                        interleave();
-                    } else {
-                        count(y0, y1);
-                    }
-                    ++t;
-                }
+            for (int t = 0; t < nt; ++t) {
+                const uint4 *q = qt + (size_t)t * 128;
+                const v8bf A0 = __builtin_bit_cast(v8bf, q[0]), A1 = __builtin_bit_cast(v8bf, q[64]);
+                v16f a0, a1;
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[0][0], zero, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bop[1][0], zero, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[0][1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bop[1][1], a1, 0, 0, 0);
+                // accumulator: column = lane & 31 (the hypothesis), 16 points in the registers
+                nn[0] += (uint32_t)__builtin_popcount(dense_collect(a0) & 0x55555555u);
+                nn[1] += (uint32_t)__builtin_popcount(dense_collect(a1) & 0x55555555u);
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -2171,41 +1740,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 4)))
     }
 }
 
-#ifdef MVS_DEBUG_HOOKS   // diagnostics build only
-// diagnostics: one 32 x 32 x 32 tile through the two MFMAs exactly as the counting kernels issue them.  A, B: [32][32] bf16
-// bit patterns (row = point / hypothesis, column = K slot); out[point][hypothesis] (binary32).  Pins the K slot mapping, the
-// accumulator layout and the accumulation error the bound assumes (tests/test_prescreen.py).
-__global__ __launch_bounds__(64) void mfma_probe_kernel(const uint16_t *A, const uint16_t *B, float *out)
-{
-    const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
-    v8bf a[2], bb[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        uint32_t wa[4], wb[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int s0 = j * 16 + half * 8 + 2 * e;
-            wa[e] = (uint32_t)A[col * 32 + s0] | ((uint32_t)A[col * 32 + s0 + 1] << 16);
-            wb[e] = (uint32_t)B[col * 32 + s0] | ((uint32_t)B[col * 32 + s0 + 1] << 16);
-        }
-        a[j] = __builtin_bit_cast(v8bf, make_uint4(wa[0], wa[1], wa[2], wa[3]));
-        bb[j] = __builtin_bit_cast(v8bf, make_uint4(wb[0], wb[1], wb[2], wb[3]));
-    }
-    v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // the point
-        out[row * 32 + col] = acc[r];
-    }
-}
-void launch_mfma_probe(const uint16_t *A, const uint16_t *B, float *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, stream, A, B, out);
-}
-
-#endif  // MVS_DEBUG_HOOKS
 
 // The pair's list in the order of the dense phase's counts, largest first (counting sort on the count, one workgroup per
 // pair; the sorted list is the second half of clist).  The finish then meets the likely winners in its first batches.
@@ -3115,32 +2649,6 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_kernel(BatchDev b, 
     }
 }
 
-#ifdef MVS_DEBUG_HOOKS   // diagnostics build only
-// diagnostics: compare the unscaled sqrt / div sequences with the compiler's IEEE ones on caller-supplied operands.
-// out[0] = sqrt mismatches among operands that pass sqrt_fast_ok, out[1] = div mismatches among operand pairs
-// inside the guarded range, out[2] / out[3] = number of operands / pairs that were inside the guards.
-__global__ __launch_bounds__(256) void fastmath_check_kernel(const double *x, const double *y, int n, unsigned long long *out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    const double a = x[i], b = y[i];
-    if (sqrt_fast_ok(a)) {
-        const double f = sqrt_fast(a), g = dsqrt(a);
-        atomicAdd(&out[2], 1ull);
-        if (__double_as_longlong(f) != __double_as_longlong(g) && !(f != f && g != g))
-            atomicAdd(&out[0], 1ull);
-    }
-    const double aa = dabs(a), ab = dabs(b);
-    if (ab >= 0x1p-200 && ab <= 0x1p200 && ((aa >= 0x1p-200 && aa <= 0x1p200) || a == 0.0)) {
-        const double f = div_fast(a, b), g = a / b;
-        atomicAdd(&out[3], 1ull);
-        if (__double_as_longlong(f) != __double_as_longlong(g))
-            atomicAdd(&out[1], 1ull);
-    }
-}
-
-#endif  // MVS_DEBUG_HOOKS
 
 // find_fundamental_matrix on one explicit sample (single lane); diagnostics / API parity only.
 __global__ __launch_bounds__(64, 1) void fundamental_kernel(const double *p1, const double *p2, double *Fout, int *okout)
@@ -3642,6 +3150,13 @@ __global__ __launch_bounds__(kFinThreads) void finalize_select_kernel(BatchDev b
     }
 }
 
+// The retired kernels of the experiment ladder (rounds 1-3: ransac_solve / ransac_score / ransac_solve_av / ransac_count and the
+// device-side probes of the matrix-core tile and of the unscaled sequences) live in their own file, which ONLY the diagnostics
+// build compiles: libmvslam_hip.so contains none of it (tests/test_abi.py reads its symbol table).
+#ifdef MVS_DEBUG_HOOKS
+#include "kernels_experiments.hip"
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
@@ -3658,9 +3173,11 @@ constexpr int kSplitMinPairs = 3;  // one or two pairs stay on the fused kernel 
 // Which launches take the pre-screened stage: three or more pairs; two pairs when their hypotheses fill the chip more than once
 // on the fused kernel (2 x 50 000: 0.35 ms against 0.40, profiles/r04_single_pair_paths.json); one pair never (0.32 against 0.25:
 // the stage is a chain of latencies there).  (Diagnostics: a split minimum other than 3 is taken literally.)
-static bool prescreened_launch(int n_active, int H)
+// ("the chip": one fused workgroup per compute unit at one wavefront per SIMD -- the device's own count, BatchDev::cu_count.)
+static bool prescreened_launch(const BatchDev &b, int n_active, int H)
 {
-    return n_active >= kSplitMinPairs || (kSplitMinPairs == 3 && n_active == 2 && 2 * ((H + kHypPerBlock - 1) / kHypPerBlock) > 256);
+    const int cus = b.cu_count > 0 ? b.cu_count : 256;
+    return n_active >= kSplitMinPairs || (kSplitMinPairs == 3 && n_active == 2 && 2 * ((H + kHypPerBlock - 1) / kHypPerBlock) > cus);
 }
 
 
@@ -3751,8 +3268,8 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
         d.dynamic_lds = (size_t)kFinUpperChunk * 64 + (size_t)(kFinUpperThreads / 64) * kDenseWin * 16;
         break;
     case kKRansacCountMfma:
-        d.name = "ransac_count_mfma_kernel<false, 512, 4, 0, 672>";
-        d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>);
+        d.name = "ransac_count_mfma_kernel<false, 512, 4, 672>";
+        d.fn = reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches>);
         d.threads = kDenseThreads;
         d.dynamic_lds = (size_t)kDenseChunkD * 64 + (size_t)(kDenseThreads / 64) * kDenseWin * 16;
         break;
@@ -3819,18 +3336,15 @@ hipError_t prepare_kernels()
                          reinterpret_cast<const void *>(ransac_count2_kernel<kCntThreads, kCntPpl, true>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0>),
                          reinterpret_cast<const void *>(ransac_count32_kernel<kCnt32Threads, kCnt32Ppl, kCnt32Slots, 0, true>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches, kDensePipe>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches>),
 #ifdef MVS_DEBUG_HOOKS
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 0, 768>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 0, 768>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 2, 768>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 2, 768>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 2, 768>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0, 768>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0, 640>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 0, 672>),
-                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 2, 0, 672>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 256, 8, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 384, 6, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 768>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 640>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 4, 672>),
+                         reinterpret_cast<const void *>(ransac_count_mfma_kernel<false, 512, 2, 672>),
 #endif
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<false>),
                          reinterpret_cast<const void *>(ransac_finish_mfma_kernel<true>),
@@ -4042,21 +3556,18 @@ static void launch_counting(const BatchDev &b, const RunParams &rp, int n_active
         };
 #ifdef MVS_DEBUG_HOOKS
         // A/B of the dense phase's shape: mvs_debug_set_count_dense(10 + k)
-        if (g_count_dense == 10) dense(ransac_count_mfma_kernel<false, 256, 8, 0, 768>, 256, 8, 768);
-        else if (g_count_dense == 11) dense(ransac_count_mfma_kernel<false, 384, 6, 0, 768>, 384, 6, 768);
-        else if (g_count_dense == 12) dense(ransac_count_mfma_kernel<false, 256, 8, 2, 768>, 256, 8, 768);
-        else if (g_count_dense == 13) dense(ransac_count_mfma_kernel<false, 384, 6, 2, 768>, 384, 6, 768);
-        else if (g_count_dense == 14) dense(ransac_count_mfma_kernel<false, 512, 4, 2, 768>, 512, 4, 768);
-        else if (g_count_dense == 15) dense(ransac_count_mfma_kernel<false, 512, 4, 0, 768>, 512, 4, 768);
-        else if (g_count_dense == 16) dense(ransac_count_mfma_kernel<false, 512, 4, 0, 640>, 512, 4, 640);
-        else if (g_count_dense == 17) dense(ransac_count_mfma_kernel<false, 512, 4, 0, 672>, 512, 4, 672);
-        else if (g_count_dense == 18) dense(ransac_count_mfma_kernel<false, 512, 2, 0, 672>, 512, 2, 672);
+        if (g_count_dense == 10) dense(ransac_count_mfma_kernel<false, 256, 8, 768>, 256, 8, 768);
+        else if (g_count_dense == 11) dense(ransac_count_mfma_kernel<false, 384, 6, 768>, 384, 6, 768);
+        else if (g_count_dense == 15) dense(ransac_count_mfma_kernel<false, 512, 4, 768>, 512, 4, 768);
+        else if (g_count_dense == 16) dense(ransac_count_mfma_kernel<false, 512, 4, 640>, 512, 4, 640);
+        else if (g_count_dense == 17) dense(ransac_count_mfma_kernel<false, 512, 4, 672>, 512, 4, 672);
+        else if (g_count_dense == 18) dense(ransac_count_mfma_kernel<false, 512, 2, 672>, 512, 2, 672);
         else
 #endif
         if (stats)
-            dense(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches, kDensePipe>, kDenseThreads, kDenseBatches);
+            dense(ransac_count_mfma_kernel<true, kDenseThreads, kDenseBatches>, kDenseThreads, kDenseBatches);
         else
-            dense(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches, kDensePipe>, kDenseThreads, kDenseBatches);
+            dense(ransac_count_mfma_kernel<false, kDenseThreads, kDenseBatches>, kDenseThreads, kDenseBatches);
         if (lt) lt->mark(kKRansacCountFinish);
         const dim3 fin_grid(n_active, (H + kFinishThreads - 1) / kFinishThreads);   // workgroups past the list's end leave at once
         if (g_count_dense != 2)
@@ -4130,13 +3641,13 @@ static void launch_prescreened(const BatchDev &b, const RunParams &rp, int n_act
 static void launch_ransac_product(const BatchDev &b, const RunParams &rp, int n_active, bool stats, hipStream_t stream,
                                   LaunchTimer *lt, dim3 grid, dim3 block)
 {
-    const bool split_ok = !stats && b.hyp_F && prescreened_launch(n_active, rp.num_hypotheses);
+    const bool split_ok = !stats && b.hyp_F && prescreened_launch(b, n_active, rp.num_hypotheses);
     if (!split_ok || b.hyp_count) {
         if (!stats)
             launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
         else
             launch_ransac_var<120>(b, rp, grid, block, true, stream, lt);
-        if (stats && b.hyp_F && !b.hyp_count && prescreened_launch(n_active, rp.num_hypotheses))
+        if (stats && b.hyp_F && !b.hyp_count && prescreened_launch(b, n_active, rp.num_hypotheses))
             launch_prescreened(b, rp, n_active, stream, nullptr, true);   // + the product path's own counters
     } else {
         launch_prescreened(b, rp, n_active, stream, lt, false);
@@ -4151,7 +3662,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
     launch_ransac_product(b, rp, n_active, stats, stream, lt, grid, block);
 #else
     // diagnostics build: the experiment ladder of rounds 1-2 behind mvs_debug_set_ransac_variant (tools/ab_ransac.py)
-    const bool split_ok = !stats && b.hyp_F && prescreened_launch(n_active, rp.num_hypotheses);
+    const bool split_ok = !stats && b.hyp_F && prescreened_launch(b, n_active, rp.num_hypotheses);
     switch (g_ransac_variant) {
     case 9000: launch_ransac_product(b, rp, n_active, stats, stream, lt, grid, block); break;
     case 0: launch_ransac_var<0>(b, rp, grid, block, stats, stream, lt); break;
@@ -4189,7 +3700,7 @@ void launch_ransac(const BatchDev &b, const RunParams &rp, int n_active, bool st
                 launch_ransac_var<248 + 1024>(b, rp, grid, block, false, stream, lt);
             else
                 launch_ransac_var<120>(b, rp, grid, block, stats, stream, lt);
-            if (stats && b.hyp_F && !b.hyp_count && prescreened_launch(n_active, rp.num_hypotheses) && g_ransac_variant == 1784) {
+            if (stats && b.hyp_F && !b.hyp_count && prescreened_launch(b, n_active, rp.num_hypotheses) && g_ransac_variant == 1784) {
                 // the instrumented replay also runs the product path once with the counting kernel's evaluation counter
                 // (stats[2]): the roofline quotes EXECUTED evaluations for the pruned kernel, not the H x M it avoids
                 hipLaunchKernelGGL((ransac_solve_kernel<240 + 1024>), dim3(G * (kHypPerBlock / kSolveBlock), n_active),
@@ -4226,357 +3737,12 @@ void launch_finalize(const BatchDev &b, const RunParams &rp, int n_active, int m
     hipLaunchKernelGGL(finalize_select_kernel, dim3(n_active), dim3(kFinThreads), 0, stream, b);
 }
 
-#ifdef MVS_DEBUG_HOOKS   // diagnostics build only
-// diagnostics: one Jacobi pair step on two rows of three elements, guarded (unscaled sequences, seeded divisions) against
-// the compiler's IEEE sqrt / division, bit for bit.  rows: n x 6 doubles (row i, row j).  out[0] = steps whose rotated
-// rows or norms differ, out[1] = steps compared (both rotate, guards hold), out[2] = steps where the decision differs
-__global__ __launch_bounds__(256) void pairstep_check_kernel(const double *rows, int n, unsigned long long *out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    double A[2][2][3], V[2][2][3], W[2][2];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            double sd = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                A[v][r][k] = rows[(size_t)i * 6 + r * 3 + k];
-                V[v][r][k] = r == k ? 1.0 : 0.0;
-                sd = dfma(A[v][r][k], A[v][r][k], sd);
-            }
-            W[v][r] = sd;
-        }
-    }
-    {   // accuracy of the reciprocal estimate the divisions start from: max |1 - gamma * 2 h| as double bits in out[3]
-        const double g2 = dfma(W[0][0], W[0][0], W[0][1] * W[0][1]) + 0x1p-300;
-        double h;
-        const double gamma = sqrt_fast_nz_h(g2, h);
-        const double e = dabs(dfma(-gamma, h + h, 1.0));
-        atomicMax(&out[3], (unsigned long long)__double_as_longlong(e));
-    }
-    bool ch0 = false, ch1 = false, bad0 = false, bad1 = false;
-    unsigned r0 = 0, r1 = 0;
-    double q0 = 0x1p1000, q1 = 0x1p1000;
-    jacobi_pair<3, 3, true, true, true, true>(A[0][0], A[0][1], V[0][0], V[0][1], W[0][0], W[0][1], ch0, r0, bad0, q0);
-    jacobi_pair<3, 3, true, false, false, false>(A[1][0], A[1][1], V[1][0], V[1][1], W[1][0], W[1][1], ch1, r1, bad1, q1);
-    if (ch0 != ch1) {
-        atomicAdd(&out[2], 1ull);
-        return;
-    }
-    if (!ch0 || !(q0 >= kGuardQMin) || !(W[1][0] + W[1][1] <= kGuardWSumMax))
-        return;
-    atomicAdd(&out[1], 1ull);
-    bool same = __double_as_longlong(W[0][0]) == __double_as_longlong(W[1][0]) &&
-                __double_as_longlong(W[0][1]) == __double_as_longlong(W[1][1]);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            same = same && __double_as_longlong(A[0][r][k]) == __double_as_longlong(A[1][r][k]) &&
-                   __double_as_longlong(V[0][r][k]) == __double_as_longlong(V[1][r][k]);
-    if (!same)
-        atomicAdd(&out[0], 1ull);
-}
-
-void launch_pairstep_check(const double *rows, int n, unsigned long long *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(pairstep_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rows, n, out);
-}
-
-void launch_fastmath_check(const double *x, const double *y, int n, unsigned long long *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(fastmath_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, out);
-}
-
-#endif  // MVS_DEBUG_HOOKS
-
+// full-population audit, worst-case-construction probes (diagnostics build only: tests/audit_gpu_check.py,
+// tests/constants_gpu_check.py)
 #ifdef MVS_DEBUG_HOOKS
-// ---- full-population audit of the pre-screened stage (diagnostics build; tests/audit_gpu_check.py, VERDICT r3 #1b) -------
-// Every hypothesis of every pair is solved EXACTLY once more (the arithmetic of ransac_exact_list_kernel) and scored exactly
-// on every match (estimator-RANSAC.cpp:100-129), and what the stage decided about it is checked on the device:
-//   PHASE 0  the records are the pre-screen's own (pair_prepare + ransac_prescreen just ran, nothing else): state byte 0 only
-//            if the exact path rejects the sample, no approximate record for a rejected sample; for every certified record
-//            and EVERY match |r_i(F_J) - r~_i| <= the band the record carries (B), with r~ evaluated as the vector counting
-//            kernels do (mode 1: binary32 nested fma on the rounded point; mode 2: the contract's fused form on F~), and
-//            U >= c_J >= L for the counts against the record's own thresholds.
-//   PHASE 1  the batch has just run the whole default stage: a hypothesis the stage DROPPED (record still approximate, or a
-//            mode-0 record whose count was pruned) has an exact count strictly below the pair's final bound (count_viol); a
-//            record marked exact holds F_J bit for bit; a survivor's recorded (matrix-core) upper count is >= its exact
-//            count; no approximate record reaches the bound without having been solved; state 0 <=> the exact path rejects
-//            the sample; maxc[pair] = the largest exact count (the host compares it with the bound and with best_count).
-// out[16]: 0 hypotheses audited, 1 state violations, 2 count_viol, 3 upper-bound violations, 4 lower-bound violations,
-// 5 matches violating (B), 6 bits of the worst |r_J - r~| / band, 7 certified records (phase 0) / survivors (phase 1)
-// checked, 8 largest 9x9 sweep count, 9 exact records that differ from F_J, 10 approximate records at or above the bound,
-// 11 matches with a NaN exact residual (skipped in (B)), 12 mode-0 counts that differ from the exact count, 13 matches
-// checked for (B), 14 rejected samples, 15 sum of the 9x9 sweep counts
-template <int PHASE>
-__global__ __launch_bounds__(256, 1) void audit_kernel(BatchDev b, RunParams rp, unsigned long long *out, int32_t *maxc)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_apts[];
-    const int pair = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int M = min(b.M[pair], b.max_kp);
-    if (M < 8)
-        return;
-    const int H = rp.num_hypotheses;
-    const uint32_t h = (uint32_t)g * kHypPerBlock + tid;
-    const bool live = h < (uint32_t)H;
-    const uint32_t hh = live ? h : (uint32_t)(H - 1);
-    const uint64_t seed = rp.seed + (uint64_t)b.gidx[pair];
-    const double *P = b.pts + (size_t)pair * b.max_kp * 4;
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(P);
-        double2 *dst = reinterpret_cast<double2 *>(s_apts);
-        for (int i = tid; i < 2 * M; i += kHypPerBlock)
-            dst[i] = src[i];
-        __syncthreads();
-    }
-    double F[9];
-    unsigned rot = 0, pairs = 0;
-    bool bad = false;
-    bool ok = solve_hypothesis<240 + 1024>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
-    if (__builtin_expect(__any(bad), 0)) {
-        rot = 0;
-        pairs = 0;
-        ok = solve_hypothesis<(240 + 1024) & ~(32 | 128)>(seed, hh, M, rp.sampler, P, F, rot, pairs, bad);
-    }
-    const unsigned sweeps = pairs / 36u;
-    const double thr = pair_max_error_sq(b, rp, pair);
-    const int mode = b.mode[pair];
-    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const size_t rec = (size_t)pair * Hp + h;
-    const int state = live ? (int)b.hyp_okf[rec] : kPsInvalid;
-    const double4 *L4 = reinterpret_cast<const double4 *>(s_apts);
-    unsigned long long v_state = 0, v_count = 0, v_upper = 0, v_lower = 0, v_band = 0, n_cert = 0, v_F = 0, v_surv = 0, n_nan = 0,
-                       v_m0 = 0, n_match = 0;
-    double worst = 0.0;
-    int cJ = 0;
-    if (PHASE == 0) {
-        if (live && mode != 0) {
-            if (state == kPsInvalid && ok) ++v_state;
-            if (state == kPsApprox && !ok) ++v_state;
-            if (state == kPsApprox) {
-                ++n_cert;
-                const double *Fo = b.hyp_F + rec * kHypRec;
-                int U = 0, L = 0;
-                if (mode == 1) {
-                    const float *fo = b.hyp_r32 + rec * kHypRec32;
-                    float Ft[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k)
-                        Ft[k] = fo[k];
-                    const float tu = fo[9], tl = fo[10];
-                    const double beta = (double)tu - thr;
-                    for (int i = 0; i < M; ++i) {
-                        const double4 p = L4[i];
-                        const double rJ = epipolar_residual(F, p.x, p.y, p.z, p.w);
-                        const float x1 = (float)p.x, y1 = (float)p.y, x2 = (float)p.z, y2 = (float)p.w;
-                        // ransac_count32_kernel's chain (count_pair32)
-                        const float u0 = __builtin_fmaf(x2, Ft[0], __builtin_fmaf(y2, Ft[3], Ft[6]));
-                        const float u1 = __builtin_fmaf(x2, Ft[1], __builtin_fmaf(y2, Ft[4], Ft[7]));
-                        const float u2 = __builtin_fmaf(x2, Ft[2], __builtin_fmaf(y2, Ft[5], Ft[8]));
-                        const float r32 = __builtin_fabsf(__builtin_fmaf(u0, x1, __builtin_fmaf(u1, y1, u2)));
-                        cJ += rJ < thr ? 1 : 0;
-                        U += r32 < tu ? 1 : 0;
-                        L += r32 < tl ? 1 : 0;
-                        if (rJ != rJ) {
-                            ++n_nan;
-                        } else {
-                            const double d = dabs(rJ - (double)r32);
-                            ++n_match;
-                            if (!(d <= beta)) ++v_band;
-                            worst = fmax(worst, d / beta);
-                        }
-                    }
-                } else {
-                    double Ft[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k)
-                        Ft[k] = Fo[k];
-                    const double tu = Fo[9];
-                    const double beta = tu - thr;
-                    const double tl = thr - (tu - thr) * (1.0 + 1e-9) - 1e-15 * thr;   // ransac_count2_kernel's lower threshold
-                    for (int i = 0; i < M; ++i) {
-                        const double4 p = L4[i];
-                        const double rJ = epipolar_residual(F, p.x, p.y, p.z, p.w);
-                        const double rt = epipolar_residual(Ft, p.x, p.y, p.z, p.w);
-                        cJ += rJ < thr ? 1 : 0;
-                        U += rt < tu ? 1 : 0;
-                        L += rt < tl ? 1 : 0;
-                        if (rJ != rJ) {
-                            ++n_nan;
-                        } else {
-                            const double d = dabs(rJ - rt);
-                            ++n_match;
-                            if (!(d <= beta)) ++v_band;
-                            worst = fmax(worst, d / beta);
-                        }
-                    }
-                }
-                if (U < cJ) ++v_upper;
-                if (L > cJ) ++v_lower;
-            }
-        }
-    } else {
-        for (int i = 0; i < M; ++i) {
-            const double4 p = L4[i];
-            const double rJ = epipolar_residual(F, p.x, p.y, p.z, p.w);
-            cJ += rJ < thr ? 1 : 0;
-        }
-        if (live) {
-            const int cnt = b.hyp_cnt[rec];
-            const int bound = b.bound[pair];
-            const double *Fo = b.hyp_F + rec * kHypRec;
-            const bool counted = cnt >= 0 && cnt != 0x7fffffff;
-            if ((state == kPsInvalid) != !ok) ++v_state;
-            if (state == kPsNeedExact) ++v_state;   // nothing may still wait for its exact solve
-            if (state == kPsExact) {
-                bool same = true;
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    same = same && __double_as_longlong(Fo[k]) == __double_as_longlong(F[k]);
-                if (!same) ++v_F;
-            }
-            if (mode == 0) {
-                if (ok && counted && cnt != cJ) ++v_m0;                 // a count that survived the pruning is the exact count
-                if (ok && !counted && !(cJ < bound)) ++v_count;         // pruned: cannot reach the bound
-                if (ok && counted && cnt < bound && !(cJ < bound)) ++v_count;
-            } else {
-                if (state == kPsApprox) {
-                    if (cnt >= bound) ++v_surv;                         // would have had to be solved exactly
-                    if (!(cJ < bound)) ++v_count;                       // DROPPED although its exact count reaches the bound
-                } else if (state == kPsExact && counted) {
-                    ++n_cert;                                           // a survivor of the counting: its recorded upper count
-                    if (cnt < cJ) ++v_upper;
-                }
-            }
-        }
-    }
-    // reductions: wavefront first, one atomic per wavefront and non-zero counter
-    auto wsum = [&](unsigned long long v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            v += __shfl_xor(v, o);
-        return v;
-    };
-    const unsigned long long vals[16] = {live ? 1ull : 0ull, v_state, v_count, v_upper, v_lower, v_band, 0ull, n_cert, 0ull, v_F,
-                                         v_surv, n_nan, v_m0, n_match, (live && !ok) ? 1ull : 0ull, live ? sweeps : 0u};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k == 6 || k == 8)
-            continue;
-        const unsigned long long t = wsum(vals[k]);
-        if (lane == 0 && t)
-            atomicAdd(&out[k], t);
-    }
-    unsigned sw = live ? sweeps : 0u;
-    int mc = (live && ok) ? cJ : -1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        sw = max(sw, (unsigned)__shfl_xor((int)sw, o));
-        mc = max(mc, __shfl_xor(mc, o));
-        worst = fmax(worst, __shfl_xor(worst, o));
-    }
-    if (lane == 0) {
-        atomicMax(&out[8], (unsigned long long)sw);
-        atomicMax(&out[6], (unsigned long long)__double_as_longlong(worst));   // non-negative doubles order like their bits
-        if (PHASE == 1)
-            atomicMax(&maxc[pair], mc);
-    }
-}
+#include "kernels_audit.hip"
+#endif
 
-// ---- worst-case-construction probes (tests/test_constants.py, VERDICT r3 #1c) -------------------------------------------
-// every record of pair p except hypothesis keep[p] becomes a rejected sample (keep[p] < 0: the pair is left alone)
-__global__ __launch_bounds__(256) void keep_only_kernel(BatchDev b, const int32_t *keep)
-{
-    const int pair = blockIdx.y;
-    const size_t Hp = (size_t)b.max_groups * kHypPerBlock;
-    const size_t h = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int k = keep[pair];
-    if (h < Hp && k >= 0 && h != (size_t)k)
-        b.hyp_okf[(size_t)pair * Hp + h] = (uint8_t)kPsInvalid;
-}
-// the counting launches of the stage alone, on the pre-screen's own records (every pair forced into mode `pmode`), with the
-// counting variant `dense` (0: ransac_count32 in one launch, 1: pilot + matrix-core dense phase + matrix-core finish, the
-// product path); afterwards hyp_cnt[keep] = U, bound = the best lower bound
-void launch_count_only(const BatchDev &b, const RunParams &rp, int n_active, int pmode, int dense, const int32_t *keep,
-                       hipStream_t stream)
-{
-    launch_prescreen_only(b, rp, n_active, pmode, stream);
-    if (keep)
-        hipLaunchKernelGGL(keep_only_kernel, dim3(b.max_groups, n_active), dim3(256), 0, stream, b, keep);
-    const int old = g_count_dense;
-    g_count_dense = dense;
-    launch_counting(b, rp, n_active, stream, nullptr, false);
-    g_count_dense = old;
-}
-// the compare-free indicator of the matrix-core counting on caller-supplied accumulator values: ind_u[i] / ind_l[i] = what
-// dense_count adds for accumulator a[i] under a record with thresholds (tu[i], tl[i]) and box term T[i]
-__global__ __launch_bounds__(64) void indicator_probe_kernel(const float *a, const float *tu, const float *tl, const float *T,
-                                                             int n, float *ind_u, float *ind_l, float *scale)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n)
-        return;
-    const f32x2 negH = {-0x1p100f, -0x1p100f};
-    bool lpos;
-    const float t2u = dense_t2_upper(tu[i], T[i], true), t2l = dense_t2_lower(tl[i], T[i], true, lpos);
-    const f32x2 x = {a[i], -a[i]};
-    const f32x2 sq = pk_mul(x, x);
-    const f32x2 u = pk_ind(sq, negH, f32x2{t2u, t2u}), l = pk_ind(sq, negH, f32x2{t2l, t2l});
-    ind_u[i] = u.x == u.y ? u.x : -1.f;
-    ind_l[i] = l.x == l.y ? l.x : -1.f;
-    scale[i] = dense_scale(tu[i], T[i], true);   // the dense phase's B-operand scale: s tu' must stay below 2
-}
-void launch_indicator_probe(const float *a, const float *tu, const float *tl, const float *T, int n, float *ind_u, float *ind_l,
-                            float *scale, hipStream_t stream)
-{
-    hipLaunchKernelGGL(indicator_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, a, tu, tl, T, n, ind_u, ind_l, scale);
-}
-// de-normalisation + fused residual exactly as the two paths run them: in[i] = Fn (9, row-major), s1, s2, m1x, m1y, m2x, m2y,
-// x1, y1, x2, y2; out[i] = {residual under prescreen_denormalise(Fn), residual under denormalise_exact(Fn)}
-__global__ __launch_bounds__(64) void rounding_probe_kernel(const double *in, int n, double *out)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n)
-        return;
-    const double *q = in + (size_t)i * 19;
-    double Fn[9], Fn3[3][3], Fa[9], Fb[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        Fn[k] = q[k];
-        Fn3[k / 3][k % 3] = q[k];
-    }
-    EightNorm nm;
-    nm.s1 = q[9]; nm.s2 = q[10]; nm.m1x = q[11]; nm.m1y = q[12]; nm.m2x = q[13]; nm.m2y = q[14];
-    prescreen_denormalise(Fn, nm, Fa);
-    denormalise_exact(Fn3, nm, Fb);
-    out[2 * i] = epipolar_residual(Fa, q[15], q[16], q[17], q[18]);
-    out[2 * i + 1] = epipolar_residual(Fb, q[15], q[16], q[17], q[18]);
-}
-void launch_rounding_probe(const double *in, int n, double *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(rounding_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, in, n, out);
-}
-
-hipError_t launch_audit(const BatchDev &b, const RunParams &rp, int n_active, int phase, unsigned long long *out, int32_t *maxc,
-                        hipStream_t stream)
-{
-    const int G = (rp.num_hypotheses + kHypPerBlock - 1) / kHypPerBlock;
-    const size_t lds = (size_t)b.max_kp * 4 * sizeof(double);
-    const void *fn = phase == 0 ? reinterpret_cast<const void *>(audit_kernel<0>) : reinterpret_cast<const void *>(audit_kernel<1>);
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKp * 32);
-    if (e != hipSuccess)
-        return e;
-    if (phase == 0)
-        hipLaunchKernelGGL(audit_kernel<0>, dim3(G, n_active), dim3(kHypPerBlock), lds, stream, b, rp, out, maxc);
-    else
-        hipLaunchKernelGGL(audit_kernel<1>, dim3(G, n_active), dim3(kHypPerBlock), lds, stream, b, rp, out, maxc);
-    return hipGetLastError();
-}
-#endif  // MVS_DEBUG_HOOKS
 
 // ---- single-shot glue (the reference's one-pair-at-a-time call pattern: front-end/image-pair.cpp:30-71) ----------------------
 // The per-pair scalars of pair 0 travel as KERNEL ARGUMENTS instead of five small host-to-device copies, and the outputs of

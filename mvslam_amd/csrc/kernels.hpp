@@ -43,6 +43,7 @@ struct BatchDev {
     int max_kp;       // N
     int desc_words;   // descriptor bytes / 4
     int max_groups;   // capacity of wgbest per pair
+    int cu_count;     // compute units of the batch's device (hipDeviceAttributeMultiprocessorCount): launch-shape decisions
 
     // inputs
     const uint32_t *desc1;  // [P][N][desc_words]   base / train (vf1)

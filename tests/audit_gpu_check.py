@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Full-population device audit of the pre-screened RANSAC stage (VERDICT r3 #1b; run by tests/test_prescreen.py in its own
-process with MVS_USE_DEBUG_LIB=1: the audit kernel exists in the diagnostics library only -- same kernels.hip, same
-launch path as the product library, plus the hooks).
+"""Full-population device audit of the pre-screened RANSAC stage (VERDICT r3 #1b), since round 5 of the PRODUCT BINARY
+(VERDICT r4 #6): libmvslam_hip.so runs the stage; its device-resident state (mvs_batch_device_state: a read-only view) is
+handed, in the same process, to the audit kernel of libmvslam_hip_dbg.so, which only replays every hypothesis exactly and
+compares -- every byte the checks read was written by the product library's kernels.  Run by tests/test_prescreen.py in its
+own process.
 
 The reference's rule (estimator-RANSAC.cpp:76-84) decides over ALL hypotheses of a pair; the pre-screen decides which of
 them are ever solved exactly.  Here every hypothesis of BASELINE configs[2] (512 pairs x 50 000 = 25.6 M) and of the first
 128 pairs of configs[4]'s sequence is solved exactly once more ON THE DEVICE and scored exactly on every match, and
-  phase 0 (records as the pre-screen wrote them): state byte 0 only for samples the exact path rejects; for every certified
-          record and every match |r_i(F_J) - r~_i| <= the record's band (B); U >= c_J >= L;
+  phase 2 (records as the product's pre-screen wrote them and the stage left them -- every record still in the approximate
+          state, i.e. all but the few the stage solved exactly afterwards): state byte 0 only for samples the exact path
+          rejects; for every such record and every match |r_i(F_J) - r~_i| <= the record's band (B); U >= c_J >= L;
   phase 1 (after the default stage): no dropped hypothesis has an exact count at or above the pair's bound (count_viol); every
           record marked exact is F_J bit for bit; every survivor's matrix-core upper count >= its exact count; state 0 <=> the
           exact path rejects; the pair's bound <= the largest exact count == the winner's count;
@@ -24,7 +27,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["MVS_USE_DEBUG_LIB"] = "1"
+os.environ.pop("MVS_USE_DEBUG_LIB", None)      # the batch below belongs to the PRODUCT library
 from mvslam_amd import capi, synth  # noqa: E402
 
 NAMES = ["hypotheses", "state_viol", "count_viol", "upper_viol", "lower_viol", "band_viol", "worst_ratio_bits", "checked",
@@ -32,12 +35,16 @@ NAMES = ["hypotheses", "state_viol", "count_viol", "upper_viol", "lower_viol", "
          "rejected_samples", "sum_sweeps9"]
 
 
-def audit(lib, b, prm, P, phase):
+def audit(dbg, b, prm, P, phase):
+    """dbg = (diagnostics library, its own context); b = a batch of the product library, synchronised"""
+    dlib, dctx = dbg
     c = (C.c_ulonglong * 16)()
     maxc, bound, mode = (np.zeros(P, dtype=np.int32) for _ in range(3))
-    st = lib.mvs_debug_audit(b._h, C.byref(prm), C.c_int(P), C.c_int(phase), c, maxc.ctypes.data_as(C.POINTER(C.c_int32)),
-                             bound.ctypes.data_as(C.POINTER(C.c_int32)), mode.ctypes.data_as(C.POINTER(C.c_int32)))
-    assert st == 0, (st, capi.lib().mvs_last_error(b.ctx._h))
+    state = b.device_state()
+    st = dlib.mvs_debug_audit_state(dctx, state, C.c_size_t(len(state)), C.byref(prm), C.c_int(P), C.c_int(phase), c,
+                                    maxc.ctypes.data_as(C.c_void_p), bound.ctypes.data_as(C.c_void_p),
+                                    mode.ctypes.data_as(C.c_void_p))
+    assert st == 0, (st, dlib.mvs_last_error(dctx))
     d = {n: int(c[k]) for k, n in enumerate(NAMES)}
     d["worst_ratio"] = float(np.array([d.pop("worst_ratio_bits")], dtype=np.uint64).view(np.float64)[0])
     return d, maxc, bound, mode
@@ -51,13 +58,13 @@ def run_case(ctx, lib, name, data, P, N, H, thr):
     b.sync()
     res = b.download(matches=False, mask=False, points=False)["results"]
     t0 = time.time()
-    a1, maxc, bound, mode = audit(lib, b, prm, P, 1)          # the stage's decisions (must come first: phase 0 rewrites records)
-    a0, _, _, mode0 = audit(lib, b, prm, P, 0)                # the pre-screen's records
+    a1, maxc, bound, mode = audit(lib, b, prm, P, 1)          # the stage's decisions
+    a0, _, _, mode0 = audit(lib, b, prm, P, 2)                # the product's approximate records, as the stage left them
     dt = time.time() - t0
     b.close()
     live = res["n_matches"] >= 8
     out = dict(case=name, pairs=P, hypotheses=a1["hypotheses"], seconds=round(dt, 2),
-               pairs_mode=[int((mode[live] == m).sum()) for m in (0, 1, 2)], phase0=a0, phase1=a1)
+               pairs_mode=[int((mode[live] == m).sum()) for m in (0, 1, 2)], phase2=a0, phase1=a1)
     # host side of phase 1: the bound never exceeds the largest exact count, which is the winner's count
     out["bound_above_max"] = int((bound[live] > maxc[live]).sum())
     out["best_count_mismatch"] = int((res["best_count"][live] != maxc[live]).sum())
@@ -71,12 +78,61 @@ def run_case(ctx, lib, name, data, P, N, H, thr):
     return out
 
 
+def run_crafted(ctx, lib, path):
+    """The matches tests/constants_gpu_check.py crafted ON the band edges of chosen hypotheses (coordinates half-way between two
+    binary32 numbers; half of them land on the wrong side in plain binary32), through the PRODUCT binary: the point sets go
+    in as a batch of sfm_solve calls (mvs_batch_run_points, K = identity: ideal coordinates pass through bit for bit), the
+    product's stage runs on them, and the audit checks every hypothesis of every pair against what it left behind."""
+    z = np.load(path)
+    P, N, H, thr = int(z["pairs"]), int(z["capacity"]), int(z["hypotheses"]), float(z["thr"])
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=int(z["seed"]), max_error_sq=thr)
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload_intrinsics(0, np.eye(3), z["global_index"], count=P)
+    out = dict(case="crafted band-edge matches through mvs_batch_run_points", trials=int(z["trials"]), pairs=P, viol=0, checked=0,
+               matches_checked=0, hypotheses=0, survivors_checked=0)
+    for t in range(int(z["trials"])):
+        sets = [z["pts_%d_%d" % (t, p)] for p in range(P)]
+        m = np.array([len(q) for q in sets], dtype=np.int32)
+        uv1, uv2 = np.zeros((P, N, 2)), np.zeros((P, N, 2))
+        for p, q in enumerate(sets):
+            uv1[p, :len(q)], uv2[p, :len(q)] = q[:, :2], q[:, 2:]
+        b.run_points(prm, uv1, uv2, m)
+        b.sync()
+        res = b.download(matches=False, mask=False, points=False)["results"]
+        assert (res["n_matches"] == m).all()
+        a1, maxc, bound, mode = audit(lib, b, prm, P, 1)
+        a2, _, _, _ = audit(lib, b, prm, P, 2)
+        out["viol"] += sum(a1[k] for k in ("state_viol", "count_viol", "upper_viol", "exact_F_mismatch", "unsolved_survivors",
+                                            "mode0_count_mismatch")) + \
+            sum(a2[k] for k in ("state_viol", "band_viol", "upper_viol", "lower_viol")) + \
+            int((bound > maxc).sum()) + int((res["best_count"] != maxc).sum())
+        out["checked"] += a2["checked"]
+        out["matches_checked"] += a2["matches_checked"]
+        out["hypotheses"] += a1["hypotheses"]
+        out["survivors_checked"] += a1["checked"]
+        out["pairs_mode"] = [int((mode == k).sum()) for k in (0, 1, 2)]
+    b.close()
+    out["ok"] = out["viol"] == 0 and out["checked"] > 0.5 * out["hypotheses"] and out["hypotheses"] == int(z["trials"]) * P * H
+    return out
+
+
 def main():
     small = len(sys.argv) > 1 and sys.argv[1] == "small"
+    crafted = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "crafted" else None
     ctx = capi.Context(0)
-    lib = capi.lib()
-    lib.mvs_debug_audit.restype = C.c_int
+    assert capi.LIB_PATH.endswith("libmvslam_hip.so")          # the product binary runs the stage ...
+    dlib = capi.dbg_lib()                                      # ... the diagnostics binary only audits what it left behind
+    dctx = C.c_void_p()
+    assert dlib.mvs_ctx_create(0, C.byref(dctx)) == 0
+    lib = (dlib, dctx)
     cases = []
+    if crafted:
+        c = run_crafted(ctx, lib, crafted)
+        ctx.close()
+        dlib.mvs_ctx_destroy(dctx)
+        print(json.dumps(dict(ok=c["ok"], stage_binary=os.path.basename(capi.LIB_PATH), audit_binary=os.path.basename(capi.DBG_LIB_PATH),
+                              cases=[c])))
+        return 0 if c["ok"] else 1
     if small:
         P, N, H = 6, 500, 2048
         cases.append(run_case(ctx, lib, "small batch @1e-2", synth.make_batch(0, P, n_kp=N), P, N, H, 1e-2))
@@ -110,8 +166,10 @@ def main():
     control = dict(count_viol=ctrl["count_viol"], bound_below_max=int((cm > cb).sum()))
     control_ok = control["count_viol"] > 0 and control["bound_below_max"] == Pc
     ctx.close()
+    dlib.mvs_ctx_destroy(dctx)
     ok = all(c["ok"] for c in cases) and control_ok
-    print(json.dumps(dict(ok=ok, negative_control=control, cases=cases)))
+    print(json.dumps(dict(ok=ok, stage_binary=os.path.basename(capi.LIB_PATH), audit_binary=os.path.basename(capi.DBG_LIB_PATH),
+                          negative_control=control, cases=cases)))
     return 0 if ok else 1
 
 

@@ -182,6 +182,7 @@ def check_band_edges(ctx, lib, rng):
     Hp = ((H + 255) // 256) * 256
     rows = []
     ok = True
+    saved = {}                                  # the crafted point sets, for the product binary's leg (audit_gpu_check.py crafted)
     for trial in range(4):                      # per pair: hypotheses inside and outside the pilot's range
         pts, keep, crafted, recs = [], np.full(P, -1, dtype=np.int32), [], []
         # pass 1: natural points, double-precision records of every hypothesis
@@ -251,10 +252,16 @@ def check_band_edges(ctx, lib, rng):
                 if not (cnt[p] >= need_u and bound[p] <= cap_l):
                     ok = False
             rows.append(row)
+        for p in range(P):
+            saved["pts_%d_%d" % (trial, p)] = pts[p]
+        saved["keep_%d" % trial] = keep.copy()
         # restore the natural points for the next trial
         b.run(prm)
         b.sync()
     b.close()
+    if os.environ.get("MVS_CRAFTED_OUT"):
+        np.savez(os.environ["MVS_CRAFTED_OUT"], trials=4, pairs=P, capacity=N, hypotheses=H, thr=THR, seed=synth.SEED_BASE,
+                 global_index=np.asarray(data["global_index"][:P], dtype=np.int64), **saved)
     return dict(ok=bool(ok), cases=len(rows), crafted=int(sum(r["crafted_upper"] + r["crafted_lower"] for r in rows)),
                 plain_f32_wrong_side=int(sum(r["plain_f32_wrong_side"] for r in rows)),
                 min_upper_margin=int(min(min(r["count32"]["U"], r["mfma"]["U"]) - r["need_upper"] for r in rows)),

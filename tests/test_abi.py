@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libmvslam_hip.so does not export %s" % name
     assert sorted(capi.EXPORTS) == declared            # the python plumbing knows the same surface
-    assert lib.mvs_abi_version() == 3
+    assert lib.mvs_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

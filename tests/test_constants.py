@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -13,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_constants_under_worst_case_constructions():
-    env = dict(os.environ, MVS_USE_DEBUG_LIB="1")
+    crafted = os.path.join(tempfile.mkdtemp(prefix="mvs_crafted_"), "crafted.npz")
+    env = dict(os.environ, MVS_USE_DEBUG_LIB="1", MVS_CRAFTED_OUT=crafted)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "constants_gpu_check.py")], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
@@ -30,3 +32,14 @@ def test_constants_under_worst_case_constructions():
     assert e["ok"] and e["crafted"] > 1500 and e["pilot_hyps"] > 0 and e["pilot_hyps"] < e["cases"]
     assert e["plain_f32_wrong_side"] > 0
     assert e["min_upper_margin"] >= 0 and e["min_lower_margin"] >= 0
+    # ... and the same crafted matches through the PRODUCT binary (round 5): libmvslam_hip.so runs its stage on
+    # them (mvs_batch_run_points), the diagnostics library audits every hypothesis against the bytes it left behind
+    env2 = {k: v for k, v in os.environ.items() if k != "MVS_USE_DEBUG_LIB"}
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "audit_gpu_check.py"), "crafted", crafted], env=env2, cwd=ROOT,
+                        capture_output=True, text=True, timeout=900)
+    assert p2.returncode == 0, (p2.stdout[-3000:], p2.stderr[-3000:])
+    st2 = json.loads([ln for ln in p2.stdout.splitlines() if ln.startswith("{")][-1])
+    print(json.dumps(st2))
+    c = st2["cases"][0]
+    assert st2["ok"] and st2["stage_binary"] == "libmvslam_hip.so" and c["viol"] == 0
+    assert c["hypotheses"] == 4 * 6 * 2048 and c["matches_checked"] > 1e7

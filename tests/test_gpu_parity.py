@@ -433,6 +433,65 @@ def test_two_view_random_scenes(ctx, m, H, noise, thr):
     assert ref["ok"] and ref["n_points"] > 8
 
 
+def test_batch_run_points_is_a_batch_of_sfm_solve(ctx):
+    """mvs_batch_run_points (round 5): the pipeline behind the matcher for a batch of caller-supplied point pairs = one
+    sfm_solve (vision/sfm.hpp:30-35) per pair.  Ragged sizes incl. fewer than 8 and zero matches, two thresholds, enough pairs
+    for the pre-screened stage and the two half batches: winner, count, residual sum, mask, point indices bit-exact against
+    the oracle's sfm_solve of each pair, pose / points to 1e-12; and equal to the single-shot mvs_two_view."""
+    K = np.array([[525.0, 0, 320], [0, 525, 240], [0, 0, 1]])
+    sizes = [1600, 900, 8, 5, 0, 300, 64, 1200] + [150 + 13 * i for i in range(60)]
+    P, N, H = len(sizes), 1700, 2048
+    uv1 = np.zeros((P, N, 2))
+    uv2 = np.zeros((P, N, 2))
+    for p, m in enumerate(sizes):
+        if m:
+            a, c = _scene(900 + p, m, 3e-4)
+            uv1[p, :m] = a * 525 + np.array([320, 240.0])
+            uv2[p, :m] = c * 525 + np.array([320, 240.0])
+    gidx = np.arange(40, 40 + P, dtype=np.int64)
+    b = capi.Batch(ctx, P, N, 32)
+    b.upload_intrinsics(0, K, gidx, count=P)
+    for thr in (1e-2, 2e-3):
+        prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=77, max_error_sq=thr)
+        b.run_points(prm, uv1, uv2, sizes)
+        b.sync()
+        out = b.download()
+        assert not out["matches"].view(np.uint8).any()                       # no match list on this path: rows cleared
+        for p, m in enumerate(sizes):
+            r = out["results"][p]
+            assert r["n_matches"] == m, p
+            if m < 8:
+                assert not r["valid"], p
+                continue
+            ref = o.sfm_solve(uv1[p, :m], uv2[p, :m], K, o.make_params(H, o.SAMPLER_PHILOX, 77 + int(gidx[p]), thr))
+            assert bool(r["valid"]) == ref["ok"], (thr, p)
+            assert r["best_hyp"] == ref["best_hyp"] and r["best_count"] == ref["best_count"], (thr, p)
+            assert r["best_residual"] == ref["best_residual"], (thr, p)
+            assert np.array_equal(out["mask"][p][:m], ref["mask"][:m]), (thr, p)
+            if ref["ok"]:
+                n = ref["n_points"]
+                assert r["n_points"] == n and np.array_equal(out["point_idx"][p][:n], ref["point_idx"]), (thr, p)
+                assert np.abs(r["R"] - ref["R"]).max() <= 1e-12 and np.abs(r["t"] - ref["t"]).max() <= 1e-12, (thr, p)
+                assert helpers.rel_err(out["points"][p][:n], ref["points"]) <= TIGHT, (thr, p)
+        # the single-shot entry point on one of the pairs: same bits (its sampler key offset is 0: compare at gidx 0)
+    b.upload_intrinsics(0, K, np.zeros(P, dtype=np.int64), count=P)
+    prm = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=77, max_error_sq=1e-2)
+    b.run_points(prm, uv1, uv2, sizes)
+    b.sync()
+    out = b.download()
+    for p in (0, 5, 7):
+        m = sizes[p]
+        one = ctx.two_view(uv1[p, :m], uv2[p, :m], K, prm)
+        r = out["results"][p]
+        assert one["best_hyp"] == r["best_hyp"] and one["best_count"] == r["best_count"]
+        assert one["R"].tobytes() == r["R"].tobytes() and one["t"].tobytes() == r["t"].tobytes()
+        assert np.array_equal(one["mask"], out["mask"][p][:m])
+    # argument checks: a count beyond the capacity, a null buffer
+    with pytest.raises(capi.MvsError):
+        b.run_points(prm, uv1[:1], uv2[:1], [N + 1])
+    b.close()
+
+
 def test_two_view_errors(ctx):
     rig = helpers.two_camera_rig("L", rpy=(1.5, 0.7, 0.0), scale=0.5)
     prm = capi.default_params()

@@ -1,9 +1,10 @@
 #!/bin/bash
-# round-4 profile set, run on the GPU box from the repo root: bash tools/profile_r04.sh [tag]
+# the round's profile set, run on the GPU box from the repo root: bash tools/profile.sh [tag]   (tag = round, default r05;
+# python tools/refresh_profiles.py <tag> then copies the summaries into profiles/<tag>_*)
 # (rocprofv3 gets the program itself after `--`, never a wrapper; counters in their own passes, one group per pass)
 set -o pipefail
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/prof_$TAG
 mkdir -p $O
 # --one-stream: every launch covers the whole batch, as in bench.py's live per-kernel table (mvs_batch_time_kernels); the default
@@ -25,5 +26,6 @@ for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WA
   D=$O/pmc_$(echo $G | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D -o p -- $PB --steps 1 --warmup 0 --pairs 128 > $D.json 2> $D.err || { echo "pmc pass failed: $G"; tail -3 $D.err; }
 done
-python3 tools/pmc_summary.py $O/${TAG}_pmc_summary.json 128 $O/pmc_*
+# the summary records the command the counters were collected under (whole-batch launches, --one-stream)
+python3 tools/pmc_summary.py $O/${TAG}_pmc_summary.json 128 "$PB --steps 1 --warmup 0 --pairs 128" $O/pmc_*
 ls $O
