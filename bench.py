@@ -767,7 +767,7 @@ def main():
         # rocprofv3 --pmc pass of this same workload committed under profiles/ ((2*FETCH_SIZE + WRITE_SIZE) KB per
         # MI355X_MICROARCH.md, its own pass); only quoted for the default workload, null otherwise
         traffic, traffic_src = None, None
-        for tname in ("r04_ransac_hbm_traffic.json", "r03_ransac_hbm_traffic.json", "r02_ransac_hbm_traffic.json"):
+        for tname in ("r05_ransac_hbm_traffic.json", "r04_ransac_hbm_traffic.json", "r03_ransac_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.kp == 2000 and args.hyp == 50000 and args.max_error_sq == 1e-2:
                 traffic = int(json.load(open(tpath))["hbm_bytes_per_pair"] * n_local)

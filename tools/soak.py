@@ -23,7 +23,8 @@ rng = np.random.default_rng(args.seed)
 PAIR0 = 10_000 + (args.seed - 2026) * 1000   # synthetic pair ids of part 1
 ctx = capi.Context(0)
 bad = []
-cnt = dict(pairs=0, pairs_ref_threshold=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0, extract=0, sequence_frames=0, single_shot=0)
+cnt = dict(pairs=0, pairs_ref_threshold=0, pairs_match_settings=0, run_points=0, match=0, ransac=0, pnp=0, sfm_refine=0, pnp_refine=0,
+           extract=0, sequence_frames=0, single_shot=0)
 t0 = time.time()
 
 # 1. whole image pairs through the batch API: ragged keypoint counts, varying noise / outliers / hypothesis counts
@@ -51,7 +52,56 @@ prm0 = capi.default_params(num_hypotheses=H, sampler=capi.SAMPLER_PHILOX, seed=5
 b.run(prm0)
 b.sync()
 out0 = b.download(points=False)
+# 1c. (round 5) the batch matcher (matrix cores once the batch has 512 workgroups) under another (ratio, max_dist): no limit
+# takes the uncapped kernel, a limit the capped one (only keys below the cap are inserted); match lists byte for byte
+ratio_c, md_c = float(rng.choice([0.5, 0.7, 0.9])), float(rng.choice([-1.0, 3.0, 25.0, 64.0]))
+b.run(capi.default_params(num_hypotheses=64, sampler=capi.SAMPLER_PHILOX, seed=1, max_error_sq=1e-2, ratio=ratio_c, max_dist=md_c))
+b.sync()
+outc = b.download(mask=False, points=False)
 b.close()
+for i, p in enumerate(data):
+    n = int(sizes[i])
+    want = o.match_visual_features(p["desc1"][:n], p["desc2"][:n], ratio_c, md_c)
+    M = int(outc["results"][i]["n_matches"])
+    cnt["pairs_match_settings"] += 1
+    if not (M == len(want) and outc["matches"][i][:M].tobytes() == want.tobytes()):
+        bad.append(("pair_match_settings", i, ratio_c, md_c))
+# 1d. (round 5) mvs_batch_run_points: a batch of sfm_solve calls on the point pairs of random scenes
+n_pts = max(8, args.cases // 2)
+m_pts = rng.integers(0, 900, size=n_pts)
+m_pts[:3] = [0, 7, 8]
+Np = int(m_pts.max())
+uvs1, uvs2 = np.zeros((n_pts, Np, 2)), np.zeros((n_pts, Np, 2))
+Kp = np.array([[525.0, 0, 320], [0, 525, 240], [0, 0, 1]])
+for i in range(n_pts):
+    if m_pts[i]:
+        a, c = TG._scene(int(rng.integers(0, 1 << 30)), int(m_pts[i]), float(rng.choice([0.0, 1e-4, 1e-3])), outliers=float(rng.choice([0.0, 0.3, 0.6])))
+        uvs1[i, :m_pts[i]] = a * 525 + np.array([320, 240.0])
+        uvs2[i, :m_pts[i]] = c * 525 + np.array([320, 240.0])
+bp = capi.Batch(ctx, n_pts, Np, 32)
+gidx_p = rng.integers(0, 1 << 20, size=n_pts).astype(np.int64)
+bp.upload_intrinsics(0, Kp, gidx_p, count=n_pts)
+thr_p, H_p, seed_p = float(rng.choice([1e-2, 1e-3, 0.0])), int(rng.choice([300, 768, 2049])), int(rng.integers(0, 1 << 30))
+prm_p = capi.default_params(num_hypotheses=H_p, sampler=capi.SAMPLER_PHILOX, seed=seed_p, max_error_sq=thr_p)
+bp.run_points(prm_p, uvs1, uvs2, m_pts)
+bp.sync()
+outp = bp.download(matches=False)
+bp.close()
+for i in range(n_pts):
+    m, r = int(m_pts[i]), outp["results"][i]
+    cnt["run_points"] += 1
+    if m < 8:
+        ok = not r["valid"] and int(r["n_matches"]) == m
+    else:
+        want = o.sfm_solve(uvs1[i, :m], uvs2[i, :m], Kp, o.make_params(H_p, o.SAMPLER_PHILOX, seed_p + int(gidx_p[i]), thr_p))
+        ok = bool(r["valid"]) == want["ok"] and int(r["best_hyp"]) == want["best_hyp"] and int(r["best_count"]) == want["best_count"] \
+            and float(r["best_residual"]) == want["best_residual"] and np.array_equal(outp["mask"][i][:m], want["mask"][:m])
+        if ok and want["ok"]:
+            k = want["n_points"]
+            ok = int(r["n_points"]) == k and np.array_equal(outp["point_idx"][i][:k], want["point_idx"]) and \
+                np.abs(r["R"] - want["R"]).max() <= 1e-12 and np.abs(r["t"] - want["t"]).max() <= 1e-12
+    if not ok:
+        bad.append(("run_points", i, m, thr_p, H_p))
 for i, p in enumerate(data):
     want = o.image_pair(p["desc1"], p["kp1"], p["desc2"], p["kp2"], p["K"], o.make_params(H, o.SAMPLER_PHILOX, 5 + i, 0.0), 0.7, 10.0)
     r = out0["results"][i]
