@@ -4,17 +4,19 @@
 A "step" is one pass of the whole hot path (match -> 8-point RANSAC -> decomposition -> triangulation)
 over one resident batch of synthetic pairs (default 512 pairs of 2000 keypoints, 50 000 hypotheses
 each = BASELINE.json configs[2] per GPU; configs[3] is the same workload on 8 GPUs).  Inputs are
-uploaded to HBM before the timed region.  Rank 0 prints ONE JSON line.
+uploaded to HBM before the timed region.  Rank 0's LAST stdout line is ONE compact JSON object (< 4 KB: the contract's
+fields, `roofline`, `cpu_baseline`, one scalar per side leg -- what the driver parses); the full object goes to
+bench_detail.json beside this file (--detail PATH; --print-detail also prints it as an earlier line).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python bench.py --gpus 8                       # spawns its own 8 rank processes (no launcher needed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Besides the contract's fields the line carries (rank 0, N = 1): `roofline.per_kernel` (executed work per kernel,
-registers / LDS / occupancy as the runtime reports them), `reference_threshold` (the SURVEY 8(d) threshold
-5e-2/K00/K11 in its own wall-clock loop with its own roofline), and the rows either side of the path:
-`sequence` (BASELINE configs[4]), `refine`, `extract`.
+The detail object carries (rank 0, N = 1): `roofline.per_kernel` (executed work per kernel, registers / LDS / occupancy as
+the runtime reports them), `reference_threshold` (the SURVEY 8(d) threshold 5e-2/K00/K11 in its own wall-clock loop with
+its own roofline), `sensitivity` (24 cells), and the rows either side of the path: `sequence` (BASELINE configs[4]),
+`refine`, `extract`.
 """
 import argparse
 import json
