@@ -3207,6 +3207,11 @@ bool kernel_desc(int id, int max_kp, int desc_words, KernelDesc *out)
                                   : reinterpret_cast<const void *>(match_mfma_kernel<true>);
         d.threads = desc_words == 8 ? kMmThreads : 1024;
         break;
+    case kKMatchTopkVec:
+        d.name = "match_topk_kernel<8>";
+        d.fn = reinterpret_cast<const void *>(match_topk_kernel<8>);
+        d.threads = 1024;
+        break;
     case kKMatchCompact:
         d.name = "match_compact_kernel";
         d.fn = reinterpret_cast<const void *>(match_compact_kernel);
@@ -3388,15 +3393,16 @@ void launch_match_topk(const BatchDev &b, const RunParams &rp, int n_active, hip
 {
     const dim3 grid((b.max_kp + 63) / 64, n_active), block(1024);
     const double ratio = rp.ratio, md = rp.max_dist;
-    if (lt) lt->mark(kKMatchTopk);
+    const int mm_groups8 = ((b.max_kp + kMmQueries - 1) / kMmQueries) * n_active;
+    const bool mfma8 = b.desc_words == 8 && (g_match_mfma == 2 || (g_match_mfma == 1 && mm_groups8 >= 512));
+    if (lt) lt->mark(b.desc_words == 8 && !mfma8 ? kKMatchTopkVec : kKMatchTopk);
     switch (b.desc_words) {
     case 4: hipLaunchKernelGGL(match_topk_kernel<4>, grid, block, 0, stream, b, ratio, md); break;
     case 8: {
         // the matrix-core kernel takes 256 queries per workgroup over all trains: throughput for a batch (0.55 against 1.05 ms
         // per 512 pairs), but a long serial walk when there are only a handful of workgroups -- one pair: 60 us against 22 for
         // the vector kernel with its 64 queries per workgroup.  Below two workgroups per CU the vector kernel runs.
-        const int mm_groups = ((b.max_kp + kMmQueries - 1) / kMmQueries) * n_active;
-        if (g_match_mfma == 2 || (g_match_mfma == 1 && mm_groups >= 512)) {
+        if (mfma8) {
             const dim3 mgrid((b.max_kp + kMmQueries - 1) / kMmQueries, n_active);
             const int cap = match_cap_distance(ratio, md);
             if (cap >= 0)

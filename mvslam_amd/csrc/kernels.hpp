@@ -326,6 +326,7 @@ enum KernelId : int {
     kKFinModel,
     kKTriangulate,
     kKFinSelect,
+    kKMatchTopkVec,    // match_topk_kernel<8>: the vector 2-NN kernel when a 256-bit launch is too small for the matrix-core one
     kKernelCountProduct,   // the product library's table ends here
     // kernels of the experiment ladder: they exist in the diagnostics build (-DMVS_DEBUG_HOOKS) only
     kKRansacScore = kKernelCountProduct,   // hypothesis-per-lane scoring of stored F records
