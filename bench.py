@@ -865,14 +865,21 @@ def main():
                     batch.run(prm)
                     batch.download()
                 out["pcie_inclusive_pairs_per_s_naive"] = round(n_local * reps / (time.perf_counter() - t0), 1)
-            # (b) double-buffered: two batches on two contexts (streams), pinned host buffers (mvs_host_alloc),
-            # asynchronous upload -> run -> asynchronous download; batch k+1's transfers overlap batch k's kernels.
-            # Every step moves the full inputs host -> device and the full outputs device -> host.
-            ctx2 = make_ctx(capi, dev, args)
+            # (b) double-buffered: two batches on two contexts, each on its own caller-owned stream, pinned host buffers
+            # (mvs_host_alloc), asynchronous upload -> run -> asynchronous download.  Every step moves the full inputs host ->
+            # device and the full outputs device -> host.  The two lanes' RUNS are chained by events (lane B's kernels wait for
+            # lane A's previous run and vice versa), the copies are not: a lane's upload and download then travel while the
+            # OTHER lane computes.  Without the chain both lanes' kernels share the chip, finish together and upload together
+            # with the GPU idle (round 4's figure, 63-92 k pairs/s: tools/pcie_probe.py and a rocprofv3 kernel + memory-copy
+            # trace showed the lock-step; round 5).  A host C++ caller does the same with mvs_ctx_create_on_stream + hipEvents.
             lanes = []
             N = args.kp
-            for cx in (ctx, ctx2):
-                bb = batch if cx is ctx else capi.Batch(cx, n_local, N, 32)
+            streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            ctxs = [capi.Context(dev, stream=st.cuda_stream) for st in streams]
+            for cx in ctxs:
+                if getattr(args, "one_stream", False):
+                    cx.set_half_batches(False)
+                bb = capi.Batch(cx, n_local, N, 32)
                 pin = {k: capi.pinned_empty(np.asarray(data[k]).shape, np.asarray(data[k]).dtype)
                        for k in ("desc1", "kp1", "n1", "desc2", "kp2", "n2", "global_index")}
                 pin["K"] = capi.pinned_empty((n_local, 9), np.float64)
@@ -884,36 +891,43 @@ def main():
                 o_pt = capi.pinned_empty((n_local, N, 3), np.float64)
                 o_ix = capi.pinned_empty((n_local, N), np.int32)
                 lanes.append((bb, pin, (o_res, o_mt, o_mk, o_pt, o_ix)))
+            run_done = [None, None]   # event behind the latest run of each lane
 
-            def submit(lane):
-                bb, pin, (o_res, o_mt, o_mk, o_pt, o_ix) = lane
+            def submit(k):
+                bb, pin, (o_res, o_mt, o_mk, o_pt, o_ix) = lanes[k]
                 bb.sync()   # the lane's previous step (incl. its download) has completed: its buffers are free
                 bb.upload_async(0, pin["desc1"], pin["kp1"], pin["n1"], pin["desc2"], pin["kp2"], pin["n2"], pin["K"],
                                 pin["global_index"])
+                if run_done[k ^ 1] is not None:
+                    streams[k].wait_event(run_done[k ^ 1])   # compute is ONE resource: the runs alternate, the copies float
                 bb.run(prm)
+                run_done[k] = torch.cuda.Event()
+                run_done[k].record(streams[k])
                 bb.download_async(0, n_local, o_res, o_mt, o_mk, o_pt, o_ix)
 
             for k in range(2):
-                submit(lanes[k % 2])
+                submit(k % 2)
             for lane in lanes:
                 lane[0].sync()
             reps = 8
             t0 = time.perf_counter()
             for k in range(reps):
-                submit(lanes[k % 2])
+                submit(k % 2)
             for lane in lanes:
                 lane[0].sync()
             dt = time.perf_counter() - t0
             out["pcie_inclusive_pairs_per_s"] = round(n_local * reps / dt, 1)
-            out["pcie_note"] = ("double-buffered over two streams with pinned host buffers: %.1f MB up + %.1f MB down per step; "
+            out["pcie_note"] = ("two lanes (context + batch on its own stream), pinned host buffers: %.1f MB up + %.1f MB down per "
+                                "step; the lanes' runs are chained by events, their copies overlap the other lane's kernels; "
                                 "valid pairs in the last downloaded step: %d"
                                 % (sum(v.nbytes for v in lanes[0][1].values()) / 1e6, sum(v.nbytes for v in lanes[0][2]) / 1e6,
                                    int(lanes[(reps - 1) % 2][2][0]["valid"].sum())))
-            lanes[1][0].close()
             for lane in lanes:
+                lane[0].close()
                 for a in list(lane[1].values()) + list(lane[2]):
                     capi.pinned_free(a)
-            ctx2.close()
+            for cx in ctxs:
+                cx.close()
         if world == 1 and "refine" in sections:
             out["refine"] = bench_refine(capi, np, batch, data, dl, args)
         if world == 1 and not args.no_cpu_baseline:
