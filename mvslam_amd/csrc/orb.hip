@@ -6,16 +6,25 @@
 // reach (the CPU oracle oracle/mvs_orb_oracle.c follows the same specification bit for bit):
 //   resize_kernel    level l from level l-1: pixel-centre bilinear in integer arithmetic (11-bit weights from exact
 //                    rationals, (sum + 2^21) >> 22)                                           thread per pixel
-//   fast_nms_kernel  FAST-9/16 score (the largest threshold at which the pixel is still a corner) and the strict 3x3
-//                    maximum of one 64x16 tile through LDS -> rank key (score desc, y, x), one atomic per tile; the
-//                    ORDER of the list does not matter, the select kernel sorts it
-//   select_kernel    one launch, one workgroup per (image, level): bitonic sort of the keys in LDS, keep 2 n_l, Harris response
-//                    (7x7, k = 0.04) of those, sort again by (response desc, y, x), keep n_l     (cv::ORB's retainBest)
-//   blur_kernel      7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18}, BORDER_REFLECT_101, rows then columns
-//                    of one tile through LDS
-//   describe_kernel  half a wavefront per keypoint: intensity-centroid moments over the radius-15 disc (32 lanes split
-//                    the disc rows, butterfly sum), cos / sin = moments / hypot (no trigonometry), 256 steered BRIEF tests
-//                    on the blurred level (lane b < 32 builds byte b), cv::KeyPoint record
+//   fast_nms_kernel  ONE launch over the tiles of every level.  FAST-9/16 score (the largest threshold at which the pixel
+//                    is still a corner) and the strict 3x3 maximum of one 64x16 tile through LDS: the cheap antipodal test
+//                    runs for every pixel, the pixels that pass it are COMPACTED into an LDS list and only those get the
+//                    full 16-pixel arc minimum, on dense lanes (round 5; before, one passing lane made its whole wavefront
+//                    pay the full score) -> rank key (score desc, y, x), one atomic per tile; the ORDER of the list does
+//                    not matter, the select kernel ranks it
+//   select_kernel    one launch, one workgroup per (image, level): the 2 n_l best FAST scores by a RADIX SELECT over the
+//                    key bytes (five 256-bin histogram passes give the exact cut-off key; round 5 -- before, a bitonic
+//                    sort of all <= 16384 candidates in 128 KB of LDS), Harris response (7x7, k = 0.04) of those from a
+//                    9 x 12 register window, bitonic sort of the <= 2 n_l keys (response desc, y, x), keep n_l
+//                    (cv::ORB's retainBest)
+//   blur_kernel      ONE launch over every level: 7x7 sigma-2 Gaussian as the Q8 kernel {18,34,49,54,49,34,18},
+//                    BORDER_REFLECT_101, rows then columns of one tile through LDS
+//   describe_kernel  a wavefront per keypoint (round 5): the 31 x 32 image window and the 37 x 40 blurred window arrive as
+//                    ten independent unaligned dword loads per lane (the next keypoint's are in flight while this one is
+//                    computed) and are parked in LDS; intensity-centroid moments over the radius-15 disc = lane per row,
+//                    v_dot4_u32_u8 against the row's mask / (u + 16) weights, butterfly sum; cos / sin = moments / hypot
+//                    (no trigonometry); 256 steered BRIEF tests on the blurred window (four per lane, bytes from LDS);
+//                    cv::KeyPoint record
 // Everything is integer or single IEEE float operations in a stated order, so GPU and oracle agree bit for bit.
 #include "kernels.hpp"
 
@@ -30,23 +39,67 @@ __constant__ int kFastDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1,
 __constant__ int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 __constant__ int kGauss[7] = {18, 34, 49, 54, 49, 34, 18};
 
+// four bytes at ANY address as one load (gfx950 global memory takes unaligned dwords; hipcc emits global_load_dword)
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // tab: per destination column / row {source index, 11-bit weight of the next sample}, computed once per level on the
-// host from the exact rationals ((2 d + 1) s_src - s_dst) / (2 s_dst) -- 64-bit divisions per pixel were 3/4 of this kernel
+// host from the exact rationals ((2 d + 1) s_src - s_dst) / (2 s_dst) -- 64-bit divisions per pixel were 3/4 of this kernel.
+// Round 5: FOUR adjacent destination pixels per thread.  Their source columns lie within eight bytes of the first one's
+// (the step between levels is 1.2; a thread whose span is wider falls back to byte loads), so the two source rows arrive
+// as two unaligned 8-byte windows instead of sixteen byte loads, and the result leaves as one dword.
 __global__ void resize_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, const int2 *xtab,
                               const int2 *ytab)
 {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int dx = 4 * (blockIdx.x * blockDim.x + threadIdx.x), dy = blockIdx.y * blockDim.y + threadIdx.y;
     if (dx >= dw || dy >= dh)
         return;
     src += (size_t)blockIdx.z * sw * sh;
     dst += (size_t)blockIdx.z * dw * dh;
-    const int2 tx = xtab[dx], ty = ytab[dy];
-    const int sx = tx.x, wx = tx.y, sy = ty.x, wy = ty.y;
-    const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
-    const uint32_t p00 = src[sy * sw + sx], p01 = src[sy * sw + sx1], p10 = src[sy1 * sw + sx], p11 = src[sy1 * sw + sx1];
-    const uint32_t v = p00 * (uint32_t)((2048 - wx) * (2048 - wy)) + p01 * (uint32_t)(wx * (2048 - wy)) +
-                       p10 * (uint32_t)((2048 - wx) * wy) + p11 * (uint32_t)(wx * wy);
-    dst[(size_t)dy * dw + dx] = (uint8_t)((v + (1u << 21)) >> 22);
+    const int2 ty = ytab[dy];
+    const int sy = ty.x, wy = ty.y, sy1 = min(sy + 1, sh - 1);
+    const uint8_t *r0 = src + (size_t)sy * sw, *r1 = src + (size_t)sy1 * sw;
+    int2 tx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        tx[k] = xtab[min(dx + k, dw - 1)];
+    const int s0 = tx[0].x;
+    const bool window = tx[3].x + 1 - s0 <= 7;   // (source columns ascend with the destination column)
+    uint64_t w0 = 0, w1 = 0;
+    if (window) {
+        w0 = (uint64_t)load_u32_unaligned(r0 + s0) | ((uint64_t)load_u32_unaligned(r0 + s0 + 4) << 32);
+        w1 = (uint64_t)load_u32_unaligned(r1 + s0) | ((uint64_t)load_u32_unaligned(r1 + s0 + 4) << 32);
+    }
+    uint32_t o8[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sx = tx[k].x, wx = tx[k].y, sx1 = min(sx + 1, sw - 1);
+        uint32_t p00, p01, p10, p11;
+        if (window) {
+            const int a = 8 * (sx - s0), b = 8 * (sx1 - s0);
+            p00 = (uint32_t)(w0 >> a) & 0xffu, p01 = (uint32_t)(w0 >> b) & 0xffu;
+            p10 = (uint32_t)(w1 >> a) & 0xffu, p11 = (uint32_t)(w1 >> b) & 0xffu;
+        } else {
+            p00 = r0[sx], p01 = r0[sx1], p10 = r1[sx], p11 = r1[sx1];
+        }
+        const uint32_t v = p00 * (uint32_t)((2048 - wx) * (2048 - wy)) + p01 * (uint32_t)(wx * (2048 - wy)) +
+                           p10 * (uint32_t)((2048 - wx) * wy) + p11 * (uint32_t)(wx * wy);
+        o8[k] = (v + (1u << 21)) >> 22;
+    }
+    uint8_t *o = dst + (size_t)dy * dw + dx;
+    if (dx + 3 < dw) {
+        const uint32_t v = o8[0] | (o8[1] << 8) | (o8[2] << 16) | (o8[3] << 24);
+        __builtin_memcpy(o, &v, 4);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (dx + k < dw)
+                o[k] = (uint8_t)o8[k];
+    }
 }
 
 __device__ __forceinline__ uint64_t rank_key(uint32_t value_desc, int y, int x)
@@ -54,78 +107,124 @@ __device__ __forceinline__ uint64_t rank_key(uint32_t value_desc, int y, int x)
     return ((uint64_t)(0xffffffffu - value_desc) << 32) | ((uint64_t)(uint32_t)y << 16) | (uint32_t)x;
 }
 
+// the tiles of every level flattened into one grid (by-value kernel argument): level l owns blocks [start[l], start[l+1])
+// of tx[l] tiles per row
+struct OrbGrid {
+    int fast_start[kOrbMaxLevels + 1], fast_tx[kOrbMaxLevels];
+    int blur_start[kOrbMaxLevels + 1], blur_tx[kOrbMaxLevels];
+};
+
+// every arc of 9 contiguous circle pixels contains one pixel of each antipodal pair: if both pixels of a pair are within
+// the threshold of the centre there is no corner (most pixels of a real image leave here)
+__device__ __forceinline__ bool fast_maybe(const uint8_t *c, int P, int threshold)
+{
+    const int ctr = c[0];
+    const int d0 = (int)c[3 * P] - ctr, d8 = (int)c[-3 * P] - ctr, d4 = (int)c[3] - ctr, d12 = (int)c[-3] - ctr;
+    return (max(abs(d0), abs(d8)) > threshold) && (max(abs(d4), abs(d12)) > threshold);
+}
+
 // FAST-9/16 score of the pixel at LDS position c (row pitch P): the largest threshold at which it is still a corner,
-// 0 if below `threshold`
+// 0 if below `threshold` (a pixel that fails fast_maybe scores below the threshold: its score is never computed).
+// score + 1 = max over the 16 arcs of 9 contiguous ring pixels of max(min(ring) - centre, centre - max(ring)), and
+// centre - max(ring) = min(255 - ring) - (255 - centre): both arc minima run through ONE network of packed 16-bit minima
+// over (ring, 255 - ring) pairs -- one v_mad_i32_i24 builds a pair (ring * -65535 + (255 << 16)), windows of 2, 4, 8 + 1 by
+// doubling (round 5: ~100 vector instructions per pixel instead of ~165 on separate min / max chains).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int fast_score_lds(const uint8_t *c, int P, int threshold)
 {
     const int ctr = c[0];
-    // every arc of 9 contiguous circle pixels contains one pixel of each antipodal pair: if both pixels of a pair are
-    // within the threshold of the centre there is no corner (most pixels of a real image leave here)
-    const int d0 = (int)c[3 * P] - ctr, d8 = (int)c[-3 * P] - ctr, d4 = (int)c[3] - ctr, d12 = (int)c[-3] - ctr;
-    if (!((max(abs(d0), abs(d8)) > threshold) && (max(abs(d4), abs(d12)) > threshold)))
-        return 0;
-    int d[16];
+    u16x2 d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int ring = c[kFastDy[k] * P + kFastDx[k]];
+        d[k] = __builtin_bit_cast(u16x2, ring * -65535 + (255 << 16));   // (ring, 255 - ring)
+    }
+    u16x2 m2[16], m4[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-        d[k] = (int)c[kFastDy[k] * P + kFastDx[k]] - ctr;
-    // min / max over every window of 9 by doubling: windows of 2, 4, 8, then one more element
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+        m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+    u16x2 best = {0, 0};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        lo2[k] = min(d[k], d[(k + 1) & 15]);
-        hi2[k] = max(d[k], d[(k + 1) & 15]);
+        const u16x2 m9 = __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = __builtin_elementwise_max(best, m9);
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
-    }
-    int best = -256;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // brighter arc: min of (ring - centre)
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // darker arc: min of (centre - ring) = -max
-        best = max(best, max(lo9, -hi9));
-    }
-    const int sc = best - 1;
+    const int sc = max((int)best.x - ctr, (int)best.y - (255 - ctr)) - 1;
     return sc >= threshold ? sc : 0;
 }
 
-// FAST + non-maximum suppression of one 64 x 16 tile through LDS: the image patch (tile + 4) is read from HBM once, the
-// scores of (tile + 1) never leave the CU, and the surviving corners are appended with ONE atomic per tile (all corners of
-// a level append to the same counter and same-address atomics serialise: one per wavefront was 46 % of the extraction).
-// Keys carry (score desc, y, x): the order of the list does not matter, select_kernel sorts it.
-constexpr int kTileW = 64, kTileH = 16;
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *img, int W, int H, int threshold, int edge, uint64_t *keys,
-                                                       int32_t *count, int cap, int level, int n_levels)
+// FAST + non-maximum suppression of one 64 x 16 tile through LDS: the image patch (tile + 4) is read from HBM once (as
+// unaligned dwords: columns past the row's end belong to pixels whose score is never taken), the scores of (tile + 1) never
+// leave the CU, and the surviving corners are appended with ONE atomic per tile (all corners of a level append to the same
+// counter and same-address atomics serialise: one per wavefront was 46 % of the extraction).  Keys carry (score desc, y,
+// x): the order of the list does not matter, select_kernel ranks it.
+// Round 5: scoring in two passes.  The antipodal test is 4 LDS bytes and a dozen instructions, the full score 16 bytes and
+// ~200; on a textured image a tenth to a third of the pixels pass the test, spread so that nearly every wavefront held one
+// and paid the full score for all 64 lanes.  Now the passing pixels are compacted (ballot + one LDS atomic per wavefront)
+// and the full score runs over the list.
+constexpr int kTileW = 64, kTileH = 16, kBlurH = 32;
+__global__ __launch_bounds__(256) void fast_nms_kernel(OrbDev d, OrbGrid g)
 {
     constexpr int PW = kTileW + 8, PH = kTileH + 8;      // image patch: +-4 (NMS 1 + circle 3)
     constexpr int SW = kTileW + 2, SH = kTileH + 2;      // score patch: +-1
-    __shared__ uint8_t s_img[PH * PW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[PH * PW];
     __shared__ uint8_t s_sc[SH * SW];
+    __shared__ uint16_t s_list[SH * SW];
+    __shared__ int s_n;
     __shared__ int wave_off[4];
     __shared__ int tile_base;
-    const int b = blockIdx.z, tid = threadIdx.x;
-    img += (size_t)b * W * H;
-    const int x0 = edge + blockIdx.x * kTileW, y0 = edge + blockIdx.y * kTileH;   // first output pixel of the tile
-    for (int i = tid; i < PH * PW; i += 256) {
-        const int py = i / PW, px = i - py * PW;
-        const int gx = min(max(x0 - 4 + px, 0), W - 1), gy = min(max(y0 - 4 + py, 0), H - 1);   // clamped reads are never used
-        s_img[i] = img[gy * W + gx];
+    int level = 0;
+    while (level + 1 < d.n_levels && (int)blockIdx.x >= g.fast_start[level + 1])
+        ++level;
+    const OrbLevel &L = d.level[level];
+    const int W = L.w, H = L.h, edge = d.edge, threshold = d.fast_threshold;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int t = (int)blockIdx.x - g.fast_start[level];
+    const int tyb = t / g.fast_tx[level], txb = t - tyb * g.fast_tx[level];
+    const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * W * H;
+    const int x0 = edge + txb * kTileW, y0 = edge + tyb * kTileH;   // first output pixel of the tile
+    if (tid == 0)
+        s_n = 0;
+    for (int q = tid; q < PH * (PW / 4); q += 256) {
+        const int py = q / (PW / 4), c = q - py * (PW / 4);
+        const int gy = min(max(y0 - 4 + py, 0), H - 1);           // clamped rows are never used
+        reinterpret_cast<uint32_t *>(s_img)[q] = load_u32_unaligned(img + (size_t)gy * W + (x0 - 4 + 4 * c));
     }
     __syncthreads();
-    for (int i = tid; i < SH * SW; i += 256) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i0 = 0; i0 < SH * SW; i0 += 256) {
+        const int i = i0 + tid;
+        bool f = false;
+        if (i < SH * SW) {
+            const int qy = i / SW, qx = i - qy * SW;
+            const int gx = x0 - 1 + qx, gy = y0 - 1 + qy;
+            s_sc[i] = 0;
+            if (gx >= 3 && gy >= 3 && gx < W - 3 && gy < H - 3)
+                f = fast_maybe(s_img + (qy + 3) * PW + (qx + 3), PW, threshold);
+        }
+        const unsigned long long m = __ballot(f);
+        if (m) {   // wavefront-uniform
+            int base = 0;
+            if (lane == 0)
+                base = atomicAdd(&s_n, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (f)
+                s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int n_list = s_n;
+    for (int j = tid; j < n_list; j += 256) {
+        const int i = s_list[j];
         const int qy = i / SW, qx = i - qy * SW;
-        const int gx = x0 - 1 + qx, gy = y0 - 1 + qy;
-        int sc = 0;
-        if (gx >= 3 && gy >= 3 && gx < W - 3 && gy < H - 3)
-            sc = fast_score_lds(s_img + (qy + 3) * PW + (qx + 3), PW, threshold);
-        s_sc[i] = (uint8_t)sc;
+        s_sc[i] = (uint8_t)fast_score_lds(s_img + (qy + 3) * PW + (qx + 3), PW, threshold);
     }
     __syncthreads();
     // 4 output pixels per thread: rows ty, ty + 4, ty + 8, ty + 12 of column tx
     const int tx = tid & 63, ty = tid >> 6;
-    const int lane = tid & 63, wave = tid >> 6;
     unsigned long long masks[4];
     int scs[4];
     int total_wave = 0;
@@ -151,7 +250,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *img, int W
     if (lane == 0)
         wave_off[wave] = total_wave;
     __syncthreads();
-    const size_t slot = (size_t)b * n_levels + level;
+    const size_t slot = (size_t)b * d.n_levels + level;
     if (tid == 0) {
         int total = 0;
 #pragma unroll
@@ -160,7 +259,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *img, int W
             wave_off[w] = total;
             total += c;
         }
-        tile_base = total ? atomicAdd(&count[slot], total) : 0;
+        tile_base = total ? atomicAdd(&d.cand_count[slot], total) : 0;
     }
     __syncthreads();
     int base = tile_base + wave_off[wave];
@@ -168,21 +267,48 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t *img, int W
     for (int r = 0; r < 4; ++r) {
         if (scs[r]) {
             const int idx = base + __popcll(masks[r] & ((1ull << lane) - 1ull));
-            if (idx < cap)
-                keys[slot * cap + idx] = rank_key((uint32_t)scs[r], y0 + ty + 4 * r, x0 + tx);
+            if (idx < d.cand_cap)
+                d.cand_keys[slot * d.cand_cap + idx] = rank_key((uint32_t)scs[r], y0 + ty + 4 * r, x0 + tx);
         }
         base += __popcll(masks[r]);
     }
 }
 
+// Harris response (7x7 window, Sobel 3x3 gradients, k = 0.04) of the pixel (x0, y0).  Round 5: rows y0-4 .. y0+4,
+// columns x0-4 .. x0+7 arrive as 27 independent unaligned dword loads and everything else happens in registers -- the
+// integer sums a, b, c are the same whatever the order (before: 49 x 8 byte loads in a dependent loop, ~1 us each from L2)
 __device__ __forceinline__ float harris_at(const uint8_t *img, int W, int x0, int y0)
 {
+    uint32_t r[9][3];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const uint8_t *p = img + (y0 - 4 + j) * W + (x0 - 4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            r[j][k] = load_u32_unaligned(p + 4 * k);
+    }
+    // per row j and window column x (0 .. 6 <-> x0-3 .. x0+3; the pixel itself is byte x + 1 of the row):
+    //   dxr = p[+1] - p[-1],  sxr = p[-1] + 2 p[0] + p[+1];   Ix = 2 dxr[j] + dxr[j-1] + dxr[j+1],  Iy = sxr[j+1] - sxr[j-1]
+    int dxr[9][7], sxr[9][7];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        int px[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            px[k] = (int)((r[j][k >> 2] >> (8 * (k & 3))) & 0xffu);
+#pragma unroll
+        for (int x = 0; x < 7; ++x) {
+            dxr[j][x] = px[x + 2] - px[x];
+            sxr[j][x] = px[x] + 2 * px[x + 1] + px[x + 2];
+        }
+    }
     int a = 0, b = 0, c = 0;
-    for (int dy = -3; dy <= 3; ++dy)
-        for (int dx = -3; dx <= 3; ++dx) {
-            const uint8_t *p = img + (y0 + dy) * W + (x0 + dx);
-            const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-W + 1] - (int)p[-W - 1]) + ((int)p[W + 1] - (int)p[W - 1]);
-            const int Iy = ((int)p[W] - (int)p[-W]) * 2 + ((int)p[W - 1] - (int)p[-W - 1]) + ((int)p[W + 1] - (int)p[-W + 1]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+#pragma unroll
+        for (int x = 0; x < 7; ++x) {
+            const int Ix = 2 * dxr[j][x] + dxr[j - 1][x] + dxr[j + 1][x];
+            const int Iy = sxr[j + 1][x] - sxr[j - 1][x];
             a += Ix * Ix;
             b += Iy * Iy;
             c += Ix * Iy;
@@ -221,28 +347,97 @@ __device__ void bitonic_sort(uint64_t *k, int n)
 
 using Sel = OrbSel;
 
-// grid (n_images, n_levels): all levels of all images in one launch (one launch per level left 3/4 of the CUs idle)
+// grid (n_images, n_levels): all levels of all images in one launch (one launch per level left 3/4 of the CUs idle).
+// Dynamic LDS: room for the next power of two above 2 max(n_l) keys (launch_orb).
+// retainBest(2 n_l) by FAST score needs the SET of the 2 n_l smallest keys, not their order: a radix select over the five
+// key bytes that vary (score, y, x; keys are unique) finds the exact cut-off key in five histogram passes over the
+// candidates in global memory (L2-resident, coalesced), a sixth pass compacts the keys at or below it.
 __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
 {
     extern __shared__ uint64_t keys[];
+    __shared__ int hist[256];
+    __shared__ int s_bin, s_k, s_cnt;
     const int b = blockIdx.x, level = blockIdx.y;
     const OrbLevel &L = d.level[level];
     if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
         return;   // sel_count stays 0
+    const int tid = threadIdx.x, lane = tid & 63;
     const size_t slot = (size_t)b * d.n_levels + level;
     const int found = d.cand_count[slot];
     const int c = min(found, d.cand_cap);
-    int n2 = 1;
-    while (n2 < c)
-        n2 <<= 1;
     const uint64_t *src = d.cand_keys + slot * d.cand_cap;
-    for (int i = threadIdx.x; i < n2; i += blockDim.x)
-        keys[i] = i < c ? src[i] : ~0ull;
-    bitonic_sort(keys, n2);
-    // retainBest(2 n_l) by FAST score, then Harris on the survivors
     const int keep1 = min(c, 2 * L.n_keep);
+    uint64_t kstar = ~0ull;   // the keep1-th smallest key
+    if (keep1 < c) {          // (uniform)
+        uint64_t prefix = 0, mask = 0;
+        int k = keep1;
+        for (int byte = 4; byte >= 0; --byte) {
+            if (tid < 256)
+                hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < c; i += 1024) {
+                const uint64_t key = src[i];
+                if ((key & mask) == prefix)
+                    atomicAdd(&hist[(int)(key >> (8 * byte)) & 255], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {   // one wavefront: lane l owns bins 4 l .. 4 l + 3
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int sum = (h0 + h1) + (h2 + h3);
+                int incl = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o)
+                        incl += up;
+                }
+                const int excl = incl - sum;
+                if (excl < k && k <= incl) {   // exactly one lane: the matching keys number at least k
+                    int r = k - excl, bin = 4 * tid;
+                    if (r > h0) {
+                        r -= h0, ++bin;
+                        if (r > h1) {
+                            r -= h1, ++bin;
+                            if (r > h2)
+                                r -= h2, ++bin;
+                        }
+                    }
+                    s_bin = bin;
+                    s_k = r;
+                }
+            }
+            __syncthreads();
+            prefix |= (uint64_t)(uint32_t)s_bin << (8 * byte);
+            mask |= 0xffull << (8 * byte);
+            k = s_k;
+            // (the next pass's barrier behind the histogram reset orders these reads before the next writes of s_bin / s_k)
+        }
+        kstar = prefix | 0xffffff0000000000ull;   // the high word of a key is 0xffffffff - score, score <= 255
+    }
+    if (tid == 0)
+        s_cnt = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < c; i0 += 1024) {
+        const int i = i0 + tid;
+        const uint64_t key = i < c ? src[i] : ~0ull;
+        const bool take = i < c && key <= kstar;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            int base = 0;
+            if (lane == 0)
+                base = atomicAdd(&s_cnt, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (take)
+                keys[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+    __syncthreads();   // s_cnt == keep1
+    // Harris on the survivors, then the order by (response desc, y, x)
+    int n2 = 1;
+    while (n2 < keep1)
+        n2 <<= 1;
     const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * L.w * L.h;
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+    for (int i = tid; i < n2; i += blockDim.x) {
         uint64_t k = ~0ull;
         if (i < keep1) {
             const int x = (int)(keys[i] & 0xffffu), y = (int)((keys[i] >> 16) & 0xffffu);
@@ -250,10 +445,7 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
         }
         keys[i] = k;   // slot i is read and written by this thread only
     }
-    int m2 = 1;
-    while (m2 < keep1)
-        m2 <<= 1;
-    bitonic_sort(keys, max(m2, 1));
+    bitonic_sort(keys, n2);
     const int keep2 = min(keep1, L.n_keep);
     Sel *sel = d.sel + slot * d.nfeatures;
     for (int i = threadIdx.x; i < keep2; i += blockDim.x) {
@@ -271,28 +463,49 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
     }
 }
 
-// 7x7 sigma-2 blur of one 64 x 16 tile: rows then columns through LDS (Q8 kernel, BORDER_REFLECT_101, u16 row sums).
+// 7x7 sigma-2 blur of one 64 x 32 tile (round 5: 32 rows -- the row pass runs over the tile's rows + 6, at 16 rows that is
+// 37 % more than the tile): rows then columns through LDS (Q8 kernel, BORDER_REFLECT_101, u16 row sums).
 // Every work item produces 4 adjacent pixels from dword LDS reads (3 per row item, 14 per column item); byte-wide LDS
 // reads made the first LDS version slower than two global passes.
-__global__ __launch_bounds__(256) void blur_kernel(const uint8_t *img, int W, int H, uint8_t *out)
+__global__ __launch_bounds__(256) void blur_kernel(OrbDev d, OrbGrid g)
 {
-    constexpr int PW = kTileW + 8, PH = kTileH + 6;   // 72-byte pitch: output column 4k starts at a dword of the patch
+    constexpr int PW = kTileW + 8, PH = kBlurH + 6;   // 72-byte pitch: output column 4k starts at a dword of the patch
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PH * PW];
     __shared__ __attribute__((aligned(16))) uint16_t s_row[PH * kTileW];
     const int tid = threadIdx.x;
-    img += (size_t)blockIdx.z * W * H;
-    out += (size_t)blockIdx.z * W * H;
-    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
-    for (int i = tid; i < PH * PW; i += 256) {
-        const int py = i / PW, px = i - py * PW;
-        int gx = x0 - 3 + px, gy = y0 - 3 + py;
-        if (gx < 0) gx = -gx;
-        if (gx >= W) gx = 2 * (W - 1) - gx;
-        if (gy < 0) gy = -gy;
-        if (gy >= H) gy = 2 * (H - 1) - gy;
-        gx = min(max(gx, 0), W - 1);   // only for tile pixels beyond the image (never written)
-        gy = min(max(gy, 0), H - 1);
-        s_img[i] = img[gy * W + gx];
+    int level = 0;
+    while (level + 1 < d.n_levels && (int)blockIdx.x >= g.blur_start[level + 1])
+        ++level;
+    const OrbLevel &L = d.level[level];
+    const int W = L.w, H = L.h;
+    const int t = (int)blockIdx.x - g.blur_start[level];
+    const int tyb = t / g.blur_tx[level], txb = t - tyb * g.blur_tx[level];
+    const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)blockIdx.y * W * H;
+    uint8_t *out = d.blur + L.offset * d.n_images + (size_t)blockIdx.y * W * H;
+    const int x0 = txb * kTileW, y0 = tyb * kBlurH;
+    if (x0 >= 3 && x0 - 3 + PW <= W) {
+        // no column of the patch leaves the row: rows reflect, columns are 18 unaligned dwords (round 5; the byte loop
+        // below was half of this kernel's instructions)
+        for (int q = tid; q < PH * (PW / 4); q += 256) {
+            const int py = q / (PW / 4), c = q - py * (PW / 4);
+            int gy = y0 - 3 + py;
+            if (gy < 0) gy = -gy;
+            if (gy >= H) gy = 2 * (H - 1) - gy;
+            gy = min(max(gy, 0), H - 1);   // only for tile rows beyond the image (never written)
+            reinterpret_cast<uint32_t *>(s_img)[q] = load_u32_unaligned(img + (size_t)gy * W + (x0 - 3 + 4 * c));
+        }
+    } else {
+        for (int i = tid; i < PH * PW; i += 256) {
+            const int py = i / PW, px = i - py * PW;
+            int gx = x0 - 3 + px, gy = y0 - 3 + py;
+            if (gx < 0) gx = -gx;
+            if (gx >= W) gx = 2 * (W - 1) - gx;
+            if (gy < 0) gy = -gy;
+            if (gy >= H) gy = 2 * (H - 1) - gy;
+            gx = min(max(gx, 0), W - 1);   // only for tile pixels beyond the image (never written)
+            gy = min(max(gy, 0), H - 1);
+            s_img[i] = img[gy * W + gx];
+        }
     }
     __syncthreads();
     for (int i = tid; i < PH * (kTileW / 4); i += 256) {   // row pass: 4 outputs from 10 patch bytes
@@ -321,8 +534,8 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *img, int W, in
         *reinterpret_cast<uint2 *>(s_row + py * kTileW + 4 * q) = pack;
     }
     __syncthreads();
-    {   // column pass: thread = (row ty, column group q), 4 outputs
-        const int q = tid & 15, oy = tid >> 4;
+    for (int oy = tid >> 4; oy < kBlurH; oy += 16) {   // column pass: thread = (row oy, column group q), 4 outputs
+        const int q = tid & 15;
         uint32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -335,10 +548,19 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *img, int W, in
         }
         const int gx = x0 + 4 * q, gy = y0 + oy;
         if (gy < H) {
+            uint32_t o8[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o)
-                if (gx + o < W)
-                    out[gy * W + gx + o] = (uint8_t)((acc[o] + 32768u) >> 16);
+                o8[o] = (acc[o] + 32768u) >> 16;
+            if (gx + 3 < W) {   // four pixels as one (unaligned) dword store
+                const uint32_t v = o8[0] | (o8[1] << 8) | (o8[2] << 16) | (o8[3] << 24);
+                __builtin_memcpy(out + (size_t)gy * W + gx, &v, 4);
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (gx + o < W)
+                        out[gy * W + gx + o] = (uint8_t)o8[o];
+            }
         }
     }
 }
@@ -363,15 +585,49 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-// grid (n_levels, n_images, kDescSplit), 256 threads = 4 wavefronts, two keypoints per wavefront at a time.  The z
-// dimension splits the keypoints of one (level, image) over 16 workgroups (more waves in flight: 0.45 -> 0.39 ms per 64
-// frames).  Tried and dropped: lane = column with row-coalesced reads for the moments plus the blurred patch staged in LDS
-// -- bit-identical but 0.53 ms: the kernel is bound by the number of byte-load and index instructions, not by the
-// scattered addresses.
-constexpr int kDescSplit = 16;
+// LDS written by some lanes of a wavefront and read by others: the LDS queue of a wavefront is in order, what is needed is
+// that the COMPILER keeps the order
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// grid 8 x kDescSplit x n_levels x ceil(n_images / 8) (see the block order below), 256 threads = 4 wavefronts, ONE keypoint
+// per wavefront at a time (round 5).
+// History: half a wavefront per keypoint with byte loads straight from the level (moments: a loop of two dependent byte
+// loads per lane and step; tests: 16 byte loads per lane) took 0.39 ms per 64 frames against 0.08 of issue time -- it waited
+// for ~20 load round trips per keypoint.  Now a keypoint costs ONE round trip: its two windows are ten independent
+// unaligned dword loads per lane, issued for the NEXT keypoint before this one is computed, parked in LDS, and everything
+// else reads LDS or registers.
+//   image window    rows -15 .. 15, columns -16 .. 15 (pitch 32): lane r < 31 owns row r - 15; its 32 bytes against the row's
+//                   byte masks (|u| <= umax(|v|)) and (u + 16) weights through v_dot4_u32_u8 give S1 = sum p and
+//                   sum (u + 16) p; m10 = sum over rows of (sum (u + 16) p - 16 S1), m01 = sum of v S1: integers, any order
+//   blurred window  rows -18 .. 18, columns -18 .. 21 (pitch 40): a rotated test point has |coordinate| <= rint(13 sqrt 2
+//                   (1 + 2^-22)) = 18 (the pattern is clipped to +-13 per axis; edge_threshold >= 19 keeps the window
+//                   inside the level); lane l evaluates tests 4 l .. 4 l + 3, the nibbles meet through three shuffles and
+//                   the descriptor leaves as eight dwords
+constexpr int kDescSplit = 8;
+constexpr int kBR = 18, kBRows = 2 * kBR + 1, kBPitch = 40, kBWords = kBRows * kBPitch / 4;   // 370 dwords
+constexpr int kIRows = 31, kIPitch = 32, kIWords = kIRows * kIPitch / 4;                      // 248 dwords
+constexpr int kBLoads = (kBWords + 63) / 64, kILoads = (kIWords + 63) / 64;                   // 6 + 4 loads per lane
+constexpr int kDescImgOff = 1536, kDescWaveLds = 2560;
+static_assert(kBWords * 4 <= kDescImgOff && kDescImgOff + kIWords * 4 <= kDescWaveLds, "describe_kernel LDS layout");
 __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
 {
-    const int level = blockIdx.x, b = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescWaveLds];
+    // XCD-aware block order.  Workgroups go round-robin to the eight XCDs, each with its own L2, and a keypoint's windows
+    // touch 68 rows of 128-byte lines for 40 + 32 useful bytes each: with the blocks of one (image, level) spread over the
+    // XCDs every XCD pulled every line through the fabric (~1 GB per 64 frames -- what the kernel's time was), and with the
+    // level as the fastest block index one XCD had all of level 0, a fifth of the keypoints.  Now XCD x = block % 8 owns the
+    // images b = x (mod 8), and the blocks it receives walk z, then the level, then the image: the workgroups that share a
+    // level image run together on the XCD whose L2 holds it.
+    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
+    const int zsplit = seq % kDescSplit, level = (seq / kDescSplit) % d.n_levels;
+    const int b = (seq / (kDescSplit * d.n_levels)) * 8 + xcd;
+    if (b >= d.n_images)
+        return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const OrbLevel &L = d.level[level];
     const size_t slot0 = (size_t)b * d.n_levels;
@@ -379,40 +635,109 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
     for (int l = 0; l < level; ++l)
         offset += d.sel_count[slot0 + l];
     const int n = d.sel_count[slot0 + level];
-    if (level == d.n_levels - 1 && threadIdx.x == 0 && blockIdx.z == 0)
+    if (level == d.n_levels - 1 && threadIdx.x == 0 && zsplit == 0)
         d.n_kp[b] = offset + n;
     const int W = L.w;
     const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * L.w * L.h;
     const uint8_t *blr = d.blur + L.offset * d.n_images + (size_t)b * L.w * L.h;
     const Sel *sel = d.sel + (slot0 + level) * d.nfeatures;
     const float fs = L.scale;
-    // two keypoints per wavefront: lanes 0-31 take keypoint i0, lanes 32-63 keypoint i0 + 1
-    const int half = lane >> 5, hl = lane & 31;
-    for (int i0 = 8 * blockIdx.z + 2 * wave; i0 < n; i0 += 8 * kDescSplit) {
-        const bool active = i0 + half < n;
-        const int i = active ? i0 + half : n - 1;
-        const int x0 = sel[i].x, y0 = sel[i].y;
-        // intensity-centroid moments over the radius-15 disc: rows +-v, lanes 0-15 take u < 0, lanes 16-31 take u >= 0
-        int m10 = 0, m01 = 0;
-        {
-            const uint8_t *c = img + y0 * W + x0;
-            const int v = hl & 15, dmax = kUmax[v];
-            const int u0 = hl < 16 ? -dmax : 0, u1 = hl < 16 ? -1 : dmax;
-            if (v == 0) {
-                for (int u = u0; u <= u1; ++u)
-                    m10 += u * c[u];
-            } else {
-                int vs = 0;
-                for (int u = u0; u <= u1; ++u) {
-                    const int vp = c[u + v * W], vm = c[u - v * W];
-                    vs += vp - vm;
-                    m10 += u * (vp + vm);
-                }
-                m01 = v * vs;
+    uint8_t *sb = s_patch[wave], *si = sb + kDescImgOff;
+    // this lane's share of the two windows: offsets from the keypoint's pixel (the same for every keypoint of the level)
+    int boff[kBLoads], ioff[kILoads];
+#pragma unroll
+    for (int t = 0; t < kBLoads; ++t) {
+        const int q = min(lane + 64 * t, kBWords - 1), row = q / (kBPitch / 4), c = q - row * (kBPitch / 4);
+        boff[t] = (row - kBR) * W + 4 * c - kBR;
+    }
+#pragma unroll
+    for (int t = 0; t < kILoads; ++t) {
+        const int q = min(lane + 64 * t, kIWords - 1), row = q / (kIPitch / 4), c = q - row * (kIPitch / 4);
+        ioff[t] = (row - 15) * W + 4 * c - 16;
+    }
+    // moment weights of this lane's row (lanes 31 .. 63: all zero)
+    const int mrow = min(lane, kIRows - 1), mv = mrow - 15, um = kUmax[abs(mv)];
+    uint32_t wm[8], wu[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wm[j] = 0;
+        wu[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * j + k - 16;
+            if (abs(u) <= um && lane < kIRows) {
+                wm[j] |= 1u << (8 * k);
+                wu[j] |= (uint32_t)(u + 16) << (8 * k);
             }
         }
+    }
+    // this lane's four tests
+    float pat[16];
+    {
+        const uint4 q = *reinterpret_cast<const uint4 *>(d.pattern + 16 * lane);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int s = 1; s < 32; s <<= 1) {   // integer sums inside each half: any order gives the same result
+        for (int k = 0; k < 16; ++k)
+            pat[k] = (float)(int8_t)(w[k >> 2] >> (8 * (k & 3)));
+    }
+    // three keypoints in flight per wavefront: this one (windows in LDS), the next one (its windows travelling into
+    // registers) and the one after (its record travelling: the windows' addresses depend on it, and a wait for it at the
+    // head of the window loads would expose one load round trip per keypoint)
+    const int step = 4 * kDescSplit;
+    int i = 4 * zsplit + wave;
+    uint32_t nb[kBLoads], ni[kILoads];
+    Sel cur{}, nxt{};
+    auto fetch = [&](const Sel &k) {
+        const uint8_t *cb = blr + k.y * W + k.x, *ci = img + k.y * W + k.x;
+#pragma unroll
+        for (int t = 0; t < kBLoads; ++t)
+            nb[t] = load_u32_unaligned(cb + boff[t]);
+#pragma unroll
+        for (int t = 0; t < kILoads; ++t)
+            ni[t] = load_u32_unaligned(ci + ioff[t]);
+    };
+    if (i < n) {
+        cur = sel[i];
+        fetch(cur);
+        if (i + step < n)
+            nxt = sel[i + step];
+    }
+    while (i < n) {
+        const int x0 = cur.x, y0 = cur.y;
+        const float harris = cur.harris;
+#pragma unroll
+        for (int t = 0; t < kBLoads; ++t)
+            if (lane + 64 * t < kBWords)
+                reinterpret_cast<uint32_t *>(sb)[lane + 64 * t] = nb[t];
+#pragma unroll
+        for (int t = 0; t < kILoads; ++t)
+            if (lane + 64 * t < kIWords)
+                reinterpret_cast<uint32_t *>(si)[lane + 64 * t] = ni[t];
+        wave_lds_sync();
+        const int inext = i + step;
+        if (inext < n) {
+            cur = nxt;
+            fetch(cur);   // in flight while this keypoint is computed
+            if (inext + step < n)
+                nxt = sel[inext + step];
+        }
+        // intensity-centroid moments over the radius-15 disc
+        int m10, m01;
+        {
+            const uint4 lo = *reinterpret_cast<const uint4 *>(si + mrow * kIPitch);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(si + mrow * kIPitch + 16);
+            const uint32_t p[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t s1 = 0, su = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s1 = __builtin_amdgcn_udot4(p[j], wm[j], s1, false);
+                su = __builtin_amdgcn_udot4(p[j], wu[j], su, false);
+            }
+            m10 = (int)su - 16 * (int)s1;
+            m01 = mv * (int)s1;
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {   // integer sums: any order gives the same result
             m10 += __shfl_xor(m10, s, 64);
             m01 += __shfl_xor(m01, s, 64);
         }
@@ -424,29 +749,33 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
             ca = f10 / hh;
             sa = f01 / hh;
         }
-        if (!active)
-            continue;
         const size_t o = (size_t)b * d.nfeatures + offset + i;
         {
-            const uint8_t *ctr = blr + y0 * W + x0;
+            const uint8_t *ctr = sb + kBR * kBPitch + kBR;
             unsigned v = 0;
 #pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const int8_t *q = d.pattern + 4 * (8 * hl + bit);
-                const float x1 = (float)q[0], y1 = (float)q[1], x2 = (float)q[2], y2 = (float)q[3];
+            for (int bit = 0; bit < 4; ++bit) {
+                const float x1 = pat[4 * bit], y1 = pat[4 * bit + 1], x2 = pat[4 * bit + 2], y2 = pat[4 * bit + 3];
                 const int ix1 = (int)rintf(x1 * ca - y1 * sa), iy1 = (int)rintf(x1 * sa + y1 * ca);
                 const int ix2 = (int)rintf(x2 * ca - y2 * sa), iy2 = (int)rintf(x2 * sa + y2 * ca);
-                v |= (unsigned)(ctr[iy1 * W + ix1] < ctr[iy2 * W + ix2]) << bit;
+                v |= (unsigned)(ctr[iy1 * kBPitch + ix1] < ctr[iy2 * kBPitch + ix2]) << bit;
             }
-            d.desc[o * 32 + hl] = (uint8_t)v;
+            // nibble of lane l = bits 4 (l & 1) .. of byte l >> 1; bytes 4 g .. 4 g + 3 (g = l >> 3) make dword g
+            v <<= 4 * (lane & 1);
+            v |= __shfl_xor(v, 1, 64);
+            v <<= 8 * ((lane >> 1) & 3);
+            v |= __shfl_xor(v, 2, 64);
+            v |= __shfl_xor(v, 4, 64);
+            if ((lane & 7) == 0)
+                reinterpret_cast<uint32_t *>(d.desc + o * 32)[lane >> 3] = v;
         }
-        if (hl == 0) {
+        if (lane == 0) {
             mvs_keypoint k;
             k.x = (float)x0 * fs;
             k.y = (float)y0 * fs;
             k.size = 31.0f * fs;
             k.angle = fast_atan2_deg(f01, f10);
-            k.response = sel[i].harris;
+            k.response = harris;
             k.octave = level;
             k.class_id = -1;
             d.kp[o] = k;
@@ -457,6 +786,8 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
             if (d.kp_oct)
                 d.kp_oct[o] = (uint8_t)level;
         }
+        wave_lds_sync();   // every read of the windows before the next keypoint's are written
+        i = inext;
     }
 }
 
@@ -487,29 +818,44 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
     const int slots = B * d.n_levels;
     hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.cand_count, slots, d.overflow);
     hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.sel_count, slots, d.overflow);
+    // the pyramid first (level l from level l - 1), then ONE launch each for FAST + NMS and the blur over the tiles of every
+    // level (round 5: the small levels' launches no longer wait for each other)
     const dim3 blk(32, 8);
+    OrbGrid g{};
+    int max_keep = 0;
+    bool live = true;
     for (int l = 0; l < d.n_levels; ++l) {
         const OrbLevel &L = d.level[l];
-        if (L.w < 1 || L.h < 1)
-            break;
-        uint8_t *img = d.pyr + L.offset * B;
+        g.fast_start[l + 1] = g.fast_start[l];
+        g.blur_start[l + 1] = g.blur_start[l];
+        g.fast_tx[l] = g.blur_tx[l] = 1;
+        live = live && L.w >= 1 && L.h >= 1;
+        if (!live)
+            continue;   // (every later level is empty too: the old per-level loop stopped here)
         if (l > 0) {
             const OrbLevel &Pv = d.level[l - 1];
-            const dim3 grid((L.w + 31) / 32, (L.h + 7) / 8, B);
-            hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, img, L.w, L.h,
-                               d.resize_tab + L.tab_offset, d.resize_tab + L.tab_offset + L.w);
+            const dim3 grid((L.w + 127) / 128, (L.h + 7) / 8, B);   // four pixels per thread
+            hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, d.pyr + L.offset * B, L.w,
+                               L.h, d.resize_tab + L.tab_offset, d.resize_tab + L.tab_offset + L.w);
         }
         if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
             continue;
-        const dim3 gin((L.w - 2 * d.edge + kTileW - 1) / kTileW, (L.h - 2 * d.edge + kTileH - 1) / kTileH, B);
-        hipLaunchKernelGGL(fast_nms_kernel, gin, dim3(256), 0, stream, img, L.w, L.h, d.fast_threshold, d.edge, d.cand_keys,
-                           d.cand_count, d.cand_cap, l, d.n_levels);
-        const dim3 gb((L.w + kTileW - 1) / kTileW, (L.h + kTileH - 1) / kTileH, B);
-        hipLaunchKernelGGL(blur_kernel, gb, dim3(256), 0, stream, img, L.w, L.h, d.blur + L.offset * B);
+        g.fast_tx[l] = (L.w - 2 * d.edge + kTileW - 1) / kTileW;
+        g.fast_start[l + 1] += g.fast_tx[l] * ((L.h - 2 * d.edge + kTileH - 1) / kTileH);
+        g.blur_tx[l] = (L.w + kTileW - 1) / kTileW;
+        g.blur_start[l + 1] += g.blur_tx[l] * ((L.h + kBlurH - 1) / kBlurH);
+        max_keep = std::max(max_keep, L.n_keep);
     }
-    hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), (size_t)d.cand_cap * sizeof(uint64_t), stream,
+    if (g.fast_start[d.n_levels] > 0) {
+        hipLaunchKernelGGL(fast_nms_kernel, dim3(g.fast_start[d.n_levels], B), dim3(256), 0, stream, d, g);
+        hipLaunchKernelGGL(blur_kernel, dim3(g.blur_start[d.n_levels], B), dim3(256), 0, stream, d, g);
+    }
+    size_t sel_keys = 1;
+    while (sel_keys < (size_t)std::min(2 * (long long)max_keep, (long long)d.cand_cap))
+        sel_keys <<= 1;
+    hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), sel_keys * sizeof(uint64_t), stream,
                        d);   // LDS limit raised in orb_prepare()
-    hipLaunchKernelGGL(describe_kernel, dim3(d.n_levels, B, kDescSplit), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(describe_kernel, dim3(8 * kDescSplit * d.n_levels * ((B + 7) / 8)), dim3(256), 0, stream, d);
 }
 
 }  // namespace mvs
