@@ -114,13 +114,17 @@ struct OrbGrid {
     int blur_start[kOrbMaxLevels + 1], blur_tx[kOrbMaxLevels];
 };
 
-// every arc of 9 contiguous circle pixels contains one pixel of each antipodal pair: if both pixels of a pair are within
-// the threshold of the centre there is no corner (most pixels of a real image leave here)
+// An arc of 9 contiguous ring pixels contains two ADJACENT compass points (ring positions 0, 4, 8, 12), so a corner at
+// threshold t has two adjacent compass points both brighter than centre + t or both darker than centre - t.  (Round 5; the
+// unsigned form of rounds 1-4 -- one pixel of each antipodal pair differs by more than t -- let twice as many pixels
+// through on a textured image.)
 __device__ __forceinline__ bool fast_maybe(const uint8_t *c, int P, int threshold)
 {
     const int ctr = c[0];
-    const int d0 = (int)c[3 * P] - ctr, d8 = (int)c[-3 * P] - ctr, d4 = (int)c[3] - ctr, d12 = (int)c[-3] - ctr;
-    return (max(abs(d0), abs(d8)) > threshold) && (max(abs(d4), abs(d12)) > threshold);
+    const int d0 = (int)c[3 * P] - ctr, d4 = (int)c[3] - ctr, d8 = (int)c[-3 * P] - ctr, d12 = (int)c[-3] - ctr;
+    const int brighter = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
+    const int darker = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+    return brighter > threshold || darker < -threshold;
 }
 
 // FAST-9/16 score of the pixel at LDS position c (row pitch P): the largest threshold at which it is still a corner,
@@ -166,7 +170,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *c, int P, int thres
 // and paid the full score for all 64 lanes.  Now the passing pixels are compacted (ballot + one LDS atomic per wavefront)
 // and the full score runs over the list.
 constexpr int kTileW = 64, kTileH = 16, kBlurH = 32;
-__global__ __launch_bounds__(256) void fast_nms_kernel(OrbDev d, OrbGrid g)
+__global__ __launch_bounds__(256) void fast_nms_kernel(OrbDev d, OrbGrid g, int tile_first, int n_tiles)
 {
     constexpr int PW = kTileW + 8, PH = kTileH + 8;      // image patch: +-4 (NMS 1 + circle 3)
     constexpr int SW = kTileW + 2, SH = kTileH + 2;      // score patch: +-1
@@ -176,13 +180,19 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(OrbDev d, OrbGrid g)
     __shared__ int s_n;
     __shared__ int wave_off[4];
     __shared__ int tile_base;
+    // block order: XCD x = block % 8 owns the images b = x (mod 8) and walks their tiles in order -- neighbouring tiles
+    // share halo rows and 128-byte lines, and an XCD's L2 sees them together
+    // (a launch covers tiles [tile_first, tile_first + n_tiles) of the flattened list: launch_orb)
+    const int seq = blockIdx.x >> 3, tile = tile_first + seq % n_tiles;
+    const int b = (seq / n_tiles) * 8 + (blockIdx.x & 7), tid = threadIdx.x;
+    if (b >= d.n_images)
+        return;
     int level = 0;
-    while (level + 1 < d.n_levels && (int)blockIdx.x >= g.fast_start[level + 1])
+    while (level + 1 < d.n_levels && tile >= g.fast_start[level + 1])
         ++level;
     const OrbLevel &L = d.level[level];
     const int W = L.w, H = L.h, edge = d.edge, threshold = d.fast_threshold;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int t = (int)blockIdx.x - g.fast_start[level];
+    const int t = tile - g.fast_start[level];
     const int tyb = t / g.fast_tx[level], txb = t - tyb * g.fast_tx[level];
     const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * W * H;
     const int x0 = edge + txb * kTileW, y0 = edge + tyb * kTileH;   // first output pixel of the tile
@@ -467,21 +477,25 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
 // 37 % more than the tile): rows then columns through LDS (Q8 kernel, BORDER_REFLECT_101, u16 row sums).
 // Every work item produces 4 adjacent pixels from dword LDS reads (3 per row item, 14 per column item); byte-wide LDS
 // reads made the first LDS version slower than two global passes.
-__global__ __launch_bounds__(256) void blur_kernel(OrbDev d, OrbGrid g)
+__global__ __launch_bounds__(256) void blur_kernel(OrbDev d, OrbGrid g, int tile_first, int n_tiles)
 {
     constexpr int PW = kTileW + 8, PH = kBlurH + 6;   // 72-byte pitch: output column 4k starts at a dword of the patch
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PH * PW];
     __shared__ __attribute__((aligned(16))) uint16_t s_row[PH * kTileW];
     const int tid = threadIdx.x;
+    const int seq = blockIdx.x >> 3, tile = tile_first + seq % n_tiles;   // (block order and tile range: fast_nms_kernel)
+    const int b = (seq / n_tiles) * 8 + (blockIdx.x & 7);
+    if (b >= d.n_images)
+        return;
     int level = 0;
-    while (level + 1 < d.n_levels && (int)blockIdx.x >= g.blur_start[level + 1])
+    while (level + 1 < d.n_levels && tile >= g.blur_start[level + 1])
         ++level;
     const OrbLevel &L = d.level[level];
     const int W = L.w, H = L.h;
-    const int t = (int)blockIdx.x - g.blur_start[level];
+    const int t = tile - g.blur_start[level];
     const int tyb = t / g.blur_tx[level], txb = t - tyb * g.blur_tx[level];
-    const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)blockIdx.y * W * H;
-    uint8_t *out = d.blur + L.offset * d.n_images + (size_t)blockIdx.y * W * H;
+    const uint8_t *img = d.pyr + L.offset * d.n_images + (size_t)b * W * H;
+    uint8_t *out = d.blur + L.offset * d.n_images + (size_t)b * W * H;
     const int x0 = txb * kTileW, y0 = tyb * kBlurH;
     if (x0 >= 3 && x0 - 3 + PW <= W) {
         // no column of the patch leaves the row: rows reflect, columns are 18 unaligned dwords (round 5; the byte loop
@@ -791,11 +805,13 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
     }
 }
 
-__global__ void orb_clear_kernel(int32_t *count, int n, int32_t *overflow)
+__global__ void orb_clear_kernel(int32_t *count_a, int32_t *count_b, int n, int32_t *overflow)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        count[i] = 0;
+    if (i < n) {
+        count_a[i] = 0;
+        count_b[i] = 0;
+    }
     if (i == 0)
         *overflow = 0;
 }
@@ -810,35 +826,27 @@ hipError_t orb_prepare(int cand_cap)
                                (int)((size_t)cand_cap * sizeof(uint64_t)));
 }
 
+// Measured and not kept: level 0's FAST + blur on a second stream beside the pyramid chain (a fork inside the captured graph):
+// 110.6 k against 111.2 k images/s -- the graph's launches already follow each other without gaps.
 void launch_orb(const OrbDev &d, hipStream_t stream)
 {
     const int B = d.n_images;
     if (B <= 0)
         return;
     const int slots = B * d.n_levels;
-    hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.cand_count, slots, d.overflow);
-    hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.sel_count, slots, d.overflow);
-    // the pyramid first (level l from level l - 1), then ONE launch each for FAST + NMS and the blur over the tiles of every
-    // level (round 5: the small levels' launches no longer wait for each other)
-    const dim3 blk(32, 8);
+    hipLaunchKernelGGL(orb_clear_kernel, dim3((slots + 255) / 256), dim3(256), 0, stream, d.cand_count, d.sel_count, slots,
+                       d.overflow);
+    // tile lists of every level first (host arithmetic only)
     OrbGrid g{};
-    int max_keep = 0;
-    bool live = true;
+    int max_keep = 0, n_live = 0;
     for (int l = 0; l < d.n_levels; ++l) {
         const OrbLevel &L = d.level[l];
         g.fast_start[l + 1] = g.fast_start[l];
         g.blur_start[l + 1] = g.blur_start[l];
         g.fast_tx[l] = g.blur_tx[l] = 1;
-        live = live && L.w >= 1 && L.h >= 1;
-        if (!live)
-            continue;   // (every later level is empty too: the old per-level loop stopped here)
-        if (l > 0) {
-            const OrbLevel &Pv = d.level[l - 1];
-            const dim3 grid((L.w + 127) / 128, (L.h + 7) / 8, B);   // four pixels per thread
-            hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, d.pyr + L.offset * B, L.w,
-                               L.h, d.resize_tab + L.tab_offset, d.resize_tab + L.tab_offset + L.w);
-        }
-        if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
+        if (n_live == l && L.w >= 1 && L.h >= 1)
+            n_live = l + 1;   // (levels behind an empty one are empty too)
+        if (n_live <= l || L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
             continue;
         g.fast_tx[l] = (L.w - 2 * d.edge + kTileW - 1) / kTileW;
         g.fast_start[l + 1] += g.fast_tx[l] * ((L.h - 2 * d.edge + kTileH - 1) / kTileH);
@@ -846,10 +854,24 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
         g.blur_start[l + 1] += g.blur_tx[l] * ((L.h + kBlurH - 1) / kBlurH);
         max_keep = std::max(max_keep, L.n_keep);
     }
-    if (g.fast_start[d.n_levels] > 0) {
-        hipLaunchKernelGGL(fast_nms_kernel, dim3(g.fast_start[d.n_levels], B), dim3(256), 0, stream, d, g);
-        hipLaunchKernelGGL(blur_kernel, dim3(g.blur_start[d.n_levels], B), dim3(256), 0, stream, d, g);
+    const int b8 = (B + 7) / 8;
+    auto detect = [&](int first_level, int end_level, hipStream_t st) {   // FAST + NMS and blur of levels [first, end)
+        const int f0 = g.fast_start[first_level], fn = g.fast_start[end_level] - f0;
+        const int b0 = g.blur_start[first_level], bn = g.blur_start[end_level] - b0;
+        if (fn > 0)
+            hipLaunchKernelGGL(fast_nms_kernel, dim3(8 * fn * b8), dim3(256), 0, st, d, g, f0, fn);
+        if (bn > 0)
+            hipLaunchKernelGGL(blur_kernel, dim3(8 * bn * b8), dim3(256), 0, st, d, g, b0, bn);
+    };
+    // the pyramid (level l from level l - 1), then ONE launch each for FAST + NMS and the blur over the tiles of every level
+    const dim3 blk(32, 8);
+    for (int l = 1; l < n_live; ++l) {
+        const OrbLevel &L = d.level[l], &Pv = d.level[l - 1];
+        const dim3 grid((L.w + 127) / 128, (L.h + 7) / 8, B);   // four pixels per thread
+        hipLaunchKernelGGL(resize_kernel, grid, blk, 0, stream, d.pyr + Pv.offset * B, Pv.w, Pv.h, d.pyr + L.offset * B, L.w,
+                           L.h, d.resize_tab + L.tab_offset, d.resize_tab + L.tab_offset + L.w);
     }
+    detect(0, d.n_levels, stream);
     size_t sel_keys = 1;
     while (sel_keys < (size_t)std::min(2 * (long long)max_keep, (long long)d.cand_cap))
         sel_keys <<= 1;

@@ -273,6 +273,46 @@ def test_gpu_extract_against_golden_and_argument_errors(ctx):
     assert int(again["n"][0]) == n
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,prm", [
+    ((257, 333), dict(nfeatures=3000, nlevels=8, fast_threshold=7, edge_threshold=19)),
+    ((203, 415), dict(nfeatures=700, nlevels=6, fast_threshold=20, edge_threshold=31)),
+    ((480, 640), dict(nfeatures=1200, nlevels=8, fast_threshold=40, edge_threshold=25)),
+])
+def test_gpu_extract_batch_shapes_and_ties(ctx, shape, prm):
+    """Round 5 kernels: eleven images per call (the block orders hand image b to XCD b mod 8: a count that is not a
+    multiple of eight leaves blocks without an image), widths that are not multiples of four (unaligned dword windows
+    in FAST / blur / resize / describe, dword stores that straddle rows), levels on either side of twice the edge
+    margin, blur tiles on the border and inside, and images whose corners tie in FAST score by the thousand -- the
+    radix select of retainBest(2 n_l) then has to walk the y and x bytes of the keys."""
+    from mvslam_amd import capi
+
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    imgs = [textured(900 + s, h, w) for s in range(6)]
+    yy, xx = np.mgrid[0:h, 0:w]
+    c = 5 if h < 300 else 9     # (a level holds at most 16384 corners: MVS_ERR_CAPACITY, tested elsewhere)
+    imgs.append((((yy // c + xx // c) & 1) * 255).astype(np.uint8))                    # checkerboard: every corner ties
+    imgs.append((((yy // 9 + xx // 7) & 1) * 200 + 20).astype(np.uint8))
+    imgs.append(np.full((h, w), 77, np.uint8))                                         # nothing to find
+    imgs.append(rng.integers(0, 256 if h < 300 else 160, size=(h, w)).astype(np.uint8))   # noise: ~11 000 corners at level 0
+    c = 3 if h < 300 else 8
+    imgs.append(np.kron(rng.integers(0, 2, size=(h // c + 1, w // c + 1)).astype(np.uint8) * 255,
+                        np.ones((c, c), np.uint8))[:h, :w])                            # binary blocks
+    imgs = np.stack(imgs)
+    assert len(imgs) == 11
+    got = ctx.extract(imgs, capi.default_orb_params(**prm))
+    total = 0
+    for i in range(len(imgs)):
+        want = o.orb_extract(imgs[i], o.make_orb_params(**prm))
+        n = int(got["n"][i])
+        assert n == len(want["kp"]), i
+        assert np.array_equal(got["kp"][i][:n], want["kp"].astype(capi.KEYPOINT_DTYPE)), i
+        assert np.array_equal(got["desc"][i][:n], want["desc"]), i
+        total += n
+    assert got["n"][8] == 0 and total > 3 * prm["nfeatures"]
+
+
 # (hypotheses, sampler, max_error_sq [0 = the reference formula 5e-2 / K00 / K11, sfm-solve.cpp:311], max_dist)
 TSUKUBA_PARAMS = {
     "build": (2000, 1, 1e-3, 50.0),                 # the build's sampler, a wide matcher gate
