@@ -163,7 +163,7 @@ mvs_status mvs_ransac_fundamental(mvs_ctx *ctx, const double *p1_xy, const doubl
  * The reference forwards to cv::solvePnPRansac(SOLVEPNP_P3P, 100, 0.05, 0.95); this is the build's own P3P-RANSAC
  * (Grunert P3P on 3 points + 1 disambiguation point, reprojection-error inlier count over all points, first
  * hypothesis with the most inliers, no refit).  pose = camera in world, i.e.
- * SE3(R_world_to_camera, t).inverse() (pnp-solve.cpp:99-101).  n >= 7 (PNP_MIN_POINT_COUNT, :13) and n <= 2048.
+ * SE3(R_world_to_camera, t).inverse() (pnp-solve.cpp:99-101).  n >= 7 (PNP_MIN_POINT_COUNT, :13) and n <= 4096 (the keypoint capacity).
  * inlier_idx: capacity n, ascending.  returns MVS_OK (true) / MVS_NO_MODEL (false). */
 typedef struct mvs_pnp_params {
     int32_t num_hypotheses; /* reference: iterationsCount = 100 (pnp-solve.cpp:47) */

@@ -124,7 +124,7 @@ struct RunParams {
 };
 
 // ---- pnp_solve (row f1) ----------------------------------------------------------------------------
-constexpr int kPnpMaxPoints = 2048;  // LDS-staged point stream: 48 B per point
+constexpr int kPnpMaxPoints = kMaxKp;  // = the keypoint capacity (round 5: the point stream is chunked through LDS; 2048 before)
 
 struct PnpRec {  // best hypothesis of one RANSAC workgroup
     int32_t count;

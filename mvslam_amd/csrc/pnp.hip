@@ -236,10 +236,18 @@ __global__ __launch_bounds__(256) void pnp_prep_kernel(PnpDev p)
     p.fb[3 * o + 2] = 1.0 / nn;
 }
 
-// grid (ceil(H/256), Q), block 256
+constexpr int kPnpChunk = 768;
+// grid (ceil(H/256), Q), block 256.
+// Round 5: (1) the point stream goes through LDS in chunks of 768 points (36 KB: four workgroups per CU) -- the 2048-point
+// array of rounds 2-4 (96 KB) left ONE workgroup per CU, four rounds of workgroups for the sequence's 998 tracks of ~570
+// points; (2) a block with fewer than 129 live
+// hypotheses -- the reference's iterationsCount is 100 -- has idle wavefronts: they take the same hypotheses and a share of the
+// POINTS (wavefront w: hypothesis group w mod groups, points part, part + split, ...), and the integer counts are added up
+// in LDS.  Every hypothesis is still solved and scored by the same operations on the same numbers: same counts, same winner.
 __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
 {
-    __shared__ __attribute__((aligned(16))) double s_pts[kPnpMaxPoints * 6];  // X0 X1 X2 x y pad
+    __shared__ __attribute__((aligned(16))) double s_pts[kPnpChunk * 6];  // a chunk of the point stream: X0 X1 X2 x y pad
+    __shared__ int s_part[4][64];
     __shared__ int s_cnt[4];
     __shared__ uint32_t s_hyp[4];
     __shared__ uint32_t s_win;
@@ -256,18 +264,14 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
     const double *X = p.X + 3 * o, *xy = p.xy + 2 * o, *fb = p.fb + 3 * o;
     const double *K = p.K + (size_t)q * 9;
     const double fx2 = K[0] * K[0], fy2 = K[4] * K[4], thr2 = p.thr2;
-    for (int i = tid; i < n; i += 256) {
-        s_pts[6 * i + 0] = X[3 * i];
-        s_pts[6 * i + 1] = X[3 * i + 1];
-        s_pts[6 * i + 2] = X[3 * i + 2];
-        s_pts[6 * i + 3] = xy[2 * i];
-        s_pts[6 * i + 4] = xy[2 * i + 1];
-        s_pts[6 * i + 5] = 0.0;
-    }
-    __syncthreads();
-    const uint32_t h = blockIdx.x * 256 + tid;
-    const bool live = h < (uint32_t)p.num_hypotheses;
-    const uint32_t hh = live ? h : (uint32_t)(p.num_hypotheses - 1);
+    // hypotheses of this block: groups of 64 (one per lane); 4 / groups wavefronts share a group's points
+    const int lane = tid & 63, wave = tid >> 6;
+    const int in_block = min(p.num_hypotheses - (int)blockIdx.x * 256, 256);
+    const int groups = (in_block + 63) >> 6, split = 4 / groups;          // 1, 2, 3, 4 groups -> 4, 2, 1, 1 parts
+    const int grp = wave % groups, part = wave / groups;                   // (3 groups: wavefront 3 has part 1 >= split: idle)
+    const uint32_t h = blockIdx.x * 256 + grp * 64 + lane;
+    const bool live = h < (uint32_t)p.num_hypotheses && part < split;
+    const uint32_t hh = h < (uint32_t)p.num_hypotheses ? h : (uint32_t)(p.num_hypotheses - 1);
     const uint64_t seed = p.seed + (p.gidx ? (uint64_t)p.gidx[q] : 0ull);
     int idx[4];
     sample4(seed, hh, n, p.sampler, idx);
@@ -285,15 +289,36 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
     double R[9], t[3];
     const bool have = p3p_select(f3, X3, X4, xy[2 * idx[3]], xy[2 * idx[3] + 1], fx2, fy2, thr2, R, t);
     int cnt = 0;
-    if (__any(have)) {
+    const bool score = part < split && __any(have);
+    for (int c0 = 0; c0 < n; c0 += kPnpChunk) {   // the point stream in LDS chunks (n is the same for the whole block)
+        const int cn = min(n - c0, kPnpChunk);
+        __syncthreads();
+        for (int i = tid; i < cn; i += 256) {
+            s_pts[6 * i + 0] = X[3 * (c0 + i)];
+            s_pts[6 * i + 1] = X[3 * (c0 + i) + 1];
+            s_pts[6 * i + 2] = X[3 * (c0 + i) + 2];
+            s_pts[6 * i + 3] = xy[2 * (c0 + i)];
+            s_pts[6 * i + 4] = xy[2 * (c0 + i) + 1];
+            s_pts[6 * i + 5] = 0.0;
+        }
+        __syncthreads();
+        if (score) {
 #pragma unroll 4
-        for (int i = 0; i < n; ++i) {
-            const double *pt = &s_pts[6 * i];  // wave-uniform address: LDS broadcast
-            double lhs, rhs;
-            cnt += pnp_inlier(R, t, pt[0], pt[1], pt[2], pt[3], pt[4], fx2, fy2, thr2, lhs, rhs) ? 1 : 0;
+            for (int i = part; i < cn; i += split) {
+                const double *pt = &s_pts[6 * i];  // wave-uniform address: LDS broadcast
+                double lhs, rhs;
+                cnt += pnp_inlier(R, t, pt[0], pt[1], pt[2], pt[3], pt[4], fx2, fy2, thr2, lhs, rhs) ? 1 : 0;
+            }
         }
     }
-    if (!have || !live)
+    s_part[wave][lane] = cnt;
+    __syncthreads();
+    if (part == 0) {
+        cnt = 0;
+        for (int k = 0; k < split; ++k)
+            cnt += s_part[grp + k * groups][lane];
+    }
+    if (!have || !live || part != 0)
         cnt = -1;
     // workgroup arg-best: most inliers, then the smaller hypothesis id (first maximum of the sequential loop)
     int bc = cnt;
@@ -307,9 +332,9 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
             bh = oh;
         }
     }
-    if ((tid & 63) == 0) {
-        s_cnt[tid >> 6] = bc;
-        s_hyp[tid >> 6] = bh;
+    if (lane == 0) {
+        s_cnt[wave] = bc;
+        s_hyp[wave] = bh;
     }
     __syncthreads();
     if (tid == 0) {
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(256) void pnp_ransac_kernel(PnpDev p)
         rec->hyp = bh;
     }
     __syncthreads();
-    if (h == s_win) {
+    if (h == s_win && part == 0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i)
             rec->R[i] = R[i];

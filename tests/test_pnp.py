@@ -116,7 +116,12 @@ def test_gpu_pnp_solve_cube(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,H,noise,n_out", [(7, 64, 0.0, 0), (50, 100, 0.01, 10), (300, 1000, 0.01, 60),
-                                               (2048, 4096, 0.02, 500), (400, 257, 0.5, 100)])
+                                               (2048, 4096, 0.02, 500), (400, 257, 0.5, 100),
+                                               # round 5: the point stream goes through LDS in 768-point chunks and a block
+                                               # with <= 128 hypotheses splits the points over its wavefronts (1, 2, 3, 4
+                                               # hypothesis groups -> 4, 2, 1, 1 parts); 4096 = the keypoint capacity
+                                               (769, 64, 0.01, 100), (1537, 100, 0.01, 300), (4096, 129, 0.02, 900),
+                                               (3000, 200, 0.02, 700), (900, 40, 0.01, 0)])
 def test_gpu_pnp_matches_oracle_bit_for_bit(ctx, n, H, noise, n_out):
     """inlier indices and the winning hypothesis bit-exact; pose bitwise (the path uses only + - * / sqrt)."""
     from mvslam_amd import capi
