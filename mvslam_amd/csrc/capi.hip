@@ -3084,13 +3084,19 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     d.kp_xy = d_kp_xy_ext;
     d.kp_oct = d_kp_oct_ext;
     hipStream_t s = ctx->stream;
+    // the test pattern and the resize tables depend on (size, parameters, workspace) only: a call with the key of the captured
+    // graph finds them in the workspace (round 5: they were uploaded, and the stream synchronised for them, on every call)
+    const bool same_key = ctx->orb_graph_valid && std::memcmp(&ctx->orb_graph_key, &d, sizeof(d)) == 0;
     int8_t pat[1024];
-    orb_pattern_host(pat);
-    HIP_TRY(ctx, hipMemcpyAsync(base + o_pat, pat, sizeof(pat), hipMemcpyHostToDevice, s));
-    if (!tab.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(base + o_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+    if (!same_key) {
+        orb_pattern_host(pat);
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_pat, pat, sizeof(pat), hipMemcpyHostToDevice, s));
+        if (!tab.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(base + o_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d.pyr, images, (size_t)w * h * B, hipMemcpyHostToDevice, s));  // level 0 = the input
-    HIP_TRY(ctx, sync_stream(ctx));   // `pat` and `tab` live on this frame
+    if (!same_key)
+        HIP_TRY(ctx, sync_stream(ctx));   // `pat` and `tab` live on this frame
 #ifdef MVS_DEBUG_HOOKS
     static const bool no_graph = std::getenv("MVS_NO_GRAPH") != nullptr;   // A/B switch for tools/extract_bench.py (diagnostics build only)
 #else
