@@ -436,6 +436,19 @@ def bench_extract(capi, np, dev, args, images=64, width=640, height=480):
     for _ in range(3):
         ctx.extract(imgs, prm)
     host_ms = (time.perf_counter() - t0) * 1e3 / 3
+    # the reference's own call pattern: ONE frame per VisualFeature::extract (vision/visual-feature.cpp:40-49), pinned host
+    # buffers in and out, wall clock per mvs_extract call
+    one = capi.pinned_empty((1, height, width), np.uint8)
+    one[...] = imgs[:1]
+    one_out = dict(kp=capi.pinned_empty((1, args.kp), capi.KEYPOINT_DTYPE), desc=capi.pinned_empty((1, args.kp, 32), np.uint8),
+                   n=capi.pinned_empty((1,), np.int32))
+    for _ in range(3):
+        ctx.extract(one, prm, out=one_out)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        ctx.extract(one, prm, out=one_out)
+    single_ms = (time.perf_counter() - t0) * 1e3 / 50
+    single_kernel_ms = ctx.extract_time(steps=20)
     ctx.close()
     pyr = sum(round(width / 1.2 ** l) * round(height / 1.2 ** l) for l in range(8))
     alg_bytes = 9.0 * pyr * images   # u8 pixels, ~9 passes over the 3.16 x pyramid
@@ -443,6 +456,7 @@ def bench_extract(capi, np, dev, args, images=64, width=640, height=480):
            "value": round(images / (kernel_ms * 1e-3), 1), "unit": "images/s", "kernel_ms_per_batch": round(kernel_ms, 4),
            "images": images, "mean_keypoints": float(out_k["n"].mean()),
            "host_buffers_ms_per_batch": round(host_ms, 3), "host_buffers_images_per_s": round(images / (host_ms * 1e-3), 1),
+           "single_image_ms": round(single_ms, 4), "single_image_kernel_ms": round(single_kernel_ms, 4),
            "roofline": {"bound": "hbm", "kernel": "resize + fast_nms + select + blur + describe (one extraction)",
                         "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -540,6 +554,7 @@ def compact_line(out, detail_path=None):
     line["sequence_frames_per_s"] = _get(out, "sequence", "value")
     line["refine_pairs_per_s"] = _get(out, "refine", "value")
     line["extract_images_per_s"] = _get(out, "extract", "value")
+    line["extract_single_image_ms"] = _get(out, "extract", "single_image_ms")
     line["sensitivity_min_pairs_per_s"] = _get(out, "sensitivity", "min_pairs_per_s")
     line["valid_pairs"] = _get(out, "work", "valid_pairs")
     line["max_sweeps9"] = _get(out, "roofline", "work", "max_sweeps9")

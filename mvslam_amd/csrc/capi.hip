@@ -3026,26 +3026,32 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     size_t off = 0;
     const size_t o_pyr = off; off = up(off + T * B);
     const size_t o_blur = off; off = up(off + T * B);
-    // resize tables: for every level >= 1, {source index, 11-bit weight} per destination column, then per row
-    std::vector<int2> tab;
+    // resize tables: for every level >= 1, {source index, 11-bit weight} per destination column, then per row.  Their layout
+    // is part of the key, their contents are built only when the key is new (below)
+    size_t tab_entries = 0;
     for (int l = 1; l < prm.nlevels; ++l) {
-        OrbLevel &Lv = d.level[l];
-        const OrbLevel &Pv = d.level[l - 1];
-        Lv.tab_offset = tab.size();
-        for (int pass = 0; pass < 2; ++pass) {
-            const long long sn = pass ? Pv.h : Pv.w, dn = pass ? Lv.h : Lv.w;
-            for (long long dd = 0; dd < dn; ++dd) {
-                const long long num = (2 * dd + 1) * sn - dn, den = 2 * dn;   // source coordinate = num / den (>= 0 here)
-                long long si = num >= 0 ? num / den : -1;
-                const long long fr = num - si * den;
-                int wgt = (int)((fr * 4096 + den) / (2 * den));               // round(frac * 2048)
-                if (si < 0) si = 0, wgt = 0;
-                if (si >= sn - 1) si = sn - 1;
-                tab.push_back(make_int2((int)si, wgt));
+        d.level[l].tab_offset = tab_entries;
+        tab_entries += (size_t)std::max(d.level[l].w, 0) + (size_t)std::max(d.level[l].h, 0);
+    }
+    auto build_tab = [&](std::vector<int2> &tab) {
+        tab.reserve(tab_entries);
+        for (int l = 1; l < prm.nlevels; ++l) {
+            const OrbLevel &Lv = d.level[l], &Pv = d.level[l - 1];
+            for (int pass = 0; pass < 2; ++pass) {
+                const long long sn = pass ? Pv.h : Pv.w, dn = pass ? Lv.h : Lv.w;
+                for (long long dd = 0; dd < dn; ++dd) {
+                    const long long num = (2 * dd + 1) * sn - dn, den = 2 * dn;   // source coordinate = num / den (>= 0 here)
+                    long long si = num >= 0 ? num / den : -1;
+                    const long long fr = num - si * den;
+                    int wgt = (int)((fr * 4096 + den) / (2 * den));               // round(frac * 2048)
+                    if (si < 0) si = 0, wgt = 0;
+                    if (si >= sn - 1) si = sn - 1;
+                    tab.push_back(make_int2((int)si, wgt));
+                }
             }
         }
-    }
-    const size_t o_tab = off; off = up(off + std::max<size_t>(tab.size(), 1) * sizeof(int2));
+    };
+    const size_t o_tab = off; off = up(off + std::max<size_t>(tab_entries, 1) * sizeof(int2));
     const size_t o_keys = off; off = up(off + B * L * kOrbCandCap * 8);
     const size_t o_cc = off; off = up(off + B * L * 4);
     const size_t o_sel = off; off = up(off + B * L * NF * sizeof(OrbSel));
@@ -3069,6 +3075,9 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     d.edge = prm.edge_threshold;
     d.fast_threshold = prm.fast_threshold;
     d.cand_cap = kOrbCandCap;
+#ifdef MVS_DEBUG_HOOKS
+    d.flat_order = std::getenv("MVS_ORB_FLAT_ORDER") != nullptr;   // A/B of the describe kernel's block order (tools/profile_extract.sh)
+#endif
     d.pyr = reinterpret_cast<uint8_t *>(base + o_pyr);
     d.blur = reinterpret_cast<uint8_t *>(base + o_blur);
     d.resize_tab = reinterpret_cast<const int2 *>(base + o_tab);
@@ -3088,8 +3097,10 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     // graph finds them in the workspace (round 5: they were uploaded, and the stream synchronised for them, on every call)
     const bool same_key = ctx->orb_graph_valid && std::memcmp(&ctx->orb_graph_key, &d, sizeof(d)) == 0;
     int8_t pat[1024];
+    std::vector<int2> tab;
     if (!same_key) {
         orb_pattern_host(pat);
+        build_tab(tab);
         HIP_TRY(ctx, hipMemcpyAsync(base + o_pat, pat, sizeof(pat), hipMemcpyHostToDevice, s));
         if (!tab.empty())
             HIP_TRY(ctx, hipMemcpyAsync(base + o_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, s));

@@ -240,7 +240,7 @@ void launch_refine_gather(const BatchDev &b, int n_active, double sigma_px, doub
 
 // ---- VisualFeature::extract (row f3): ORB-style extraction for a batch of equally sized images ----------------
 constexpr int kOrbMaxLevels = 16;
-constexpr int kOrbCandCap = 16384;   // corners per (image, level) after non-maximum suppression (128 KB of LDS keys)
+constexpr int kOrbCandCap = 16384;   // corners per (image, level) after non-maximum suppression (the list the radix select reads)
 
 struct OrbLevel {
     int w, h;
@@ -255,6 +255,8 @@ struct OrbSel {        // a selected keypoint of one level
 };
 struct OrbDev {
     int n_images, n_levels, nfeatures, edge, fast_threshold, cand_cap;
+    int flat_order;        // 0: XCD-aware block order of describe_kernel (the product); 1: (level, image, split) as in rounds 2-4 --
+                           // only the diagnostics build can set it (MVS_ORB_FLAT_ORDER, tools/profile_extract.sh: the A/B of DESIGN 4.8)
     OrbLevel level[kOrbMaxLevels];
     uint8_t *pyr;          // [level][image][h_l][w_l]; level 0 = the input images
     uint8_t *blur;         // same layout: blurred levels

@@ -5,13 +5,14 @@
 // pipeline with the reference's parameters and the build's own, fully specified choices where OpenCV's are out of
 // reach (the CPU oracle oracle/mvs_orb_oracle.c follows the same specification bit for bit):
 //   resize_kernel    level l from level l-1: pixel-centre bilinear in integer arithmetic (11-bit weights from exact
-//                    rationals, (sum + 2^21) >> 22)                                           thread per pixel
+//                    rationals, (sum + 2^21) >> 22)                                  four adjacent pixels per thread
 //   fast_nms_kernel  ONE launch over the tiles of every level.  FAST-9/16 score (the largest threshold at which the pixel
-//                    is still a corner) and the strict 3x3 maximum of one 64x16 tile through LDS: the cheap antipodal test
-//                    runs for every pixel, the pixels that pass it are COMPACTED into an LDS list and only those get the
-//                    full 16-pixel arc minimum, on dense lanes (round 5; before, one passing lane made its whole wavefront
-//                    pay the full score) -> rank key (score desc, y, x), one atomic per tile; the ORDER of the list does
-//                    not matter, the select kernel ranks it
+//                    is still a corner) and the strict 3x3 maximum of one 64x16 tile through LDS: a cheap pre-test (two
+//                    adjacent compass points both brighter or both darker) runs for every pixel, the pixels that pass
+//                    it are COMPACTED into an LDS list and only those get the full 16-pixel arc minimum, on dense lanes
+//                    (round 5; before, one passing lane made its whole wavefront pay the full score) -> rank key
+//                    (score desc, y, x), one atomic per tile; the ORDER of the list does not matter, the select kernel
+//                    ranks it
 //   select_kernel    one launch, one workgroup per (image, level): the 2 n_l best FAST scores by a RADIX SELECT over the
 //                    key bytes (five 256-bin histogram passes give the exact cut-off key; round 5 -- before, a bitonic
 //                    sort of all <= 16384 candidates in 128 KB of LDS), Harris response (7x7, k = 0.04) of those from a
@@ -163,6 +164,25 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *c, int P, int thres
     return sc >= threshold ? sc : 0;
 }
 
+// Block order of the tiled kernels (round 5).  Workgroups go round-robin to the eight XCDs, each with its own L2.  The first
+// 8 * floor(n_images / 8) images are owned by XCDs: XCD x = block mod 8 takes the images b = x (mod 8) and receives an image's
+// blocks one after the other (what they share -- halo rows, 128-byte lines, a keypoint's windows -- meets in one L2).  The
+// remaining n_images mod 8 images (all of them when a call brings fewer than eight -- one frame per call is the reference's own
+// pattern, vision/visual-feature.cpp:40) are spread over ALL XCDs block by block: owning them would leave most of the chip idle.
+// per_image: blocks one image needs.  Returns the image; seq = the block's index among that image's blocks.
+__device__ __forceinline__ int orb_block_image(int bid, int n_images, int per_image, int &seq)
+{
+    const int full = n_images & ~7, owned = full * per_image;
+    if (bid < owned) {
+        const int s = bid >> 3;
+        seq = s % per_image;
+        return (s / per_image) * 8 + (bid & 7);
+    }
+    const int rest = n_images - full, r = bid - owned;   // (the grid has exactly n_images * per_image blocks: rest > 0 here)
+    seq = r / rest;
+    return full + r % rest;
+}
+
 // FAST + non-maximum suppression of one 64 x 16 tile through LDS: the image patch (tile + 4) is read from HBM once (as
 // unaligned dwords: columns past the row's end belong to pixels whose score is never taken), the scores of (tile + 1) never
 // leave the CU, and the surviving corners are appended with ONE atomic per tile (all corners of a level append to the same
@@ -183,13 +203,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(OrbDev d, OrbGrid g, int 
     __shared__ int s_n;
     __shared__ int wave_off[4];
     __shared__ int tile_base;
-    // block order: XCD x = block % 8 owns the images b = x (mod 8) and walks their tiles in order -- neighbouring tiles
-    // share halo rows and 128-byte lines, and an XCD's L2 sees them together
-    // (a launch covers tiles [tile_first, tile_first + n_tiles) of the flattened list: launch_orb)
-    const int seq = blockIdx.x >> 3, tile = tile_first + seq % n_tiles;
-    const int b = (seq / n_tiles) * 8 + (blockIdx.x & 7), tid = threadIdx.x;
-    if (b >= d.n_images)
-        return;
+    // (block order: orb_block_image; a launch covers tiles [tile_first, tile_first + n_tiles) of the flattened list: launch_orb)
+    int seq;
+    const int b = orb_block_image(blockIdx.x, d.n_images, n_tiles, seq), tile = tile_first + seq, tid = threadIdx.x;
     int level = 0;
     while (level + 1 < d.n_levels && tile >= g.fast_start[level + 1])
         ++level;
@@ -486,10 +502,8 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbDev d, OrbGrid g, int tile
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PH * PW];
     __shared__ __attribute__((aligned(16))) uint16_t s_row[PH * kTileW];
     const int tid = threadIdx.x;
-    const int seq = blockIdx.x >> 3, tile = tile_first + seq % n_tiles;   // (block order and tile range: fast_nms_kernel)
-    const int b = (seq / n_tiles) * 8 + (blockIdx.x & 7);
-    if (b >= d.n_images)
-        return;
+    int seq;   // (block order and tile range: fast_nms_kernel)
+    const int b = orb_block_image(blockIdx.x, d.n_images, n_tiles, seq), tile = tile_first + seq;
     int level = 0;
     while (level + 1 < d.n_levels && tile >= g.blur_start[level + 1])
         ++level;
@@ -529,21 +543,16 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbDev d, OrbGrid g, int tile
         const int py = i / (kTileW / 4), q = i - py * (kTileW / 4);
         const uint32_t *w = reinterpret_cast<const uint32_t *>(s_img + py * PW + 4 * q);
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        int p[12];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            p[k] = (w0 >> (8 * k)) & 0xff;
-            p[4 + k] = (w1 >> (8 * k)) & 0xff;
-            p[8 + k] = (w2 >> (8 * k)) & 0xff;
-        }
+        // output o = taps 0-3 against bytes o .. o+3 and taps 4-6 against bytes o+4 .. o+6: two v_dot4_u32_u8 on byte windows
+        // cut out of (w0, w1, w2) by v_alignbyte (round 5: 14 instructions for the four outputs instead of 12 byte
+        // extractions + 28 multiply-adds; sums of products of integers: the same numbers)
+        constexpr uint32_t g03 = 18u | (34u << 8) | (49u << 16) | (54u << 24), g46 = 49u | (34u << 8) | (18u << 16);
         uint32_t r[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            int sum = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-                sum += kGauss[k] * p[o + k];
-            r[o] = (uint32_t)sum;
+            const uint32_t a = o ? __builtin_amdgcn_alignbyte(w1, w0, o) : w0;
+            const uint32_t b = o ? __builtin_amdgcn_alignbyte(w2, w1, o) : w1;
+            r[o] = __builtin_amdgcn_udot4(b, g46, __builtin_amdgcn_udot4(a, g03, 0u, false), false);
         }
         uint2 pack;
         pack.x = r[0] | (r[1] << 16);
@@ -611,7 +620,7 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// grid 8 x kDescSplit x n_levels x ceil(n_images / 8) (see the block order below), 256 threads = 4 wavefronts, ONE keypoint
+// grid kDescSplit x n_levels x n_images (see the block order below), 256 threads = 4 wavefronts, ONE keypoint
 // per wavefront at a time (round 5).
 // History: half a wavefront per keypoint with byte loads straight from the level (moments: a loop of two dependent byte
 // loads per lane and step; tests: 16 byte loads per lane) took 0.39 ms per 64 frames against 0.08 of issue time -- it waited
@@ -634,17 +643,19 @@ static_assert(kBWords * 4 <= kDescImgOff && kDescImgOff + kIWords * 4 <= kDescWa
 __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescWaveLds];
-    // XCD-aware block order.  Workgroups go round-robin to the eight XCDs, each with its own L2, and a keypoint's windows
-    // touch 68 rows of 128-byte lines for 40 + 32 useful bytes each: with the blocks of one (image, level) spread over the
-    // XCDs every XCD pulled every line through the fabric (~1 GB per 64 frames -- what the kernel's time was), and with the
-    // level as the fastest block index one XCD had all of level 0, a fifth of the keypoints.  Now XCD x = block % 8 owns the
-    // images b = x (mod 8), and the blocks it receives walk z, then the level, then the image: the workgroups that share a
-    // level image run together on the XCD whose L2 holds it.
-    const int bid = blockIdx.x, xcd = bid & 7, seq = bid >> 3;
-    const int zsplit = seq % kDescSplit, level = (seq / kDescSplit) % d.n_levels;
-    const int b = (seq / (kDescSplit * d.n_levels)) * 8 + xcd;
-    if (b >= d.n_images)
-        return;
+    // Block order (orb_block_image).  A keypoint's windows touch 68 rows of 128-byte lines for 40 + 32 useful bytes each: with
+    // the blocks of one (image, level) spread over the XCDs every XCD pulled every line through the fabric (~1 GB per 64 frames
+    // -- what the kernel's time was in rounds 2-4), and with the level as the fastest block index one XCD had all of level
+    // 0, a fifth of the keypoints.  Now the blocks of an image walk the split, then the level, on the XCD that owns the image.
+    int seq;
+    int b = orb_block_image(blockIdx.x, d.n_images, kDescSplit * d.n_levels, seq);
+    int zsplit = seq % kDescSplit, level = seq / kDescSplit;
+    if (d.flat_order) {   // diagnostics only: the level as the fastest index, then the image, then the split (rounds 2-4)
+        const int bid = blockIdx.x;
+        level = bid % d.n_levels;
+        b = (bid / d.n_levels) % d.n_images;
+        zsplit = bid / (d.n_levels * d.n_images);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const OrbLevel &L = d.level[level];
     const size_t slot0 = (size_t)b * d.n_levels;
@@ -857,14 +868,13 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
         g.blur_start[l + 1] += g.blur_tx[l] * ((L.h + kBlurH - 1) / kBlurH);
         max_keep = std::max(max_keep, L.n_keep);
     }
-    const int b8 = (B + 7) / 8;
     auto detect = [&](int first_level, int end_level, hipStream_t st) {   // FAST + NMS and blur of levels [first, end)
         const int f0 = g.fast_start[first_level], fn = g.fast_start[end_level] - f0;
         const int b0 = g.blur_start[first_level], bn = g.blur_start[end_level] - b0;
         if (fn > 0)
-            hipLaunchKernelGGL(fast_nms_kernel, dim3(8 * fn * b8), dim3(256), 0, st, d, g, f0, fn);
+            hipLaunchKernelGGL(fast_nms_kernel, dim3(fn * B), dim3(256), 0, st, d, g, f0, fn);
         if (bn > 0)
-            hipLaunchKernelGGL(blur_kernel, dim3(8 * bn * b8), dim3(256), 0, st, d, g, b0, bn);
+            hipLaunchKernelGGL(blur_kernel, dim3(bn * B), dim3(256), 0, st, d, g, b0, bn);
     };
     // the pyramid (level l from level l - 1), then ONE launch each for FAST + NMS and the blur over the tiles of every level
     const dim3 blk(32, 8);
@@ -880,7 +890,7 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
         sel_keys <<= 1;
     hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), sel_keys * sizeof(uint64_t), stream,
                        d);   // LDS limit raised in orb_prepare()
-    hipLaunchKernelGGL(describe_kernel, dim3(8 * kDescSplit * d.n_levels * ((B + 7) / 8)), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(describe_kernel, dim3(kDescSplit * d.n_levels * B), dim3(256), 0, stream, d);
 }
 
 }  // namespace mvs
