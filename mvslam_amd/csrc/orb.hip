@@ -620,7 +620,7 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// grid kDescSplit x n_levels x n_images (see the block order below), 256 threads = 4 wavefronts, ONE keypoint
+// grid split x n_levels x n_images (see the block order below), 256 threads = 4 wavefronts, ONE keypoint
 // per wavefront at a time (round 5).
 // History: half a wavefront per keypoint with byte loads straight from the level (moments: a loop of two dependent byte
 // loads per lane and step; tests: 16 byte loads per lane) took 0.39 ms per 64 frames against 0.08 of issue time -- it waited
@@ -634,13 +634,14 @@ __device__ __forceinline__ void wave_lds_sync()
 //                   (1 + 2^-22)) = 18 (the pattern is clipped to +-13 per axis; edge_threshold >= 19 keeps the window
 //                   inside the level); lane l evaluates tests 4 l .. 4 l + 3, the nibbles meet through three shuffles and
 //                   the descriptor leaves as eight dwords
-constexpr int kDescSplit = 8;
+constexpr int kDescSplit = 8, kDescSplitFew = 32;   // workgroups per (image, level): 8 in a batch; 32 when a call brings fewer than
+                                                    // eight frames (one frame: 64 workgroups would leave three quarters of the CUs idle)
 constexpr int kBR = 18, kBRows = 2 * kBR + 1, kBPitch = 40, kBWords = kBRows * kBPitch / 4;   // 370 dwords
 constexpr int kIRows = 31, kIPitch = 32, kIWords = kIRows * kIPitch / 4;                      // 248 dwords
 constexpr int kBLoads = (kBWords + 63) / 64, kILoads = (kIWords + 63) / 64;                   // 6 + 4 loads per lane
 constexpr int kDescImgOff = 1536, kDescWaveLds = 2560;
 static_assert(kBWords * 4 <= kDescImgOff && kDescImgOff + kIWords * 4 <= kDescWaveLds, "describe_kernel LDS layout");
-__global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
+__global__ __launch_bounds__(256) void describe_kernel(OrbDev d, int split)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescWaveLds];
     // Block order (orb_block_image).  A keypoint's windows touch 68 rows of 128-byte lines for 40 + 32 useful bytes each: with
@@ -648,8 +649,8 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
     // -- what the kernel's time was in rounds 2-4), and with the level as the fastest block index one XCD had all of level
     // 0, a fifth of the keypoints.  Now the blocks of an image walk the split, then the level, on the XCD that owns the image.
     int seq;
-    int b = orb_block_image(blockIdx.x, d.n_images, kDescSplit * d.n_levels, seq);
-    int zsplit = seq % kDescSplit, level = seq / kDescSplit;
+    int b = orb_block_image(blockIdx.x, d.n_images, split * d.n_levels, seq);
+    int zsplit = seq % split, level = seq / split;
     if (d.flat_order) {   // diagnostics only: the level as the fastest index, then the image, then the split (rounds 2-4)
         const int bid = blockIdx.x;
         level = bid % d.n_levels;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbDev d)
     // three keypoints in flight per wavefront: this one (windows in LDS), the next one (its windows travelling into
     // registers) and the one after (its record travelling: the windows' addresses depend on it, and a wait for it at the
     // head of the window loads would expose one load round trip per keypoint)
-    const int step = 4 * kDescSplit;
+    const int step = 4 * split;
     int i = 4 * zsplit + wave;
     uint32_t nb[kBLoads], ni[kILoads];
     Sel cur{}, nxt{};
@@ -890,7 +891,8 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
         sel_keys <<= 1;
     hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), sel_keys * sizeof(uint64_t), stream,
                        d);   // LDS limit raised in orb_prepare()
-    hipLaunchKernelGGL(describe_kernel, dim3(kDescSplit * d.n_levels * B), dim3(256), 0, stream, d);
+    const int split = B >= 8 ? kDescSplit : kDescSplitFew;
+    hipLaunchKernelGGL(describe_kernel, dim3(split * d.n_levels * B), dim3(256), 0, stream, d, split);
 }
 
 }  // namespace mvs
