@@ -137,6 +137,8 @@ __device__ __forceinline__ bool fast_maybe(const uint8_t *c, int P, int threshol
 // Measured and not kept: TWO adjacent pixels per lane in the two halves (ring values and complements through two
 // networks, 215 instructions per pair) for EVERY pixel, without pre-test and list -- bit-identical, 0.26 against 0.24 ms per
 // 64 frames on the textured bench frames (a third of whose pixels pass the pre-test; real frames pass far fewer).
+// Also measured and not kept: the non-maximum suppression over the list's entries with an LDS survivor list instead of
+// four output pixels per thread (0.2436 against 0.2439 ms: the suppression was never the cost).
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int fast_score_lds(const uint8_t *c, int P, int threshold)
 {
