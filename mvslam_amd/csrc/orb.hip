@@ -378,6 +378,7 @@ __device__ void bitonic_sort(uint64_t *k, int n)
 
 using Sel = OrbSel;
 
+constexpr int kSelTieCap = 1024;   // candidates that share the FAST score at the cut (select_kernel's fast path)
 // grid (n_images, n_levels): all levels of all images in one launch (one launch per level left 3/4 of the CUs idle).
 // Dynamic LDS: room for the next power of two above 2 max(n_l) keys (launch_orb).
 // retainBest(2 n_l) by FAST score needs the SET of the 2 n_l smallest keys, not their order: a radix select over the five
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
 {
     extern __shared__ uint64_t keys[];
     __shared__ int hist[256];
-    __shared__ int s_bin, s_k, s_cnt;
+    __shared__ int s_bin, s_k, s_hbin, s_cnt, s_tcnt;
+    __shared__ uint32_t s_tie[kSelTieCap];
     const int b = blockIdx.x, level = blockIdx.y;
     const OrbLevel &L = d.level[level];
     if (L.w <= 2 * d.edge || L.h <= 2 * d.edge || L.n_keep < 1)
@@ -398,71 +400,126 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
     const int c = min(found, d.cand_cap);
     const uint64_t *src = d.cand_keys + slot * d.cand_cap;
     const int keep1 = min(c, 2 * L.n_keep);
-    uint64_t kstar = ~0ull;   // the keep1-th smallest key
-    if (keep1 < c) {          // (uniform)
-        uint64_t prefix = 0, mask = 0;
-        int k = keep1;
-        for (int byte = 4; byte >= 0; --byte) {
-            if (tid < 256)
-                hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < c; i += 1024) {
-                const uint64_t key = src[i];
-                if ((key & mask) == prefix)
-                    atomicAdd(&hist[(int)(key >> (8 * byte)) & 255], 1);
-            }
-            __syncthreads();
-            if (tid < 64) {   // one wavefront: lane l owns bins 4 l .. 4 l + 3
-                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                const int sum = (h0 + h1) + (h2 + h3);
-                int incl = sum;
+    // one histogram pass over a key byte among the keys that match (prefix, mask): the bin that holds the k-th smallest of
+    // them, k reduced to the rank inside that bin, the bin's population
+    uint64_t prefix = 0, mask = 0;
+    int k = keep1;
+    auto radix_pass = [&](int byte) {
+        if (tid < 256)
+            hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < c; i += 1024) {
+            const uint64_t key = src[i];
+            if ((key & mask) == prefix)
+                atomicAdd(&hist[(int)(key >> (8 * byte)) & 255], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {   // one wavefront: lane l owns bins 4 l .. 4 l + 3
+            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const int sum = (h0 + h1) + (h2 + h3);
+            int incl = sum;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(incl, o, 64);
-                    if (lane >= o)
-                        incl += up;
-                }
-                const int excl = incl - sum;
-                if (excl < k && k <= incl) {   // exactly one lane: the matching keys number at least k
-                    int r = k - excl, bin = 4 * tid;
-                    if (r > h0) {
-                        r -= h0, ++bin;
-                        if (r > h1) {
-                            r -= h1, ++bin;
-                            if (r > h2)
-                                r -= h2, ++bin;
-                        }
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o)
+                    incl += up;
+            }
+            const int excl = incl - sum;
+            if (excl < k && k <= incl) {   // exactly one lane: the matching keys number at least k
+                int r = k - excl, bin = 4 * tid, hb = h0;
+                if (r > h0) {
+                    r -= h0, ++bin, hb = h1;
+                    if (r > h1) {
+                        r -= h1, ++bin, hb = h2;
+                        if (r > h2)
+                            r -= h2, ++bin, hb = h3;
                     }
-                    s_bin = bin;
-                    s_k = r;
+                }
+                s_bin = bin;
+                s_k = r;
+                s_hbin = hb;
+            }
+        }
+        __syncthreads();
+        prefix |= (uint64_t)(uint32_t)s_bin << (8 * byte);
+        mask |= 0xffull << (8 * byte);
+        k = s_k;
+        // (the next pass's barrier behind the histogram reset orders these reads before the next writes of s_bin / s_k)
+    };
+    uint64_t kstar = ~0ull;   // the keep1-th smallest key (general path)
+    bool filled = false;      // keys[0 .. keep1) already holds the selection (tie-class path)
+    if (tid == 0) {
+        s_cnt = 0;
+        s_tcnt = 0;
+    }
+    if (keep1 < c) {          // (uniform)
+        radix_pass(4);        // the score byte: every key in a lower bin is in, the bin s_bin contributes its k smallest (y, x)
+        const int n_tie = s_hbin;
+        if (n_tie <= kSelTieCap) {
+            // The usual case: the score at the cut is shared by a few dozen corners.  ONE more pass sorts the candidates into
+            // "better score" (straight into the selection) and "tie class" (an LDS list of their (y, x) words); the k smallest
+            // of the tie class are found by counting, each key's rank among its class (keys are unique).  Before: four more
+            // histogram passes over all candidates for the (y, x) bytes and a compaction pass.
+            const uint32_t cut = (uint32_t)s_bin;
+            for (int i0 = 0; i0 < c; i0 += 1024) {
+                const int i = i0 + tid;
+                const uint64_t key = i < c ? src[i] : ~0ull;
+                const uint32_t digit = (uint32_t)(key >> 32) & 255u;
+                const bool better = i < c && digit < cut, tie = i < c && digit == cut;
+                const unsigned long long mb = __ballot(better), mt = __ballot(tie);
+                if (mb) {
+                    int base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&s_cnt, __popcll(mb));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (better)
+                        keys[base + __popcll(mb & ((1ull << lane) - 1ull))] = key;
+                }
+                if (mt) {
+                    int base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&s_tcnt, __popcll(mt));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (tie)
+                        s_tie[base + __popcll(mt & ((1ull << lane) - 1ull))] = (uint32_t)key;
                 }
             }
-            __syncthreads();
-            prefix |= (uint64_t)(uint32_t)s_bin << (8 * byte);
-            mask |= 0xffull << (8 * byte);
-            k = s_k;
-            // (the next pass's barrier behind the histogram reset orders these reads before the next writes of s_bin / s_k)
+            __syncthreads();   // s_cnt == keep1 - k, s_tcnt == n_tie
+            const int n_better = s_cnt;
+            const uint64_t hi = (uint64_t)(0xffffff00u | cut) << 32;
+            for (int t = tid; t < n_tie; t += 1024) {
+                const uint32_t mine = s_tie[t];
+                int rank = 0;
+                for (int j = 0; j < n_tie; ++j)
+                    rank += s_tie[j] < mine ? 1 : 0;
+                if (rank < k)
+                    keys[n_better + rank] = hi | mine;
+            }
+            filled = true;
+        } else {
+            for (int byte = 3; byte >= 0; --byte)
+                radix_pass(byte);
+            kstar = prefix | 0xffffff0000000000ull;   // the high word of a key is 0xffffffff - score, score <= 255
         }
-        kstar = prefix | 0xffffff0000000000ull;   // the high word of a key is 0xffffffff - score, score <= 255
     }
-    if (tid == 0)
-        s_cnt = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < c; i0 += 1024) {
-        const int i = i0 + tid;
-        const uint64_t key = i < c ? src[i] : ~0ull;
-        const bool take = i < c && key <= kstar;
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            int base = 0;
-            if (lane == 0)
-                base = atomicAdd(&s_cnt, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (take)
-                keys[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+    if (!filled) {            // (uniform) everything at or below the cut-off key -- or everything, when nothing is cut
+        for (int i0 = 0; i0 < c; i0 += 1024) {
+            const int i = i0 + tid;
+            const uint64_t key = i < c ? src[i] : ~0ull;
+            const bool take = i < c && key <= kstar;
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                int base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&s_cnt, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (take)
+                    keys[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
         }
     }
-    __syncthreads();   // s_cnt == keep1
+    __syncthreads();   // keys[0 .. keep1) = the selection
     // Harris on the survivors, then the order by (response desc, y, x)
     int n2 = 1;
     while (n2 < keep1)
