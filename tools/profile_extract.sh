@@ -13,7 +13,7 @@ for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_
   D=$O/pmc_$(echo $G | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $D -o p -- $B > $D.json 2> $D.err || { echo "pmc pass failed: $G"; tail -3 $D.err; }
 done
-python3 tools/pmc_summary.py $O/extract_pmc_summary.json 64 $O/pmc_*
+python3 tools/extract_pmc_summary.py $O/extract_pmc_summary.json $(ls -d $O/pmc_* | grep -v "\.")
 # A/B of describe_kernel's block order: the diagnostics library with MVS_ORB_FLAT_ORDER runs the (level, image,
 # split) order of rounds 2-4, without it the XCD-aware order of the product; kernel times and fetched bytes of both
 export MVS_USE_DEBUG_LIB=1
