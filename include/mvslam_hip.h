@@ -468,8 +468,9 @@ typedef struct mvs_keypoint { /* layout of cv::KeyPoint (base/image.hpp:37-48 De
 void mvs_orb_params_default(mvs_orb_params *p);
 /* images: n_images x height x width grayscale (CV_8UC1, continuous), host.  keypoints: n_images x nfeatures,
  * descriptors: n_images x nfeatures x 32, n_keypoints: n_images (rows [0, n_keypoints[i]) are valid; ordered by
- * pyramid level, then response descending).  MVS_ERR_CAPACITY if a level has more corners than the candidate list
- * holds (16384) or the image is larger than 65535 in a dimension. */
+ * pyramid level, then response descending).  MVS_ERR_CAPACITY if the image is larger than 65535 in a dimension, or -- only
+ * when a level's quota exceeds 8192 features (the selection holds 2 n_l <= 16384 keys in LDS) -- if that level has more than
+ * 16384 corners; otherwise a level's candidate list holds every corner the non-maximum suppression can leave (round 5). */
 mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int width, int height,
                        const mvs_orb_params *params, mvs_keypoint *keypoints, uint8_t *descriptors,
                        int32_t *n_keypoints);

@@ -3018,7 +3018,7 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
         return MVS_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->orb_ready) {
-        HIP_TRY(ctx, orb_prepare(kOrbCandCap));
+        HIP_TRY(ctx, orb_prepare());
         ctx->orb_ready = true;
     }
     const size_t B = (size_t)n, L = (size_t)prm.nlevels, NF = (size_t)prm.nfeatures;
@@ -3052,7 +3052,27 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
         }
     };
     const size_t o_tab = off; off = up(off + std::max<size_t>(tab_entries, 1) * sizeof(int2));
-    const size_t o_keys = off; off = up(off + B * L * kOrbCandCap * 8);
+    // candidate lists: a level's list holds the non-maximum suppression's own bound -- strict 3x3 maxima of the detection
+    // area, at most one per 2x2 block -- so it cannot overflow; only when 2 n_l exceeds what the selection holds in LDS the
+    // list is capped there (and a fuller level is reported as MVS_ERR_CAPACITY, as every level was in rounds 2-4)
+    int max_keep = 0;
+    for (int l = 0; l < prm.nlevels; ++l)
+        max_keep = std::max(max_keep, d.level[l].n_keep);
+    size_t cand_total = 0;
+    for (int l = 0; l < prm.nlevels; ++l) {
+        OrbLevel &Lv = d.level[l];
+        const long long dw = (long long)Lv.w - 2 * prm.edge_threshold, dh = (long long)Lv.h - 2 * prm.edge_threshold;
+        long long cap = dw > 0 && dh > 0 ? ((dw + 1) / 2) * ((dh + 1) / 2) + 64 : 64;
+        if (2LL * max_keep > kOrbSelCap)
+            cap = std::min<long long>(cap, kOrbSelCap);
+        if (cap > 0x7fffffff)
+            return MVS_ERR_CAPACITY;
+        Lv.cand_cap = (int)cap;
+        Lv.cand_off = cand_total;
+        cand_total += (size_t)cap;
+    }
+    d.cand_stride = cand_total;
+    const size_t o_keys = off; off = up(off + B * cand_total * 8);
     const size_t o_cc = off; off = up(off + B * L * 4);
     const size_t o_sel = off; off = up(off + B * L * NF * sizeof(OrbSel));
     const size_t o_sc = off; off = up(off + B * L * 4);
@@ -3074,7 +3094,6 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
     d.nfeatures = prm.nfeatures;
     d.edge = prm.edge_threshold;
     d.fast_threshold = prm.fast_threshold;
-    d.cand_cap = kOrbCandCap;
 #ifdef MVS_DEBUG_HOOKS
     d.flat_order = std::getenv("MVS_ORB_FLAT_ORDER") != nullptr;   // A/B of the describe kernel's block order (tools/profile_extract.sh)
 #endif

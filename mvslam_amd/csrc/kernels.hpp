@@ -240,7 +240,8 @@ void launch_refine_gather(const BatchDev &b, int n_active, double sigma_px, doub
 
 // ---- VisualFeature::extract (row f3): ORB-style extraction for a batch of equally sized images ----------------
 constexpr int kOrbMaxLevels = 16;
-constexpr int kOrbCandCap = 16384;   // corners per (image, level) after non-maximum suppression (the list the radix select reads)
+constexpr int kOrbSelCap = 16384;    // keys of one (image, level) the selection can hold in LDS (128 KB): 2 n_l <= this, or the
+                                     // level's candidate list is capped at it (then, and only then, a level can overflow)
 
 struct OrbLevel {
     int w, h;
@@ -248,24 +249,28 @@ struct OrbLevel {
     float scale;       // 1.2^l
     size_t offset;     // pixels of one image's pyramid before this level
     size_t tab_offset; // first entry of this level's resize table (w column entries, then h row entries)
+    int cand_cap;      // capacity of the level's candidate list: the non-maximum suppression's own bound (one survivor per 2x2
+                       // block of the detection area: the list cannot overflow; round 5 -- 16384 before, MVS_ERR_CAPACITY beyond)
+    size_t cand_off;   // first key of the level inside one image's candidate block
 };
 struct OrbSel {        // a selected keypoint of one level
     int32_t x, y;
     float harris;
 };
 struct OrbDev {
-    int n_images, n_levels, nfeatures, edge, fast_threshold, cand_cap;
+    int n_images, n_levels, nfeatures, edge, fast_threshold;
+    size_t cand_stride;    // keys of one image's candidate block (sum of the levels' cand_cap)
     int flat_order;        // 0: XCD-aware block order of describe_kernel (the product); 1: (level, image, split) as in rounds 2-4 --
                            // only the diagnostics build can set it (MVS_ORB_FLAT_ORDER, tools/profile_extract.sh: the A/B of DESIGN 4.8)
     OrbLevel level[kOrbMaxLevels];
     uint8_t *pyr;          // [level][image][h_l][w_l]; level 0 = the input images
     uint8_t *blur;         // same layout: blurred levels
     const int2 *resize_tab;  // per level >= 1: {source index, 11-bit weight} per destination column and row
-    uint64_t *cand_keys;   // [image][level][cand_cap]
+    uint64_t *cand_keys;   // [image][cand_stride]: level l at cand_off, cand_cap keys
     int32_t *cand_count;   // [image][level]
     OrbSel *sel;           // [image][level][nfeatures]
     int32_t *sel_count;    // [image][level]
-    int32_t *overflow;     // [1] set when a level had more than cand_cap corners
+    int32_t *overflow;     // [1] set when a level had more than cand_cap corners (possible only for capped lists, see kOrbSelCap)
     const int8_t *pattern; // [256][4]
     mvs_keypoint *kp;      // [image][nfeatures]
     uint8_t *desc;         // [image][nfeatures][32]
@@ -273,7 +278,7 @@ struct OrbDev {
     float *kp_xy;          // optional [image][nfeatures][2] (the layout the matcher reads), may be null
     uint8_t *kp_oct;       // optional [image][nfeatures] octave of every keypoint (refinement weights), may be null
 };
-hipError_t orb_prepare(int cand_cap);
+hipError_t orb_prepare();
 void launch_orb(const OrbDev &d, hipStream_t stream);
 
 // ---- single-shot glue: pair 0's scalars as kernel arguments, pair 0's outputs gathered for one device-to-host copy --------

@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(OrbDev d, OrbGrid g, int 
     for (int r = 0; r < 4; ++r) {
         if (scs[r]) {
             const int idx = base + __popcll(masks[r] & ((1ull << lane) - 1ull));
-            if (idx < d.cand_cap)
-                d.cand_keys[slot * d.cand_cap + idx] = rank_key((uint32_t)scs[r], y0 + ty + 4 * r, x0 + tx);
+            if (idx < L.cand_cap)
+                d.cand_keys[(size_t)b * d.cand_stride + L.cand_off + idx] = rank_key((uint32_t)scs[r], y0 + ty + 4 * r, x0 + tx);
         }
         base += __popcll(masks[r]);
     }
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
     const int tid = threadIdx.x, lane = tid & 63;
     const size_t slot = (size_t)b * d.n_levels + level;
     const int found = d.cand_count[slot];
-    const int c = min(found, d.cand_cap);
-    const uint64_t *src = d.cand_keys + slot * d.cand_cap;
+    const int c = min(found, L.cand_cap);
+    const uint64_t *src = d.cand_keys + (size_t)b * d.cand_stride + L.cand_off;
     const int keep1 = min(c, 2 * L.n_keep);
     // one histogram pass over a key byte among the keys that match (prefix, mask): the bin that holds the k-th smallest of
     // them, k reduced to the rank inside that bin, the bin's population
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbDev d)
     }
     if (threadIdx.x == 0) {
         d.sel_count[slot] = keep2;
-        if (found > d.cand_cap)
+        if (found > L.cand_cap)
             atomicOr(d.overflow, 1);
     }
 }
@@ -894,10 +894,10 @@ __global__ void orb_clear_kernel(int32_t *count_a, int32_t *count_b, int n, int3
 
 size_t orb_sel_bytes() { return sizeof(Sel); }
 
-hipError_t orb_prepare(int cand_cap)
+hipError_t orb_prepare()
 {
     return hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)cand_cap * sizeof(uint64_t)));
+                               (int)((size_t)kOrbSelCap * sizeof(uint64_t)));
 }
 
 // Measured and not kept: level 0's FAST + blur on a second stream beside the pyramid chain (a fork inside the captured graph):
@@ -946,7 +946,7 @@ void launch_orb(const OrbDev &d, hipStream_t stream)
     }
     detect(0, d.n_levels, stream);
     size_t sel_keys = 1;
-    while (sel_keys < (size_t)std::min(2 * (long long)max_keep, (long long)d.cand_cap))
+    while (sel_keys < (size_t)std::min(2 * (long long)max_keep, (long long)kOrbSelCap))   // (orb_run caps the lists when 2 n_l is larger)
         sel_keys <<= 1;
     hipLaunchKernelGGL(select_kernel, dim3(B, d.n_levels), dim3(1024), sel_keys * sizeof(uint64_t), stream,
                        d);   // LDS limit raised in orb_prepare()

@@ -263,10 +263,19 @@ def test_gpu_extract_against_golden_and_argument_errors(ctx):
     with pytest.raises(capi.MvsError) as e:
         ctx.extract(g["image"], capi.default_orb_params(nlevels=40))
     assert e.value.status == capi.MVS_ERR_INVALID_ARG
-    # more corners at one level than the candidate list holds (16384): reported, never silently truncated
+    # round 5: a level's candidate list holds the non-maximum suppression's own bound, so a frame with far more than the
+    # 16384 corners per level that rounds 2-4 could take (~200 000 here) is simply extracted -- and equals the oracle
     noise = np.random.default_rng(0).integers(0, 256, size=(1, 1100, 1400), dtype=np.uint8)
+    prm = dict(nfeatures=100, nlevels=1, fast_threshold=5)
+    big = ctx.extract(noise, capi.default_orb_params(**prm))
+    want = o.orb_extract(noise[0], o.make_orb_params(**prm))
+    nb = int(big["n"][0])
+    assert nb == len(want["kp"]) == 100
+    assert np.array_equal(big["kp"][0][:nb], want["kp"].astype(capi.KEYPOINT_DTYPE)) and np.array_equal(big["desc"][0][:nb], want["desc"])
+    # only when 2 n_l exceeds what the selection holds in LDS (16384 keys) the list is capped there, and a fuller level is
+    # reported, never silently truncated
     with pytest.raises(capi.MvsError) as e:
-        ctx.extract(noise, capi.default_orb_params(nfeatures=100, nlevels=1, fast_threshold=5))
+        ctx.extract(noise, capi.default_orb_params(nfeatures=20000, nlevels=1, fast_threshold=5))
     assert e.value.status == capi.MVS_ERR_CAPACITY
     # ... and the context is still usable afterwards
     again = ctx.extract(g["image"], capi.default_orb_params(nfeatures=int(g["nfeatures"]), nlevels=int(g["nlevels"])))
