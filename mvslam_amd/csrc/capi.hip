@@ -40,6 +40,7 @@ struct mvs_ctx {
     void *d_ref = nullptr;      // sfm_refine / pnp_refine workspace
     size_t ref_bytes = 0;
     void *d_orb = nullptr;      // extraction workspace
+    int32_t *h_orb_ovf = nullptr;   // pinned: the extraction's overflow flag travels with the outputs (one stream wait per call)
     size_t orb_bytes = 0;
     bool orb_ready = false;
     // the ~50 launches of one extraction, captured once per (batch shape, parameters, buffers) and replayed
@@ -807,6 +808,7 @@ void mvs_ctx_destroy(mvs_ctx *ctx)
     if (ctx->d_single_in) (void)hipFree(ctx->d_single_in);
     if (ctx->orb_graph) (void)hipGraphExecDestroy(ctx->orb_graph);
     if (ctx->d_orb) (void)hipFree(ctx->d_orb);
+    if (ctx->h_orb_ovf) (void)hipHostFree(ctx->h_orb_ovf);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
@@ -3004,9 +3006,11 @@ static bool orb_layout_host(int w, int h, const mvs_orb_params &p, OrbDev &d, si
 
 // runs the extraction of n images (host pointer) through the ctx workspace; outputs go to the given DEVICE arrays
 // (desc / kp_xy / n_kp may belong to a sequence) and, when kp_rec_out is non-null, records are also left in the workspace
+// wait = false: the overflow flag's copy is queued but not waited for -- the caller queues its own downloads behind it, waits
+// once and then reads *ctx->h_orb_ovf
 static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int h, const mvs_orb_params &prm,
                           uint8_t *d_desc_ext, float *d_kp_xy_ext, int32_t *d_n_ext, OrbDev &d,
-                          uint8_t *d_kp_oct_ext = nullptr)
+                          uint8_t *d_kp_oct_ext = nullptr, bool wait = true)
 {
     if (w < 1 || h < 1 || w > 65535 || h > 65535)
         return MVS_ERR_CAPACITY;
@@ -3152,10 +3156,13 @@ static mvs_status orb_run(mvs_ctx *ctx, const uint8_t *images, int n, int w, int
         HIP_TRY(ctx, hipGraphLaunch(ctx->orb_graph, s));
     }
     HIP_TRY(ctx, hipGetLastError());
-    int32_t ovf = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&ovf, d.overflow, sizeof(ovf), hipMemcpyDeviceToHost, s));
+    if (!ctx->h_orb_ovf)
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_orb_ovf), 64, hipHostMallocDefault));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_orb_ovf, d.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!wait)
+        return MVS_OK;
     HIP_TRY(ctx, sync_stream(ctx));
-    return ovf ? MVS_ERR_CAPACITY : MVS_OK;
+    return *ctx->h_orb_ovf ? MVS_ERR_CAPACITY : MVS_OK;
 }
 
 mvs_status mvs_extract_time(mvs_ctx *ctx, int steps, float *ms_total)
@@ -3191,7 +3198,8 @@ mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int wi
     if (!ctx || !images || !params || !keypoints || !descriptors || !n_keypoints || n_images < 1)
         return MVS_ERR_INVALID_ARG;
     OrbDev d;
-    const mvs_status st = orb_run(ctx, images, n_images, width, height, *params, nullptr, nullptr, nullptr, d);
+    // one wait per call: the outputs are queued behind the launches and the overflow flag (round 5: the flag had its own wait)
+    const mvs_status st = orb_run(ctx, images, n_images, width, height, *params, nullptr, nullptr, nullptr, d, nullptr, false);
     if (st != MVS_OK)
         return st;
     const size_t B = n_images, NF = params->nfeatures;
@@ -3200,7 +3208,7 @@ mvs_status mvs_extract(mvs_ctx *ctx, const uint8_t *images, int n_images, int wi
     HIP_TRY(ctx, hipMemcpyAsync(descriptors, d.desc, B * NF * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(n_keypoints, d.n_kp, B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, sync_stream(ctx));
-    return MVS_OK;
+    return *ctx->h_orb_ovf ? MVS_ERR_CAPACITY : MVS_OK;
 }
 
 mvs_status mvs_seq_upload_images(mvs_seq *q, int first, int count, const uint8_t *images, int width, int height,
